@@ -1,0 +1,17 @@
+"""blackstar_amd -- MI355X-native drop-in for the hot path of flannelhead/blackstar: `Raytracer.render`.
+
+The product is blackstar_amd/libblackstar_gpu.so (hand-written HIP for gfx950 behind the C ABI of
+include/blackstar_gpu.h).  The Python modules mirror the reference's module interface for that path
+(ConfigFile, StarMap, Raytracer, Animation, ImageFilters) on top of the C ABI via ctypes; they contain
+no pixel arithmetic of their own and no CPU fallback.
+"""
+from . import _lib  # noqa: F401
+from .animation import Animation, Keyframe, generate_frames, validate_keyframes  # noqa: F401
+from .config_file import Camera, Config, ConfigError, Scene, prepare_scene  # noqa: F401
+from .raytracer import render, render_device, trace_rays, write_img  # noqa: F401
+from .star_map import (StarTree, build_star_tree, read_map, read_map_from_file, read_tree_from_file,  # noqa: F401
+                       star_lookup, tree_to_byte_string)
+
+__all__ = ["Animation", "Keyframe", "generate_frames", "validate_keyframes", "Camera", "Config", "ConfigError", "Scene",
+           "prepare_scene", "render", "render_device", "trace_rays", "write_img", "StarTree", "build_star_tree", "read_map",
+           "read_map_from_file", "read_tree_from_file", "star_lookup", "tree_to_byte_string"]

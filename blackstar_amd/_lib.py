@@ -1,0 +1,103 @@
+"""ctypes loader for blackstar_amd/libblackstar_gpu.so (the C ABI of include/blackstar_gpu.h).
+
+The library is the product; this module only binds it.  There is no fallback of any kind: if the
+shared object is missing, `lib()` raises, and if no HIP device is present `bs_create` fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libblackstar_gpu.so")
+
+BS_MODE_STRICT, BS_MODE_FAST = 0, 1
+
+
+class BsConfig(C.Structure):
+    """struct bs_config (include/blackstar_gpu.h)."""
+    _fields_ = [("cam_pos", C.c_double * 3), ("cam_lookat", C.c_double * 3), ("cam_up", C.c_double * 3), ("fov", C.c_double),
+                ("step_size", C.c_double), ("star_intensity", C.c_double), ("star_saturation", C.c_double),
+                ("disk_hsi", C.c_double * 3), ("disk_opacity", C.c_double), ("disk_inner", C.c_double), ("disk_outer", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32), ("supersampling", C.c_int32), ("_pad", C.c_int32)]
+
+
+class BsStats(C.Structure):
+    """struct bs_stats_t."""
+    _fields_ = [(k, C.c_uint64) for k in ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")] + \
+               [("kernel_ms", C.c_double), ("wall_ms", C.c_double)]
+
+
+# struct bs_star / struct bs_ray_record as numpy structured dtypes (same layout as the C structs)
+STAR_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("hue", "<f8"), ("sat", "<f8"), ("mag", "<i4"), ("_pad", "<i4")])
+RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4), ("steps", "<i4"), ("fate", "<i4"),
+                         ("disk_hits", "<i4"), ("star_hits", "<i4")])
+
+# every symbol include/blackstar_gpu.h declares
+SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
+           "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
+           "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup")
+
+_lib = None
+
+
+class BlackstarError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise BlackstarError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
+    L.bs_create.restype = vp
+    L.bs_create.argtypes = [C.c_int, vp, sz]
+    L.bs_destroy.restype = None
+    L.bs_destroy.argtypes = [vp]
+    L.bs_render.argtypes = [vp, C.POINTER(BsConfig), vp, sz]
+    L.bs_render_device.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
+    L.bs_render_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.bs_trace_rays.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
+    L.bs_debug_sqrt_div.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bs_star_lookup.argtypes = [vp, dp, dp, vp, sz, vp, vp]
+    L.bs_set_mode.argtypes = [vp, C.c_int]
+    L.bs_get_mode.argtypes = [vp]
+    L.bs_set_max_steps.argtypes = [vp, C.c_int]
+    L.bs_stats.argtypes = [vp, C.POINTER(BsStats)]
+    L.bs_last_error.restype = C.c_char_p
+    L.bs_read_ppm.restype = C.c_long
+    L.bs_read_ppm.argtypes = [vp, sz, vp, sz]
+    L.bs_hsi_to_rgb.argtypes = [dp, dp, dp, vp]
+    if hasattr(L, "bs_bloom_device"):
+        L.bs_bloom_device.argtypes = [vp, vp, C.c_int, C.c_int, dp, C.c_int, vp]
+        L.bs_bloom.argtypes = [vp, vp, C.c_int, C.c_int, dp, C.c_int]
+        L.bs_srgb8_device.argtypes = [vp, vp, vp, sz, vp]
+        L.bs_srgb8.argtypes = [vp, vp, vp, sz]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return (lib().bs_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise BlackstarError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def make_config(d: dict) -> BsConfig:
+    c = BsConfig()
+    for k in ("cam_pos", "cam_lookat", "cam_up", "disk_hsi"):
+        for i in range(3):
+            getattr(c, k)[i] = float(d[k][i])
+    for k in ("fov", "step_size", "star_intensity", "star_saturation", "disk_opacity", "disk_inner", "disk_outer"):
+        setattr(c, k, float(d[k]))
+    c.width, c.height, c.supersampling = int(d["width"]), int(d["height"]), int(bool(d["supersampling"]))
+    return c

@@ -1,0 +1,98 @@
+"""Animation keyframes -- host-side mirror of the reference's Animation module (src/Animation.hs).
+
+`generate_frames` restates src/Animation.hs:45-86: nFrames cameras by linear interpolation of fov,
+position, lookAt and upVec between time-sorted keyframes, t_i = i * (1 / (nFrames - 1)).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass
+from typing import Any, List
+
+import yaml
+
+from .config_file import Camera, Config, ConfigError, Scene
+
+
+@dataclass
+class Keyframe:
+    camera: Camera
+    time: float
+
+    @staticmethod
+    def decode(obj: Any) -> "Keyframe":
+        if not isinstance(obj, dict) or "camera" not in obj or "time" not in obj:
+            raise ConfigError("keyframe: keys 'camera' and 'time' are required")
+        t = obj["time"]
+        if isinstance(t, bool) or not isinstance(t, (int, float)):
+            raise ConfigError(f"keyframe.time: expected a number, got {t!r}")
+        return Keyframe(Camera.decode(obj["camera"]), float(t))
+
+
+@dataclass
+class Animation:
+    scene: Scene
+    nFrames: int
+    interpolation: str  # any string parses as Linear (src/Animation.hs:29-34)
+    keyframes: List[Keyframe]
+
+    @staticmethod
+    def decode(obj: Any) -> "Animation":
+        if not isinstance(obj, dict):
+            raise ConfigError("animation: expected an object")
+        for k in ("scene", "nFrames", "interpolation", "keyframes"):
+            if k not in obj:
+                raise ConfigError(f"animation: key {k!r} not present")
+        if isinstance(obj["nFrames"], bool) or not isinstance(obj["nFrames"], int):
+            raise ConfigError("animation.nFrames: expected Int")
+        if not isinstance(obj["interpolation"], str):
+            raise ConfigError("animation.interpolation: expected String")
+        if not isinstance(obj["keyframes"], list):
+            raise ConfigError("animation.keyframes: expected a list")
+        return Animation(Scene.decode(obj["scene"]), int(obj["nFrames"]), "linear", [Keyframe.decode(k) for k in obj["keyframes"]])
+
+    @staticmethod
+    def from_file(path: str) -> "Animation":
+        try:
+            with open(path, "r", encoding="utf-8") as f:
+                return Animation.decode(yaml.safe_load(f.read()))
+        except (OSError, yaml.YAMLError) as e:
+            raise ConfigError(str(e)) from e
+
+
+def validate_keyframes(frs: List[Keyframe]) -> None:
+    """src/Animation.hs:38-43 (raises instead of returning Left)."""
+    if len(frs) < 2:
+        raise ConfigError("Must have at least two keyframes")
+    if not (frs[0].time == 0 and frs[-1].time == 1):
+        raise ConfigError("First keyframe must have time == 0, last time == 1")
+
+
+def _interpolate(frames: List[Keyframe], t: float) -> Camera:
+    # findFrames (src/Animation.hs:63-66): first adjacent pair with time fr1 <= t < time fr2; past the end -> (last, last{time+1})
+    f1 = f2 = None
+    for a, b in zip(frames, frames[1:]):
+        if t >= a.time and t < b.time:
+            f1, f2 = a, b
+            break
+    if f1 is None:
+        f1 = frames[-1]
+        f2 = Keyframe(f1.camera, f1.time + 1)
+    tp = (t - f1.time) / (f2.time - f1.time)
+
+    def lerp(a, b):  # a + t `times` (b - a)  (src/Animation.hs:86)
+        return a + tp * (b - a)
+
+    def lerp3(a, b):
+        return tuple(lerp(x, y) for x, y in zip(a, b))
+
+    c1, c2 = f1.camera, f2.camera
+    return Camera(position=lerp3(c1.position, c2.position), lookAt=lerp3(c1.lookAt, c2.lookAt),
+                  upVec=lerp3(c1.upVec, c2.upVec), fov=lerp(c1.fov, c2.fov))
+
+
+def generate_frames(animation: Animation) -> List[Config]:
+    stepsize = 1.0 / float(animation.nFrames - 1)
+    frames = sorted(animation.keyframes, key=lambda k: k.time)  # sortBy (comparing time) is stable, like sorted()
+    points = [float(i) * stepsize for i in range(animation.nFrames)]
+    return [Config(scene=copy.deepcopy(animation.scene), camera=_interpolate(frames, p)) for p in points]

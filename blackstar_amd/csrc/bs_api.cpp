@@ -1,0 +1,340 @@
+// bs_api.cpp -- the C ABI of include/blackstar_gpu.h: context lifetime, parameter derivation, launches,
+// result / statistics read-back.  No CPU rendering path exists here: without a HIP device every render
+// entry point fails with BS_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bs_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(BS_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct bs_ctx {
+    int device = -1;
+    int mode = BS_MODE_STRICT;
+    int max_steps = 100000;
+    size_t n_stars = 0;
+    bs::StarNode *d_nodes = nullptr;
+    bs::StarColor *d_colors = nullptr;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *h_counters = nullptr;  // pinned
+    double *d_img = nullptr;                   // scratch image for bs_render (host-output variant)
+    size_t img_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // kernel start / kernel end / counters landed
+    bool pending = false;  // a render has been enqueued whose stats were not read back yet
+    uint64_t last_rays = 0;
+    double last_wall_ms = 0;
+    bs_stats_t stats{};
+};
+
+namespace {
+
+int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
+{
+    std::string err;
+    std::memset(&p, 0, sizeof p);
+    if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
+    p.max_steps = ctx->max_steps;
+    p.n_stars = (int32_t)ctx->n_stars;
+    p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
+    p.nodes = ctx->d_nodes;
+    p.colors = ctx->d_colors;
+    p.counters = ctx->d_counters;
+    return BS_OK;
+}
+
+int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_doubles, hipStream_t s)
+{
+    if (!ctx || !cfg || !d_out) return fail(BS_EINVAL, "null argument");
+    bs::TraceParams p;
+    int rc = fill_params(ctx, cfg, p);
+    if (rc) return rc;
+    if (out_doubles < (size_t)cfg->width * cfg->height * 3) return fail(BS_EINVAL, "output buffer too small");
+    p.out = d_out;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, bs::kCounters * sizeof(unsigned long long), s));
+    HIP_TRY(hipEventRecord(ctx->ev0, s));
+    if (bs::launch_trace(p, ctx->mode, s)) return fail(BS_EDEVICE, "kernel launch failed");
+    HIP_TRY(hipEventRecord(ctx->ev1, s));
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, bs::kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(ctx->ev2, s));
+    ctx->pending = true;
+    ctx->last_rays = (uint64_t)p.wt * (uint64_t)p.ht;
+    return BS_OK;
+}
+
+int resolve_stats(bs_ctx *ctx)
+{
+    if (!ctx->pending) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev2));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    bs_stats_t &st = ctx->stats;
+    st.rays = ctx->last_rays;
+    st.steps = ctx->h_counters[0];
+    st.capped = ctx->h_counters[1];
+    st.horizon = ctx->h_counters[2];
+    st.escaped = ctx->h_counters[3];
+    st.disk_hits = ctx->h_counters[4];
+    st.star_hits = ctx->h_counters[5];
+    st.kernel_ms = ms;
+    st.wall_ms = ctx->last_wall_ms;
+    ctx->pending = false;
+    return BS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bs_abi_version(void) { return BS_ABI_VERSION; }
+
+const char *bs_last_error(void) { return g_err.c_str(); }
+
+bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
+{
+    if (device < 0) { fail(BS_EDEVICE, "this library has no CPU backend: device must be a HIP device ordinal >= 0"); return nullptr; }
+    if (n_stars && !stars) { fail(BS_EINVAL, "stars is null"); return nullptr; }
+    if (n_stars >= (size_t(1) << 30)) { fail(BS_EINVAL, "too many stars"); return nullptr; }
+    for (size_t i = 0; i < n_stars; i++) {
+        double h = stars[i].hue * 2 * 3.141592653589793;
+        if (!(h >= 0 && h < 2 * 3.141592653589793)) { fail(BS_EINVAL, "HSI pixel is not properly scaled (star hue outside [0,1))"); return nullptr; }
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device >= count) {
+        fail(BS_EDEVICE, e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no such HIP device");
+        return nullptr;
+    }
+    bs_ctx *ctx = new (std::nothrow) bs_ctx();
+    if (!ctx) { fail(BS_ENOMEM, "out of host memory"); return nullptr; }
+    ctx->device = device;
+    ctx->n_stars = n_stars;
+    if (const char *m = std::getenv("BLACKSTAR_MODE")) {
+        if (!std::strcmp(m, "fast")) ctx->mode = BS_MODE_FAST;
+        else if (!std::strcmp(m, "strict")) ctx->mode = BS_MODE_STRICT;
+    }
+    std::vector<bs::StarNode> nodes;
+    std::vector<bs::StarColor> colors;
+    bs::build_star_index(stars, n_stars, nodes, colors);
+    auto ok = [&](hipError_t r, const char *what) {
+        if (r == hipSuccess) return true;
+        fail(BS_EDEVICE, std::string(what) + ": " + hipGetErrorString(r));
+        return false;
+    };
+    bool good = ok(hipSetDevice(device), "hipSetDevice") &&
+                ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+                ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev1), "hipEventCreate") &&
+                ok(hipEventCreate(&ctx->ev2), "hipEventCreate") &&
+                ok(hipMalloc((void **)&ctx->d_nodes, nodes.size() * sizeof(bs::StarNode)), "hipMalloc nodes") &&
+                ok(hipMalloc((void **)&ctx->d_colors, colors.size() * sizeof(bs::StarColor)), "hipMalloc colors") &&
+                ok(hipMalloc((void **)&ctx->d_counters, bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
+                ok(hipHostMalloc((void **)&ctx->h_counters, bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
+                ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
+                ok(hipMemcpy(ctx->d_colors, colors.data(), colors.size() * sizeof(bs::StarColor), hipMemcpyHostToDevice), "upload colors");
+    if (!good) {
+        std::string keep = g_err;
+        bs_destroy(ctx);
+        g_err = keep;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void bs_destroy(bs_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->device >= 0 && hipSetDevice(ctx->device) == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+        if (ctx->d_colors) (void)hipFree(ctx->d_colors);
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_img) (void)hipFree(ctx->d_img);
+        if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+        if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int bs_set_mode(bs_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != BS_MODE_STRICT && mode != BS_MODE_FAST)) return fail(BS_EINVAL, "bad mode");
+    ctx->mode = mode;
+    return BS_OK;
+}
+
+int bs_get_mode(const bs_ctx *ctx) { return ctx ? ctx->mode : BS_EINVAL; }
+
+int bs_set_max_steps(bs_ctx *ctx, int max_steps)
+{
+    if (!ctx || max_steps <= 0) return fail(BS_EINVAL, "bad max_steps");
+    ctx->max_steps = max_steps;
+    return BS_OK;
+}
+
+int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t out_doubles, void *hip_stream)
+{
+    return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream));
+}
+
+int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
+{
+    if (!ctx || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
+    auto t0 = std::chrono::steady_clock::now();
+    size_t need = (size_t)cfg->width * cfg->height * 3;
+    if (out_doubles < need) return fail(BS_EINVAL, "output buffer too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->img_cap < need) {
+        if (ctx->d_img) (void)hipFree(ctx->d_img);
+        ctx->d_img = nullptr;
+        ctx->img_cap = 0;
+        if (hipMalloc((void **)&ctx->d_img, need * sizeof(double)) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc image failed");
+        ctx->img_cap = need;
+    }
+    int rc = enqueue_render(ctx, cfg, ctx->d_img, need, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_rgb, ctx->d_img, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return BS_OK;
+}
+
+int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs)
+{
+    if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
+    for (int c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+    // One host thread per context (= per device); frame i goes to context i % n_ctx.  No data-path
+    // collective: frames are independent (app/Main.hs:72-77 renders them one after another).
+    std::vector<int> rcs(n_ctx, BS_OK);
+    std::vector<std::string> errs(n_ctx);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n_ctx; c++) {
+        th.emplace_back([&, c]() {
+            for (int i = c; i < n_frames; i += n_ctx) {
+                size_t need = (size_t)cfgs[i].width * cfgs[i].height * 3;
+                int rc = bs_render(ctxs[c], &cfgs[i], outs[i], need);
+                if (rc) { rcs[c] = rc; errs[c] = g_err; return; }
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n_ctx; c++)
+        if (rcs[c]) return fail(rcs[c], errs[c]);
+    return BS_OK;
+}
+
+int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out)
+{
+    if (!ctx || !cfg || (n_rays && (!yx || !out))) return fail(BS_EINVAL, "null argument");
+    bs::TraceParams p;
+    int rc = fill_params(ctx, cfg, p);
+    if (rc) return rc;
+    if (n_rays == 0) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int32_t *d_yx = nullptr;
+    bs_ray_record *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_yx, n_rays * 2 * sizeof(int32_t)));
+    if (hipMalloc((void **)&d_out, n_rays * sizeof(bs_ray_record)) != hipSuccess) {
+        (void)hipFree(d_yx);
+        return fail(BS_ENOMEM, "hipMalloc records failed");
+    }
+    hipError_t e = hipMemcpyAsync(d_yx, yx, n_rays * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && bs::launch_trace_records(p, ctx->mode, d_yx, n_rays, d_out, ctx->stream)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n_rays * sizeof(bs_ray_record), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_yx);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_trace_rays: ") + hipGetErrorString(e));
+    return BS_OK;
+}
+
+int bs_stats(bs_ctx *ctx, bs_stats_t *out)
+{
+    if (!ctx || !out) return fail(BS_EINVAL, "null argument");
+    int rc = resolve_stats(ctx);
+    if (rc) return rc;
+    ctx->stats.wall_ms = ctx->last_wall_ms;
+    *out = ctx->stats;
+    return BS_OK;
+}
+
+int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const double *dirs, size_t n, double *out_rgb, int32_t *out_hits)
+{
+    if (!ctx || (n && (!dirs || !out_rgb))) return fail(BS_EINVAL, "null argument");
+    if (n == 0) return BS_OK;
+    bs::TraceParams p;
+    std::memset(&p, 0, sizeof p);
+    p.star_intensity = intensity;
+    p.star_saturation = saturation;
+    p.star_a = std::log(2.0) / 50;
+    p.n_stars = (int32_t)ctx->n_stars;
+    p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
+    p.nodes = ctx->d_nodes;
+    p.colors = ctx->d_colors;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d = nullptr;
+    int32_t *dh = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 6 * n * sizeof(double)));
+    if (hipMalloc((void **)&dh, n * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d); return fail(BS_ENOMEM, "hipMalloc failed"); }
+    hipError_t e = hipMemcpy(d, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && bs::launch_star_lookup(p, d, n, d + 3 * n, dh, ctx->stream)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, d + 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_hits) e = hipMemcpy(out_hits, dh, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    (void)hipFree(dh);
+    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_star_lookup: ") + hipGetErrorString(e));
+    return BS_OK;
+}
+
+int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div)
+{
+    if (!ctx || (n && (!a || !b || !out_sqrt || !out_div))) return fail(BS_EINVAL, "null argument");
+    if (n == 0) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 4 * n * sizeof(double)));
+    hipError_t e = hipMemcpy(d, a, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && bs::launch_sqrt_div(d, d + n, n, d + 2 * n, d + 3 * n, ctx->stream)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_sqrt, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_div, d + 3 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_debug_sqrt_div: ") + hipGetErrorString(e));
+    return BS_OK;
+}
+
+}  // extern "C"

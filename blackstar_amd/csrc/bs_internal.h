@@ -1,0 +1,70 @@
+// Internal types shared by the host side (bs_api.cpp, star_index.cpp) and the gfx950 kernels
+// (trace_kernel.hip).  Not part of the ABI.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/blackstar_gpu.h"
+
+namespace bs {
+
+// One node of the flat k-d array: 32 B, loaded as two dwordx4 (or one ds_read_b128 pair from LDS).
+// Layout: 1-based Eytzinger order of a left-balanced k-d tree (children of i are 2i, 2i+1; the split
+// axis of a node at depth d is d % 3, mirroring kdt's `cycle (pointAsList q)`), so the top L levels are
+// the first 2^L - 1 entries and can be staged in LDS as one contiguous block.
+struct alignas(32) StarNode {
+    double x, y, z;
+    int32_t mag;  // magnitude * 100 (StarMap.hs:57)
+    int32_t id;   // index into the caller's star array (for tests / canonical ordering)
+};
+
+struct alignas(16) StarColor {
+    double hue, sat;  // starColor' (StarMap.hs:61-72), indexed like StarNode
+};
+
+constexpr int kLdsLevels = 9;                       // top levels of the k-d array staged in LDS
+constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 511 nodes * 32 B = 16352 B per workgroup
+constexpr int kCounters = 8;                        // steps, capped, horizon, escaped, disk_hits, star_hits
+
+// Everything the trace kernel needs, passed by value as the kernel argument (lands in SGPRs / kernarg).
+struct TraceParams {
+    double cam[3];
+    double xa[3], ya[3], za[3];  // look-at basis, computed once on the host with the reference's op order
+    double fov, W, H;            // traced resolution as doubles (cfg' of Raytracer.hs:63)
+    double h, hh, h6;            // stepSize, h/2, h/6
+    double safe, in2, out2;      // safeDistance, diskInner^2, diskOuter^2 (Raytracer.hs:59-62)
+    double rI, rO;               // sqrt in2, sqrt out2 (Raytracer.hs:107-108)
+    double disk_rgb[3];          // toPixelRGB diskColor (:65)
+    double disk_opacity;
+    double star_intensity, star_saturation;
+    double star_a;               // log 2 / 50 (StarMap.hs:108)
+    int32_t wt, ht;              // traced resolution
+    int32_t ss;                  // supersampling
+    int32_t out_w, out_h;
+    int32_t max_steps;
+    int32_t n_stars;
+    int32_t lds_nodes;           // min(n_stars, kLdsNodes)
+    const StarNode *nodes;       // device, n_stars + 1 entries (entry 0 unused)
+    const StarColor *colors;     // device, n_stars + 1 entries
+    double *out;                 // device, out_h * out_w * 3
+    unsigned long long *counters;  // device, kCounters
+};
+
+// Host-side strict math (host_math.cpp, compiled -ffp-contract=off).
+void host_hsi_to_rgb(double hue, double s, double i, double rgb[3], bool *ok);
+// Fills every derived field of TraceParams except the device pointers.  Returns false + message on bad input.
+bool derive_params(const bs_config &cfg, TraceParams &p, std::string &err);
+
+// star_index.cpp: build the 1-based Eytzinger left-balanced k-d array from the caller's stars.
+void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors);
+
+// trace_kernel.hip launchers (enqueue on `stream`, no sync).
+int launch_trace(const TraceParams &p, int mode, void *stream);
+int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, size_t n_rays, bs_ray_record *d_out, void *stream);
+int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, double *d_rgb, int32_t *d_hits, void *stream);
+int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, void *stream);
+
+}  // namespace bs

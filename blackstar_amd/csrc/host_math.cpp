@@ -1,0 +1,151 @@
+// host_math.cpp -- per-frame scalar derivations done once on the host, with the reference's operation
+// order (compiled -ffp-contract=off so nothing is fused).  These are the parts of Raytracer.render /
+// generateRay that do not depend on the pixel: scene constants (src/Raytracer.hs:57-65) and the look-at
+// basis (linear's lookAt, src/Raytracer.hs:47), plus the catalogue record parser (src/StarMap.hs:45-75).
+#include <cmath>
+#include <cstring>
+
+#include "bs_internal.h"
+
+namespace bs {
+
+namespace {
+inline double quadrance(const double v[3]) { return (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; }
+
+inline void cross(const double a[3], const double b[3], double o[3])
+{
+    // linear: cross (V3 a b c) (V3 d e f) = V3 (b*f-c*e) (c*d-a*f) (a*e-b*d)
+    double x = a[1] * b[2] - a[2] * b[1];
+    double y = a[2] * b[0] - a[0] * b[2];
+    double z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+inline void normalize(const double v[3], double o[3])
+{
+    // linear: normalize v = if nearZero l || nearZero (1-l) then v else fmap (/sqrt l) v ; nearZero = (<= 1e-12) . abs
+    double l = quadrance(v);
+    if (std::fabs(l) <= 1e-12 || std::fabs(1.0 - l) <= 1e-12) {
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    } else {
+        double s = std::sqrt(l);
+        o[0] = v[0] / s; o[1] = v[1] / s; o[2] = v[2] / s;
+    }
+}
+}  // namespace
+
+void host_hsi_to_rgb(double hp, double s, double i, double rgb[3], bool *ok)
+{
+    // massiv-io Graphics.ColorSpace: toPixelRGB (PixelHSI h' s i)  (recalled)
+    const double pi = 3.141592653589793;
+    double h = hp * 2 * pi;
+    double is = i * s;
+    double second = i - is;
+    *ok = true;
+    if (h >= 0 && h < 2 * pi / 3) {
+        double r = i + is * std::cos(h) / std::cos(pi / 3 - h);
+        double b = second;
+        double g = i + 2 * is + b - r;
+        rgb[0] = r; rgb[1] = g; rgb[2] = b;
+    } else if (h >= 0 && h < 4 * pi / 3) {
+        double g = i + is * std::cos(h - 2 * pi / 3) / std::cos(h + pi);
+        double r = second;
+        double b = i + 2 * is + r - g;
+        rgb[0] = r; rgb[1] = g; rgb[2] = b;
+    } else if (h >= 0 && h < 2 * pi) {
+        double b = i + is * std::cos(h - 4 * pi / 3) / std::cos(2 * pi - pi / 3 - h);
+        double g = second;
+        double r = i + 2 * is + g - b;
+        rgb[0] = r; rgb[1] = g; rgb[2] = b;
+    } else {
+        // the reference raises `error "HSI pixel is not properly scaled"`
+        rgb[0] = rgb[1] = rgb[2] = std::nan("");
+        *ok = false;
+    }
+}
+
+bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
+{
+    if (c.width <= 0 || c.height <= 0) { err = "resolution must be positive"; return false; }
+    if ((long long)c.width * c.height > (1LL << 28)) { err = "resolution too large"; return false; }
+    std::memcpy(p.cam, c.cam_pos, sizeof p.cam);
+    // linear lookAt eye center up: za = normalize (center - eye); xa = normalize (cross za up); ya = cross xa za
+    double d[3] = {c.cam_lookat[0] - c.cam_pos[0], c.cam_lookat[1] - c.cam_pos[1], c.cam_lookat[2] - c.cam_pos[2]};
+    double t[3];
+    normalize(d, p.za);
+    cross(p.za, c.cam_up, t);
+    normalize(t, p.xa);
+    cross(p.xa, p.za, p.ya);
+    p.fov = c.fov;
+    p.ss = c.supersampling ? 1 : 0;
+    p.wt = p.ss ? 2 * c.width : c.width;    // Raytracer.hs:58
+    p.ht = p.ss ? 2 * c.height : c.height;
+    p.out_w = c.width;
+    p.out_h = c.height;
+    p.W = (double)p.wt;
+    p.H = (double)p.ht;
+    p.h = c.step_size;
+    p.hh = c.step_size / 2;  // rk4: h / 2, h / 6  (:130-134)
+    p.h6 = c.step_size / 6;
+    double a = 50.0 * 50.0, b = 2 * quadrance(c.cam_pos);  // :59-60, max x y = if x <= y then y else x
+    p.safe = (a <= b) ? b : a;
+    p.in2 = c.disk_inner * c.disk_inner;   // :61
+    p.out2 = c.disk_outer * c.disk_outer;  // :62
+    p.rI = std::sqrt(p.in2);               // :107
+    p.rO = std::sqrt(p.out2);              // :108
+    bool ok;
+    host_hsi_to_rgb(c.disk_hsi[0], c.disk_hsi[1], c.disk_hsi[2], p.disk_rgb, &ok);  // :65
+    if (!ok) { err = "HSI pixel is not properly scaled (diskColor hue outside [0,360))"; return false; }
+    p.disk_opacity = c.disk_opacity;
+    p.star_intensity = c.star_intensity;
+    p.star_saturation = c.star_saturation;
+    p.star_a = std::log(2.0) / 50;  // StarMap.hs:108  a = log 2 / dynamic
+    return true;
+}
+
+}  // namespace bs
+
+extern "C" int bs_hsi_to_rgb(double hue, double sat, double intensity, double rgb[3])
+{
+    if (!rgb) return BS_EINVAL;
+    bool ok;
+    bs::host_hsi_to_rgb(hue, sat, intensity, rgb, &ok);
+    return ok ? BS_OK : BS_EINVAL;
+}
+
+extern "C" long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size_t cap)
+{
+    // readMap (StarMap.hs:45-58): skip 28; replicateM (remaining `div` 28) of
+    //   getFloat64be ra, getFloat64be dec, getWord8 spectral, skip 1, getInt16be mag, skip 8
+    if (!bytes || nbytes < 28) return BS_EINVAL;
+    const unsigned char *b = static_cast<const unsigned char *>(bytes);
+    size_t n = (nbytes - 28) / 28;
+    auto be64 = [](const unsigned char *q) {
+        uint64_t u = 0;
+        for (int i = 0; i < 8; i++) u = (u << 8) | q[i];
+        double dd;
+        std::memcpy(&dd, &u, 8);
+        return dd;
+    };
+    for (size_t i = 0; i < n && i < cap && out; i++) {
+        const unsigned char *r = b + 28 + i * 28;
+        double ra = be64(r), dec = be64(r + 8);
+        bs_star &s = out[i];
+        s.x = std::cos(dec) * std::cos(ra);  // raDecToCartesian (StarMap.hs:74-75)
+        s.y = std::cos(dec) * std::sin(ra);
+        s.z = std::sin(dec);
+        s.mag = (int16_t)(((uint16_t)r[18] << 8) | r[19]);
+        s._pad = 0;
+        switch (r[16]) {  // starColor (StarMap.hs:64-72)
+        case 'O': s.hue = 0.631; s.sat = 0.39; break;
+        case 'B': s.hue = 0.628; s.sat = 0.33; break;
+        case 'A': s.hue = 0.622; s.sat = 0.21; break;
+        case 'F': s.hue = 0.650; s.sat = 0.03; break;
+        case 'G': s.hue = 0.089; s.sat = 0.09; break;
+        case 'K': s.hue = 0.094; s.sat = 0.29; break;
+        case 'M': s.hue = 0.094; s.sat = 0.56; break;
+        default: s.hue = 0; s.sat = 0; break;
+        }
+    }
+    return (long)n;
+}

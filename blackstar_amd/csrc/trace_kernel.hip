@@ -1,0 +1,427 @@
+// trace_kernel.hip -- gfx950 (CDNA4) geodesic trace kernel: one wavefront lane per ray.
+//
+// Implements, per lane, the reference's per-pixel function (file:line into /root/reference):
+//   generateRay  src/Raytracer.hs:40-51      traceRay/colorize :69-86     findColor :88-102
+//   diskColor'   :104-111                    rk4 :113-134                 blend :34-37
+//   starLookup   src/StarMap.hs:93-115       supersample src/ImageFilters.hs:88-97 (fused epilogue)
+//
+// The path is scalar FP64 ODE work: ~145 flop per RK4 step per ray against <= 24 B written per ray, so the
+// bound is the FP64 VALU issue rate (v_fma_f64 / v_mul_f64 / v_add_f64 at 16 lanes/clk/SIMD), not HBM and
+// not MFMA (there is no dense contraction to feed a matrix core).  State (vel, pos), h^2 and the RGBA
+// accumulator live in VGPRs for the whole ray; nothing is spilled or re-read.
+//
+// This translation unit is compiled with -ffp-contract=off: STRICT mode is one IEEE binary64 operation
+// per reference operation in the reference's order (f64 sqrt and / lower to correctly rounded sequences),
+// which makes step counts, fates and terminal states bit-identical to the CPU oracle.  FAST mode spells
+// its FMAs explicitly.
+#include <hip/hip_runtime.h>
+
+#include "bs_internal.h"
+
+namespace bs {
+namespace {
+
+constexpr int kBlock = 256;  // 4 wavefronts; each wavefront owns one 8x8 tile of traced pixels
+
+__device__ __forceinline__ double quadrance(double x, double y, double z) { return (x * x + y * y) + z * z; }
+
+// GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
+__device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
+
+// c such that the velocity derivative is -(c * pos):  c = (1.5*h2) / |pos|^5   (Raytracer.hs:127)
+template <bool FAST>
+__device__ __forceinline__ double accel_coef(double h2c, double px, double py, double pz)
+{
+    if constexpr (!FAST) {
+        double n = __builtin_sqrt(quadrance(px, py, pz));  // norm pos
+        double n2 = n * n;
+        double n5 = (n2 * n2) * n;  // x^5 = ((x*x)*(x*x))*x  (GHC.Real (^))
+        return h2c / n5;
+    } else {
+        // |pos|^-5 from v_rsq_f64 (~2^-26) + one cubic Newton step (-> ~1 ulp), no sqrt, no divide.
+        double q = __builtin_fma(pz, pz, __builtin_fma(py, py, px * px));
+        double y0 = __builtin_amdgcn_rsq(q);
+        double t = q * y0;
+        double e = __builtin_fma(-t, y0, 1.0);
+        double p = __builtin_fma(0.375, e, 0.5);
+        double y1 = __builtin_fma(y0 * e, p, y0);
+        double y2 = y1 * y1;
+        double y4 = y2 * y2;
+        return h2c * (y4 * y1);
+    }
+}
+
+// One classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134)
+template <bool FAST>
+__device__ __forceinline__ void rk4(const TraceParams &P, double h2c, const double v[3], const double p[3], double nv[3], double np[3])
+{
+    const double h = P.h, hh = P.hh, h6 = P.h6;
+    double a1[3], a2[3], a3[3], a4[3], v2[3], v3[3], v4[3], q[3];
+    if constexpr (!FAST) {
+        double c = accel_coef<false>(h2c, p[0], p[1], p[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a1[i] = -(c * p[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v2[i] = v[i] + a1[i] * hh; q[i] = p[i] + v[i] * hh; }
+        c = accel_coef<false>(h2c, q[0], q[1], q[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a2[i] = -(c * q[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v3[i] = v[i] + a2[i] * hh; q[i] = p[i] + v2[i] * hh; }
+        c = accel_coef<false>(h2c, q[0], q[1], q[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a3[i] = -(c * q[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v4[i] = v[i] + a3[i] * h; q[i] = p[i] + v3[i] * h; }
+        c = accel_coef<false>(h2c, q[0], q[1], q[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a4[i] = -(c * q[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double sv = ((a1[i] + a2[i] * 2) + a3[i] * 2) + a4[i];  // sumK = ((k1 + 2 k2) + 2 k3) + k4
+            double sp = ((v[i] + v2[i] * 2) + v3[i] * 2) + v4[i];
+            nv[i] = v[i] + sv * h6;
+            np[i] = p[i] + sp * h6;
+        }
+    } else {
+        double c = -accel_coef<true>(h2c, p[0], p[1], p[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a1[i] = c * p[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v2[i] = __builtin_fma(a1[i], hh, v[i]); q[i] = __builtin_fma(v[i], hh, p[i]); }
+        c = -accel_coef<true>(h2c, q[0], q[1], q[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a2[i] = c * q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v3[i] = __builtin_fma(a2[i], hh, v[i]); q[i] = __builtin_fma(v2[i], hh, p[i]); }
+        c = -accel_coef<true>(h2c, q[0], q[1], q[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a3[i] = c * q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v4[i] = __builtin_fma(a3[i], h, v[i]); q[i] = __builtin_fma(v3[i], h, p[i]); }
+        c = -accel_coef<true>(h2c, q[0], q[1], q[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) a4[i] = c * q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double sv = __builtin_fma(2.0, a3[i], __builtin_fma(2.0, a2[i], a1[i])) + a4[i];
+            double sp = __builtin_fma(2.0, v3[i], __builtin_fma(2.0, v2[i], v[i])) + v4[i];
+            nv[i] = __builtin_fma(sv, h6, v[i]);
+            np[i] = __builtin_fma(sp, h6, p[i]);
+        }
+    }
+}
+
+// massiv-io Graphics.ColorSpace toPixelRGB (PixelHSI h' s i), h' in [0,1)  (recalled)
+__device__ __forceinline__ void hsi_to_rgb(double hp, double s, double i, double &r, double &g, double &b)
+{
+    const double pi = 3.141592653589793;
+    double h = hp * 2 * pi;
+    double is = i * s;
+    double second = i - is;
+    // Sector k: first = i + is*cos a / cos b, third = i + 2*is + second - first; (r,g,b) is a rotation of
+    // (first, third, second).  Written with selects so the three channels stay in registers.
+    const int k = (h < 2 * pi / 3) ? 0 : ((h < 4 * pi / 3) ? 1 : 2);
+    double a = k == 0 ? h : (k == 1 ? h - 2 * pi / 3 : h - 4 * pi / 3);
+    double bb = k == 0 ? pi / 3 - h : (k == 1 ? h + pi : 2 * pi - pi / 3 - h);
+    double first = i + is * cos(a) / cos(bb);
+    double third = i + 2 * is + second - first;
+    r = k == 0 ? first : (k == 1 ? second : third);
+    g = k == 0 ? third : (k == 1 ? first : second);
+    b = k == 0 ? second : (k == 1 ? third : first);
+}
+
+// starLookup (StarMap.hs:93-115) over the flat k-d array.  Stackless depth-first traversal: `pending`
+// holds one bit per depth whose far child is still to be visited; the path itself is the node index.
+// Returns the number of stars within the radius; rgb = min 1 (sum of per-star colours).
+__device__ __forceinline__ int star_lookup(const TraceParams &P, const StarNode *lds_nodes, double vx, double vy, double vz, double &R,
+                                           double &G, double &B)
+{
+    const double w = 0.0005;
+    const double radius = 3 * w;            // StarMap.hs:104  inRadius starmap (3 * w) nvel
+    const double r2 = radius * radius;      // kdt: distSqr p q <= radius * radius
+    const double two_w2 = 2 * (w * w);
+    // linear.normalize: unchanged when |l| or |1-l| <= 1e-12
+    double l = quadrance(vx, vy, vz);
+    double nx = vx, ny = vy, nz = vz;
+    if (!(fabs(l) <= 1e-12 || fabs(1.0 - l) <= 1e-12)) {
+        double s = __builtin_sqrt(l);
+        nx = vx / s; ny = vy / s; nz = vz / s;
+    }
+    double accR = 0, accG = 0, accB = 0;
+    int hits = 0;
+    const unsigned n = (unsigned)P.n_stars;
+    const unsigned nl = (unsigned)P.lds_nodes;
+    unsigned i = 1, pending = 0;
+    int depth = 0, axis = 0;
+    for (;;) {
+        while (i <= n) {
+            StarNode nd = (i <= nl) ? lds_nodes[i - 1] : P.nodes[i];
+            double dx = nd.x - nx, dy = nd.y - ny, dz = nd.z - nz;  // qd pos nvel = quadrance (pos - nvel)
+            double d2 = quadrance(dx, dy, dz);
+            if (d2 <= r2) {
+                StarColor sc = P.colors[i];
+                double e = exp(P.star_a * (950.0 - (double)nd.mag) - d2 / two_w2);
+                double m = (1.0 <= e) ? 1.0 : e;  // min 1
+                double val = m * P.star_intensity;
+                double cr, cg, cb;
+                hsi_to_rgb(sc.hue, P.star_saturation * sc.sat, val, cr, cg, cb);
+                accR = accR + cr; accG = accG + cg; accB = accB + cb;
+                hits++;
+            }
+            double qa = axis == 0 ? nx : (axis == 1 ? ny : nz);
+            double sa = axis == 0 ? nd.x : (axis == 1 ? nd.y : nd.z);
+            double diff = qa - sa;
+            if (fabs(diff) <= radius) pending |= 1u << (depth + 1);  // far child intersects the ball
+            i = 2 * i + (diff <= 0 ? 0u : 1u);                        // near child
+            depth++;
+            axis = (axis == 2) ? 0 : axis + 1;
+        }
+        if (pending == 0) break;
+        int dd = 31 - __clz((int)pending);
+        pending &= ~(1u << dd);
+        i = (i >> (depth - dd)) ^ 1u;  // sibling of the near child taken at depth dd
+        depth = dd;
+        axis = dd % 3;
+    }
+    R = (1.0 <= accR) ? 1.0 : accR;  // fmap (min 1)
+    G = (1.0 <= accG) ? 1.0 : accG;
+    B = (1.0 <= accB) ? 1.0 : accB;
+    return hits;
+}
+
+struct RayResult {
+    double vel[3], pos[3], rgba[4];
+    int steps, fate, disk_hits, star_hits;
+};
+
+// traceRay + colorize for traced pixel (yi, xi).
+template <bool FAST>
+__device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, int yi, int xi, RayResult &res)
+{
+    // generateRay (Raytracer.hs:40-51); basis hoisted to the host (identical arithmetic, once per frame).
+    double v0 = P.fov * ((double)xi / P.W - 0.5);
+    double v1 = P.fov * (0.5 - (double)yi / P.H) * P.H / P.W;
+    double d[3], v[3], p[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = (P.xa[i] * v0 + P.ya[i] * v1) + P.za[i];  // (-za_i) * (-1) == za_i exactly
+    double l = quadrance(d[0], d[1], d[2]);
+    if (fabs(l) <= 1e-12 || fabs(1.0 - l) <= 1e-12) {
+        v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
+    } else {
+        double s = __builtin_sqrt(l);
+        v[0] = d[0] / s; v[1] = d[1] / s; v[2] = d[2] / s;
+    }
+    p[0] = P.cam[0]; p[1] = P.cam[1]; p[2] = P.cam[2];
+    // h2 = quadrance (pos `cross` vel)   (:73)
+    double cx = p[1] * v[2] - p[2] * v[1], cy = p[2] * v[0] - p[0] * v[2], cz = p[0] * v[1] - p[1] * v[0];
+    double h2 = quadrance(cx, cy, cz);
+    double h2c = 1.5 * h2;
+
+    double rgba[4] = {0, 0, 0, 0};
+    int steps = 0, fate = 2, disk_hits = 0, star_hits = 0;
+    double r2 = quadrance(p[0], p[1], p[2]);
+    const bool disk = P.disk_opacity != 0;
+    while (steps < P.max_steps) {
+        steps++;
+        // findColor guards on the PRE-step position (:93-95); rk4's result is not needed when they fire.
+        if (r2 < 1.0) { fate = 0; break; }
+        if (r2 > P.safe) { fate = 1; break; }
+        double nv[3], np[3];
+        rk4<FAST>(P, h2c, v, p, nv, np);
+        double r2n = quadrance(np[0], np[1], np[2]);
+        double y = p[1], yn = np[1];
+        if (disk && signum(yn) != signum(y)) {  // :96
+            double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
+            if (r2ave > P.in2 && r2ave < P.out2) {           // :97
+                // diskColor' (:104-111)
+                const double pi = 3.141592653589793;
+                double r = __builtin_sqrt(r2ave);
+                double t = (P.rO - r) / (P.rO - P.rI);
+                double inten = sin(pi * (t * t));
+                double om = 1 - rgba[3];  // blend: top + layer * (1 - top_alpha), all four channels (:34-37)
+                rgba[0] = rgba[0] + (P.disk_rgb[0] * inten) * om;
+                rgba[1] = rgba[1] + (P.disk_rgb[1] * inten) * om;
+                rgba[2] = rgba[2] + (P.disk_rgb[2] * inten) * om;
+                rgba[3] = rgba[3] + (inten * P.disk_opacity) * om;
+                disk_hits++;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
+        r2 = r2n;
+    }
+    if (fate == 0) {  // Bottom (PixelRGBA 0 0 0 1)
+        double om = 1 - rgba[3];
+        rgba[0] = rgba[0] + 0.0 * om; rgba[1] = rgba[1] + 0.0 * om; rgba[2] = rgba[2] + 0.0 * om;
+        rgba[3] = rgba[3] + 1.0 * om;
+    } else if (fate == 1) {  // Bottom . addAlpha 1 $ starLookup ... vel   (OLD vel, :94-95)
+        double sr, sg, sb;
+        star_hits = star_lookup(P, lds_nodes, v[0], v[1], v[2], sr, sg, sb);
+        double om = 1 - rgba[3];
+        rgba[0] = rgba[0] + sr * om; rgba[1] = rgba[1] + sg * om; rgba[2] = rgba[2] + sb * om;
+        rgba[3] = rgba[3] + 1.0 * om;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { res.vel[i] = v[i]; res.pos[i] = p[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) res.rgba[i] = rgba[i];
+    res.steps = steps; res.fate = fate; res.disk_hits = disk_hits; res.star_hits = star_hits;
+}
+
+__device__ __forceinline__ void stage_tree(const TraceParams &P, StarNode *s_nodes)
+{
+    for (int k = threadIdx.x; k < P.lds_nodes; k += kBlock) s_nodes[k] = P.nodes[k + 1];
+    __syncthreads();
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Frame kernel.  grid = (ceil(wt/16), ceil(ht/16)); block = 256 = 2x2 wavefront tiles of 8x8 traced pixels.
+// With supersampling the four rays of an output pixel sit in four adjacent lanes (quad), in the order
+// p(2y,2x), p(2y+1,2x), p(2y,2x+1), p(2y+1,2x+1) of ImageFilters.hs:94-96, and are reduced with lane
+// shuffles so only the h x w image is ever written.
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void trace_frame_kernel(const TraceParams P)
+{
+    __shared__ StarNode s_nodes[kLdsNodes];
+    stage_tree(P, s_nodes);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tx = blockIdx.x * 16 + (wave & 1) * 8;
+    const int ty = blockIdx.y * 16 + (wave >> 1) * 8;
+    int lx, ly;
+    if (P.ss) {
+        int q = lane >> 2, sub = lane & 3;
+        lx = (q & 3) * 2 + (sub >> 1);
+        ly = (q >> 2) * 2 + (sub & 1);
+    } else {
+        lx = lane & 7;
+        ly = lane >> 3;
+    }
+    const int xi = tx + lx, yi = ty + ly;
+    const bool inb = xi < P.wt && yi < P.ht;
+
+    RayResult res;
+    res.rgba[0] = res.rgba[1] = res.rgba[2] = res.rgba[3] = 0;
+    res.steps = 0; res.fate = -1; res.disk_hits = 0; res.star_hits = 0;
+    if (inb) trace_ray<FAST>(P, s_nodes, yi, xi, res);
+
+    if (P.ss) {
+        const int base = lane & ~3;
+        double o[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double a = __shfl(res.rgba[c], base + 0, 64);
+            double b = __shfl(res.rgba[c], base + 1, 64);
+            double cc = __shfl(res.rgba[c], base + 2, 64);
+            double dd = __shfl(res.rgba[c], base + 3, 64);
+            o[c] = 0.25 * (((a + b) + cc) + dd);
+        }
+        if (inb && (lane & 3) == 0) {
+            double *dst = P.out + ((size_t)(yi >> 1) * P.out_w + (xi >> 1)) * 3;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        }
+    } else if (inb) {
+        double *dst = P.out + ((size_t)yi * P.out_w + xi) * 3;
+        dst[0] = res.rgba[0]; dst[1] = res.rgba[1]; dst[2] = res.rgba[2];  // dropAlpha
+    }
+
+    unsigned s_steps = wave_sum((unsigned)res.steps);
+    unsigned s_cap = wave_sum(res.fate == 2 ? 1u : 0u);
+    unsigned s_hor = wave_sum(res.fate == 0 ? 1u : 0u);
+    unsigned s_esc = wave_sum(res.fate == 1 ? 1u : 0u);
+    unsigned s_disk = wave_sum((unsigned)res.disk_hits);
+    unsigned s_star = wave_sum((unsigned)res.star_hits);
+    if (lane == 0) {
+        atomicAdd(&P.counters[0], (unsigned long long)s_steps);
+        if (s_cap) atomicAdd(&P.counters[1], (unsigned long long)s_cap);
+        if (s_hor) atomicAdd(&P.counters[2], (unsigned long long)s_hor);
+        if (s_esc) atomicAdd(&P.counters[3], (unsigned long long)s_esc);
+        if (s_disk) atomicAdd(&P.counters[4], (unsigned long long)s_disk);
+        if (s_star) atomicAdd(&P.counters[5], (unsigned long long)s_star);
+    }
+}
+
+// Test hook: trace an explicit list of traced-resolution pixels, one lane per listed ray.
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams P, const int32_t *yx, size_t n_rays, bs_ray_record *out)
+{
+    __shared__ StarNode s_nodes[kLdsNodes];
+    stage_tree(P, s_nodes);
+    size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_rays) return;
+    RayResult res;
+    trace_ray<FAST>(P, s_nodes, yx[2 * k], yx[2 * k + 1], res);
+    bs_ray_record r;
+    for (int i = 0; i < 3; i++) { r.vel[i] = res.vel[i]; r.pos[i] = res.pos[i]; }
+    for (int i = 0; i < 4; i++) r.rgba[i] = res.rgba[i];
+    r.steps = res.steps; r.fate = res.fate; r.disk_hits = res.disk_hits; r.star_hits = res.star_hits;
+    out[k] = r;
+}
+
+// starLookup over a batch of directions (same device function as the trace kernel's escape branch).
+__global__ __launch_bounds__(kBlock) void star_lookup_kernel(const TraceParams P, const double *dirs, size_t n, double *rgb, int32_t *hits)
+{
+    __shared__ StarNode s_nodes[kLdsNodes];
+    stage_tree(P, s_nodes);
+    size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    double r, g, b;
+    int h = star_lookup(P, s_nodes, dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2], r, g, b);
+    rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b;
+    if (hits) hits[k] = h;
+}
+
+// Test hook: device sqrt / divide, to check that the f64 lowerings are correctly rounded.
+__global__ void sqrt_div_kernel(const double *a, const double *b, size_t n, double *s, double *d)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    s[k] = __builtin_sqrt(a[k]);
+    d[k] = a[k] / b[k];
+}
+
+}  // namespace
+
+int launch_trace(const TraceParams &p, int mode, void *stream)
+{
+    dim3 grid((unsigned)((p.wt + 15) / 16), (unsigned)((p.ht + 15) / 16));
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == BS_MODE_FAST) hipLaunchKernelGGL(trace_frame_kernel<true>, grid, dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL(trace_frame_kernel<false>, grid, dim3(kBlock), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, size_t n_rays, bs_ray_record *d_out, void *stream)
+{
+    if (n_rays == 0) return 0;
+    dim3 grid((unsigned)((n_rays + kBlock - 1) / kBlock));
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == BS_MODE_FAST) hipLaunchKernelGGL(trace_records_kernel<true>, grid, dim3(kBlock), 0, s, p, d_yx, n_rays, d_out);
+    else hipLaunchKernelGGL(trace_records_kernel<false>, grid, dim3(kBlock), 0, s, p, d_yx, n_rays, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, double *d_rgb, int32_t *d_hits, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(star_lookup_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, p, d_dirs, n,
+                       d_rgb, d_hits);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sqrt_div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_a, d_b, n, d_sqrt, d_div);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace bs

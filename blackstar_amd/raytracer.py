@@ -1,0 +1,72 @@
+"""Host-side mirror of the reference's Raytracer module: `render` and `write_img` (src/Raytracer.hs:4).
+
+    render :: Config -> StarTree -> Image U RGB Double        (src/Raytracer.hs:53)
+
+Here `render(cfg, startree)` returns a float64 ndarray (height, width, 3): linear light, unclamped, already
+supersample-reduced -- produced entirely by the gfx950 kernel behind bs_render.  Nothing in this module
+computes pixels on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+
+from . import _lib
+from .config_file import Config
+from .star_map import StarTree
+
+
+def _bs_config(cfg) -> _lib.BsConfig:
+    return _lib.make_config(cfg.to_bs_config() if isinstance(cfg, Config) else cfg)
+
+
+def render(cfg, startree: StarTree) -> np.ndarray:
+    c = _bs_config(cfg)
+    out = np.empty((c.height, c.width, 3), np.float64)
+    _lib.check(_lib.lib().bs_render(startree.handle, C.byref(c), out.ctypes.data, out.size), "bs_render")
+    return out
+
+
+def render_device(cfg, startree: StarTree, d_out_ptr: int, out_doubles: int, stream_ptr: int = 0) -> None:
+    """Enqueue a render whose image stays in HBM (d_out_ptr = device pointer, e.g. torch tensor.data_ptr())."""
+    c = _bs_config(cfg)
+    _lib.check(_lib.lib().bs_render_device(startree.handle, C.byref(c), d_out_ptr, out_doubles, stream_ptr or None), "bs_render_device")
+
+
+def trace_rays(cfg, startree: StarTree, ys, xs) -> np.ndarray:
+    """Test hook: per-ray terminal records for traced-resolution pixels (ys, xs)."""
+    c = _bs_config(cfg)
+    yx = np.ascontiguousarray(np.stack([np.asarray(ys), np.asarray(xs)], axis=1).astype(np.int32))
+    rec = np.zeros(len(yx), _lib.RECORD_DTYPE)
+    _lib.check(_lib.lib().bs_trace_rays(startree.handle, C.byref(c), yx.ctypes.data, len(yx), rec.ctypes.data), "bs_trace_rays")
+    return rec
+
+
+def srgb(x: np.ndarray) -> np.ndarray:
+    """sRGB transfer (src/Raytracer.hs:23-27)."""
+    a = 0.055
+    x = np.asarray(x, np.float64)
+    with np.errstate(invalid="ignore"):
+        return np.where(x < 0.0031308, 12.92 * x, (1 + a) * np.power(x, 1.0 / 2.4) - a)
+
+
+def to_word8(x: np.ndarray) -> np.ndarray:
+    """massiv-io toWord8: clamp to [0,1], scale by 255, round half to even (recalled)."""
+    return np.rint(255 * np.clip(x, 0.0, 1.0)).astype(np.uint8)
+
+
+def write_img(img: np.ndarray, path: str) -> None:
+    """writeImg (src/Raytracer.hs:29-32): sRGB transfer, 8-bit quantise, PNG."""
+    rgb8 = to_word8(srgb(img))
+    h, w, _ = rgb8.shape
+    raw = b"".join(b"\x00" + rgb8[y].tobytes() for y in range(h))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))

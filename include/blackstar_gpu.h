@@ -1,0 +1,142 @@
+/*
+ * blackstar_gpu.h -- C ABI of the MI355X-native replacement for blackstar's Raytracer.render.
+ *
+ * The reference has no FFI: the hot path sits behind ONE pure Haskell function,
+ *     render :: Config -> StarTree -> Image U RGB Double        (src/Raytracer.hs:53, exported :4)
+ * whose only caller is app/Main.hs:109.  This header is what a `foreign import ccall` shim for that
+ * function binds (INTEGRATION.md shows the Haskell side).  Plain pointers and sizes only; no C++,
+ * torch or HIP types appear in any signature (streams / device pointers travel as void*).
+ *
+ * Library: blackstar_amd/libblackstar_gpu.so (hipcc --offload-arch=gfx950).  There is NO CPU backend in
+ * this library: every entry point that renders requires a HIP device and fails (never falls back).
+ *
+ * Conventions: caller allocates and owns every buffer; callee never frees caller memory, never calls
+ * back, never throws across the ABI.  A bs_ctx belongs to one device; one render at a time per ctx;
+ * different contexts may be driven from different OS threads.  Functions returning int return 0 on
+ * success and a negative BS_E* code on failure; bs_last_error() gives a thread-local message.
+ */
+#ifndef BLACKSTAR_GPU_H
+#define BLACKSTAR_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BS_ABI_VERSION 1
+
+enum {
+    BS_OK = 0,
+    BS_EINVAL = -1,  /* bad argument (null pointer, non-positive resolution, buffer too small, bad hue) */
+    BS_EDEVICE = -2, /* no such HIP device / HIP runtime error */
+    BS_ENOMEM = -3,  /* host or device allocation failed */
+    BS_ECAPPED = -4, /* reserved */
+    BS_EINTERNAL = -5
+};
+
+/* Arithmetic mode of the trace kernel (DESIGN.md "Kernels").
+ * STRICT: one IEEE binary64 operation per reference operation, in the reference's order, no FMA
+ *         contraction, correctly rounded sqrt and divide -> trajectories bit-identical to the CPU oracle.
+ * FAST:   same algorithm with FMA contraction and r^-5 from v_rsq_f64 + one cubic Newton step
+ *         (about 1 ulp per RHS, same accuracy class as STRICT); results agree with STRICT to ~1e-12. */
+enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
+
+/* Replaces the `Config` argument of render (src/ConfigFile.hs:16-38), AS PARSED: radii un-squared,
+ * safeDistance absent (render derives it, src/Raytracer.hs:59-60), user resolution (render doubles it
+ * when supersampling, :58).  disk_hsi[0] is hue/360 as produced by src/ConfigFile.hs:51. */
+typedef struct bs_config {
+    double cam_pos[3], cam_lookat[3], cam_up[3], fov; /* Camera, src/ConfigFile.hs:34-38 */
+    double step_size, star_intensity, star_saturation; /* Scene, :21,:24,:25 */
+    double disk_hsi[3];                                /* Scene.diskColor :26 */
+    double disk_opacity, disk_inner, disk_outer;       /* :27-29 */
+    int32_t width, height, supersampling;              /* :30-31 */
+    int32_t _pad;
+} bs_config;
+
+/* Replaces one element of the `StarTree` argument: (V3 position, (mag*100, hue, sat)), i.e. one
+ * `KdMap.assocs` entry after starColor' (src/StarMap.hs:25-26,61-62).  Position is a unit vector. */
+typedef struct bs_star {
+    double x, y, z, hue, sat;
+    int32_t mag;
+    int32_t _pad;
+} bs_star;
+
+/* Counters of the most recent render on a context (no reference counterpart; feeds the roofline). */
+typedef struct bs_stats_t {
+    uint64_t rays;      /* traced rays = w' * h' */
+    uint64_t steps;     /* sum over rays of colorize' iterations (src/Raytracer.hs:80-86) */
+    uint64_t capped;    /* rays stopped by the step cap (the reference would not terminate) */
+    uint64_t horizon;   /* rays ended by r^2 < 1 (:93) */
+    uint64_t escaped;   /* rays ended by r^2 > safeDistance (:94) */
+    uint64_t disk_hits; /* Layer blends (:96-98) */
+    uint64_t star_hits; /* stars summed by starLookup (src/StarMap.hs:104) */
+    double kernel_ms;   /* hipEvent time of the kernels of the last render */
+    double wall_ms;     /* host wall time of the last bs_render call (H2D params + kernels + D2H image) */
+} bs_stats_t;
+
+/* Test hook: per-ray terminal state (not part of the reference interface). */
+typedef struct bs_ray_record {
+    double vel[3], pos[3]; /* state fed to the terminating findColor call */
+    double rgba[4];        /* composited colour before dropAlpha */
+    int32_t steps, fate;   /* fate: 0 horizon, 1 escaped, 2 step cap */
+    int32_t disk_hits, star_hits;
+} bs_ray_record;
+
+typedef struct bs_ctx bs_ctx;
+
+/* Replaces: readTreeFromFile's result being handed to doStart once (app/Main.hs:46-49) -- the star set is
+ * uploaded once and reused for every frame.  Copies `stars`, builds the flat k-d array, uploads.
+ * n_stars == 0 is the "no starmap" case: inRadius yields [] and escaped rays are black (src/StarMap.hs:104,115).
+ * device: HIP device ordinal (>= 0).  Returns NULL on error. */
+bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars);
+void bs_destroy(bs_ctx *ctx);
+
+/* Replaces: render cfg tree (src/Raytracer.hs:53-67) at its only call site app/Main.hs:109.
+ * Blocking.  Fills out_rgb[height*width*3], interleaved RGB f64, row-major (y down), linear light,
+ * unclamped, already supersample-reduced -- the `Image S RGB Double` layout the Haskell shim wraps. */
+int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles);
+
+/* Same, but the image stays in HBM: d_out_rgb is a device pointer on the context's device, the work is
+ * enqueued on hip_stream (a hipStream_t cast to void*, NULL = default stream) and the call returns without
+ * synchronising.  Used by bench.py (inputs/outputs resident) and by on-device post-processing. */
+int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t out_doubles, void *hip_stream);
+
+/* Batch mode (app/Main.hs:68-77 renders a directory of scenes sequentially with the same tree):
+ * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin); outs[i] is
+ * a host buffer of cfgs[i].height*width*3 doubles. */
+int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs);
+
+/* Test hook: trace the given traced-resolution pixels (y,x pairs) and return per-ray records (host buffers). */
+int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out);
+
+/* Replaces: starLookup starmap intensity saturation vel (src/StarMap.hs:93-115), batched: dirs holds n
+ * un-normalised direction vectors (x,y,z interleaved, host); out_rgb gets n RGB triples, out_hits (may be
+ * NULL) the number of stars within the radius.  Runs the same device function the trace kernel calls. */
+int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const double *dirs, size_t n, double *out_rgb, int32_t *out_hits);
+
+/* Test hook: out_sqrt[i] = sqrt(a[i]), out_div[i] = a[i] / b[i] computed on the device (host buffers);
+ * proves the f64 sqrt / divide lowerings STRICT mode relies on are correctly rounded. */
+int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div);
+
+int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_STRICT */
+int bs_get_mode(const bs_ctx *ctx);
+int bs_set_max_steps(bs_ctx *ctx, int max_steps); /* safety cap; the reference has none (src/Raytracer.hs:80-86). default 100000 */
+int bs_stats(bs_ctx *ctx, bs_stats_t *out);       /* synchronises the context's last render first */
+const char *bs_last_error(void);
+int bs_abi_version(void);
+
+/* Replaces: readMap + starColor' (src/StarMap.hs:45-75): parse a PPM catalogue image held in memory
+ * (28-byte header, 28-byte big-endian records) into bs_star.  Returns the number of stars the buffer
+ * holds; writes at most `cap` of them.  Host-only; returns BS_EINVAL if nbytes < 28. */
+long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size_t cap);
+
+/* Replaces: toPixelRGB on PixelHSI (massiv-io Graphics.ColorSpace; call sites src/Raytracer.hs:65,
+ * src/StarMap.hs:114).  Host-only; returns BS_EINVAL if the hue is outside [0,1). */
+int bs_hsi_to_rgb(double hue, double sat, double intensity, double rgb[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLACKSTAR_GPU_H */

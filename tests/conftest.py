@@ -1,0 +1,56 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    if "cfg" in d:
+        d["cfg"] = json.loads(str(d["cfg"]))
+    return d
+
+
+@pytest.fixture(scope="session")
+def catalogue_bytes():
+    with open(os.path.join(GOLDEN, "catalogue_2000.ppm"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import c_oracle
+    c_oracle.build()
+    return c_oracle
+
+
+@pytest.fixture(scope="session")
+def oracle_stars(oracle, catalogue_bytes):
+    return oracle.read_ppm(catalogue_bytes)
+
+
+@pytest.fixture(scope="session")
+def oracle_index(oracle, oracle_stars):
+    return oracle.Index(oracle_stars)
+
+
+@pytest.fixture(scope="session")
+def oracle_index_empty(oracle):
+    return oracle.Index(None)
+
+
+IMAGE_GOLDENS = ["c2_default_96x54_nostars", "c3_default_aa_96x54", "c4_lensing_disk_96x54", "c5_ani_frame300_80x45",
+                 "odd_default_aa_37x23"]
+TRACE_GOLDENS = ["c1", "c2", "c3", "c4", "c5_f0", "c5_f599"]

@@ -1,0 +1,101 @@
+"""Regenerates tests/golden/*.npz.  Run from the repo root:  python tests/golden/make_golden.py
+
+The reference (Haskell) cannot run in this image and holds no golden vectors, so these fixtures come from
+the INDEPENDENT numpy restatement (oracle/np_oracle.py) -- not from the C oracle and not from the product.
+They are data only: inputs (config, pixel list, catalogue bytes) and expected outputs.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import np_oracle as no  # noqa: E402
+from oracle import scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED_SMALL = 0x5EEDB1AC57A2 + 1
+
+
+def small_catalogue():
+    """2,000-star PPM-layout catalogue (SURVEY 8d recipe, seed+1), generated here independently of the product."""
+    mask = (1 << 64) - 1
+
+    def splitmix(seed, n):
+        out, s = [], seed & mask
+        for _ in range(n):
+            s = (s + 0x9E3779B97F4A7C15) & mask
+            z = s
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+            out.append(z ^ (z >> 31))
+        return out
+
+    n = 2000
+    u = np.array([(x >> 11) * 2.0 ** -53 for x in splitmix(SEED_SMALL, 4 * n)]).reshape(n, 4)
+    dec = np.arcsin(2 * u[:, 0] - 1)
+    ra = 2 * np.pi * u[:, 1]
+    mag = (1200 - np.floor(700 * u[:, 2] ** 3)).astype(np.int16)
+    sp = np.frombuffer(b"OBAFGKM?", np.uint8)[np.floor(8 * u[:, 3]).astype(int)]
+    rec = np.zeros(n, np.dtype([("ra", ">f8"), ("dec", ">f8"), ("sp", "u1"), ("skip", "u1"), ("mag", ">i2"), ("pad", "u1", 8)]))
+    rec["ra"], rec["dec"], rec["sp"], rec["mag"] = ra, dec, sp, mag
+    return bytes(28) + rec.tobytes()
+
+
+COLOURS = {ord("O"): (0.631, 0.39), ord("B"): (0.628, 0.33), ord("A"): (0.622, 0.21), ord("F"): (0.650, 0.03),
+           ord("G"): (0.089, 0.09), ord("K"): (0.094, 0.29), ord("M"): (0.094, 0.56)}
+
+
+def parse_catalogue(data):
+    rec = np.frombuffer(data, np.dtype([("ra", ">f8"), ("dec", ">f8"), ("sp", "u1"), ("skip", "u1"), ("mag", ">i2"), ("pad", "u1", 8)]), offset=28)
+    hs = np.array([COLOURS.get(int(c), (0.0, 0.0)) for c in rec["sp"]])
+    return np.stack([np.cos(rec["dec"]) * np.cos(rec["ra"]), np.cos(rec["dec"]) * np.sin(rec["ra"]), np.sin(rec["dec"]),
+                     hs[:, 0], hs[:, 1], rec["mag"].astype(np.float64)], axis=1)
+
+
+def main():
+    cat = small_catalogue()
+    with open(os.path.join(HERE, "catalogue_2000.ppm"), "wb") as f:
+        f.write(cat)
+    stars = parse_catalogue(cat)
+    np.savez_compressed(os.path.join(HERE, "catalogue_2000_parsed.npz"), stars=stars)
+
+    images = {
+        "c2_default_96x54_nostars": (scenes.with_res(scenes.DEFAULT, 96, 54), None),
+        "c3_default_aa_96x54": (scenes.with_res(scenes.DEFAULT_AA, 96, 54), stars),
+        "c4_lensing_disk_96x54": (scenes.with_res(scenes.LENSING_DISK, 96, 54), stars),
+        "c5_ani_frame300_80x45": (scenes.with_res(scenes.ani_frame(300, 600), 80, 45), stars),
+        "odd_default_aa_37x23": (scenes.with_res(scenes.DEFAULT_AA, 37, 23), stars),
+    }
+    for name, (cfg, st) in images.items():
+        img, rec = no.render(cfg, st)
+        np.savez_compressed(os.path.join(HERE, f"image_{name}.npz"), cfg=json.dumps(cfg), img=img,
+                            total_steps=np.int64(rec["steps"].sum()), fate_counts=np.bincount(rec["fate"], minlength=3),
+                            disk_hits=np.int64(rec["disk_hits"].sum()), star_hits=np.int64(rec["star_hits"].sum()))
+        print(name, img.shape, int(rec["steps"].sum()))
+
+    # per-ray traces at FULL BASELINE resolution: grid + random pixels + rays bracketing the shadow edge / disk edges
+    rng = np.random.default_rng(20260927)
+    trace_cfgs = {"c1": scenes.with_res(scenes.DEFAULT, 640, 480), "c2": scenes.DEFAULT, "c3": scenes.DEFAULT_AA,
+                  "c4": scenes.with_res(scenes.LENSING_DISK, 3840, 2160), "c5_f0": scenes.ani_frame(0, 600),
+                  "c5_f599": scenes.ani_frame(599, 600)}
+    for name, cfg in trace_cfgs.items():
+        sc = no.derive(cfg)
+        gy, gx = np.meshgrid(np.linspace(0, sc["ht"] - 1, 12).astype(int), np.linspace(0, sc["wt"] - 1, 12).astype(int), indexing="ij")
+        ys = np.concatenate([gy.ravel(), rng.integers(0, sc["ht"], 80)])
+        xs = np.concatenate([gx.ravel(), rng.integers(0, sc["wt"], 80)])
+        # a dense horizontal scan line through the image centre crosses the shadow edge and both disk edges
+        ys = np.concatenate([ys, np.full(160, sc["ht"] // 2 + 3)])
+        xs = np.concatenate([xs, np.linspace(0, sc["wt"] - 1, 160).astype(int)])
+        rec = no.trace(cfg, stars, ys, xs)
+        v0, p0 = no.generate_rays(sc, ys, xs)
+        np.savez_compressed(os.path.join(HERE, f"trace_{name}.npz"), cfg=json.dumps(cfg), ys=ys.astype(np.int32), xs=xs.astype(np.int32),
+                            vel0=v0, h2=rec["h2"], vel=rec["vel"], pos=rec["pos"], rgba=rec["rgba"], steps=rec["steps"],
+                            fate=rec["fate"], disk_hits=rec["disk_hits"], star_hits=rec["star_hits"])
+        print(name, len(ys), rec["steps"].mean(), np.bincount(rec["fate"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,254 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI
+(libblackstar_gpu.so via ctypes); the oracle and the committed golden vectors are only the checkers.
+
+Bars: STRICT mode -- trajectories (step counts, fates, terminal vel/pos, disk crossings, star hit sets)
+bit-exact; colours within 1e-12 (device exp/sin/cos differ from glibc in the last ulp).  FAST mode -- the
+north_star tolerance, 1e-4 relative (+1e-7 absolute) per channel per pixel.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import blackstar_amd as bs
+from blackstar_amd import _lib, synthetic
+from conftest import IMAGE_GOLDENS, TRACE_GOLDENS, load_golden
+from oracle import scenes
+
+pytestmark = pytest.mark.gpu
+
+RTOL_STRICT, ATOL_STRICT = 1e-12, 1e-14
+RTOL_FAST, ATOL_FAST = 1e-4, 1e-7  # BASELINE.json north_star / SURVEY 8d "Parity check"
+
+
+@pytest.fixture(scope="module")
+def tree(catalogue_bytes):
+    t = bs.StarTree(bs.read_map(catalogue_bytes), device=0)
+    yield t
+    t.close()
+
+
+@pytest.fixture(scope="module")
+def tree_empty():
+    t = bs.StarTree(None, device=0)
+    yield t
+    t.close()
+
+
+def test_native_library_is_what_runs():
+    assert os.path.exists(_lib.SO_PATH)
+    with open("/proc/self/maps") as f:
+        _lib.lib()
+        assert "libblackstar_gpu.so" in f.read()
+
+
+def test_device_sqrt_and_divide_are_correctly_rounded(tree_empty):
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    a = np.concatenate([rng.uniform(0.5, 3000.0, n // 2), np.exp(rng.uniform(-20, 20, n // 2))])
+    b = np.concatenate([rng.uniform(1e-3, 1e5, n // 2), np.exp(rng.uniform(-20, 20, n // 2))])
+    s = np.zeros(n); d = np.zeros(n)
+    _lib.check(_lib.lib().bs_debug_sqrt_div(tree_empty.handle, a.ctypes.data, b.ctypes.data, n, s.ctypes.data, d.ctypes.data), "sqrt_div")
+    assert np.array_equal(s, np.sqrt(a))
+    assert np.array_equal(d, a / b)
+
+
+@pytest.mark.parametrize("name", TRACE_GOLDENS)
+def test_strict_trajectories_bit_exact_vs_golden_and_oracle(name, tree, oracle, oracle_index):
+    g = load_golden("trace_" + name)
+    tree.set_mode(_lib.BS_MODE_STRICT)
+    rec = bs.trace_rays(g["cfg"], tree, g["ys"], g["xs"])
+    orc = oracle.trace_rays(g["cfg"], oracle_index, g["ys"], g["xs"])
+    for ref in (g, orc):
+        assert np.array_equal(rec["steps"], ref["steps"])
+        assert np.array_equal(rec["fate"], ref["fate"])
+        assert np.array_equal(rec["disk_hits"], ref["disk_hits"])
+        assert np.array_equal(rec["star_hits"], ref["star_hits"])
+        assert np.array_equal(rec["vel"], ref["vel"]), "terminal velocity not bit-exact"
+        assert np.array_equal(rec["pos"], ref["pos"]), "terminal position not bit-exact"
+        np.testing.assert_allclose(rec["rgba"], ref["rgba"], rtol=RTOL_STRICT, atol=ATOL_STRICT)
+
+
+@pytest.mark.parametrize("name", TRACE_GOLDENS)
+def test_fast_trajectories_close(name, tree):
+    g = load_golden("trace_" + name)
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        rec = bs.trace_rays(g["cfg"], tree, g["ys"], g["xs"])
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    assert np.array_equal(rec["fate"], g["fate"])
+    assert np.array_equal(rec["steps"], g["steps"])
+    assert np.array_equal(rec["disk_hits"], g["disk_hits"])
+    np.testing.assert_allclose(rec["vel"], g["vel"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(rec["rgba"], g["rgba"], rtol=RTOL_FAST, atol=ATOL_FAST)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("name", IMAGE_GOLDENS)
+def test_images_match_golden(name, mode, tree, tree_empty):
+    g = load_golden("image_" + name)
+    t = tree_empty if "nostars" in name else tree
+    t.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+    try:
+        img = bs.render(g["cfg"], t)
+        st = t.stats()
+    finally:
+        t.set_mode(_lib.BS_MODE_STRICT)
+    assert img.shape == g["img"].shape
+    rtol, atol = (RTOL_FAST, ATOL_FAST) if mode == "fast" else (RTOL_STRICT, ATOL_STRICT)
+    bad = np.abs(img - g["img"]) > atol + rtol * np.abs(g["img"])
+    assert bad.sum() == 0, f"{bad.sum()} channel values outside tolerance, max abs err {np.abs(img - g['img']).max()}"
+    assert st["steps"] == int(g["total_steps"])
+    assert [st["horizon"], st["escaped"], st["capped"]] == list(g["fate_counts"])
+    assert st["disk_hits"] == int(g["disk_hits"]) and st["star_hits"] == int(g["star_hits"])
+    assert st["rays"] == img.shape[0] * img.shape[1] * (4 if g["cfg"]["supersampling"] else 1)
+
+
+def test_star_lookup_matches_brute_force(tree, oracle, oracle_stars, oracle_index):
+    rng = np.random.default_rng(5)
+    n = 10000
+    dirs = rng.normal(size=(n, 3))
+    near = oracle_stars[rng.integers(0, len(oracle_stars), n // 2)]
+    dirs[: n // 2] = np.stack([near["x"], near["y"], near["z"]], axis=1) * rng.uniform(0.5, 3, (n // 2, 1)) + rng.normal(scale=5e-4, size=(n // 2, 3))
+    rgb, hits = bs.star_lookup(tree, 0.4, 1.5, dirs, return_hits=True)
+    assert hits.sum() > 2000 and hits.max() >= 2
+    for k in range(n):
+        ref, nref = oracle.star_lookup(oracle_index, 0.4, 1.5, dirs[k], brute=(k % 10 == 0))
+        assert hits[k] == nref, f"hit SET differs for query {k}"
+        np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
+
+
+def test_star_lookup_full_catalogue_vs_oracle_index(oracle):
+    stars = bs.read_map(synthetic.ppm_catalogue_bytes())  # 470,000 stars, the BASELINE catalogue
+    t = bs.StarTree(stars)
+    ix = oracle.Index(oracle.read_ppm(synthetic.ppm_catalogue_bytes()))
+    rng = np.random.default_rng(9)
+    dirs = rng.normal(size=(20000, 3))
+    rgb, hits = bs.star_lookup(t, 0.4, 1.5, dirs, return_hits=True)
+    assert 0.15 < hits.mean() < 0.4  # expected ~0.26 hits per lookup
+    for k in range(0, 20000, 4):
+        ref, nref = oracle.star_lookup(ix, 0.4, 1.5, dirs[k])
+        assert hits[k] == nref
+        np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
+    t.close()
+
+
+def test_supersample_is_the_2x2_mean_of_the_doubled_render(tree):
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 50, 30)
+    big = bs.render(scenes.with_res(cfg, 100, 60, ss=False), tree)
+    st_big = tree.stats()
+    small = bs.render(cfg, tree)
+    st_small = tree.stats()
+    exp = 0.25 * (((big[0::2, 0::2] + big[1::2, 0::2]) + big[0::2, 1::2]) + big[1::2, 1::2])  # ImageFilters.hs:94-96
+    assert np.array_equal(small, exp)
+    assert st_small["steps"] == st_big["steps"] and st_small["rays"] == st_big["rays"]
+
+
+@pytest.mark.parametrize("w,h,ss", [(1, 1, False), (1, 1, True), (17, 9, True), (33, 5, False), (16, 16, True), (2, 31, False)])
+def test_ragged_resolutions(w, h, ss, tree, oracle, oracle_index):
+    cfg = scenes.with_res(scenes.LENSING_DISK, w, h, ss=ss)
+    img = bs.render(cfg, tree)
+    ref, st = oracle.render(cfg, oracle_index, threads=1)
+    np.testing.assert_allclose(img, ref, rtol=RTOL_STRICT, atol=ATOL_STRICT)
+    assert tree.stats()["steps"] == st["steps"]
+
+
+def test_empty_star_set_and_transparent_disk(tree_empty):
+    cfg = scenes.with_res(scenes.DEFAULT, 64, 36)
+    cfg["disk_opacity"] = 0.0
+    img = bs.render(cfg, tree_empty)
+    assert np.all(img == 0) and tree_empty.stats()["disk_hits"] == 0
+
+
+def test_step_cap_reports_capped_rays(tree_empty):
+    cfg = scenes.with_res(scenes.DEFAULT, 16, 9)
+    tree_empty.set_max_steps(50)
+    try:
+        bs.render(cfg, tree_empty)
+        st = tree_empty.stats()
+    finally:
+        tree_empty.set_max_steps(100000)
+    assert st["capped"] == 144 and st["steps"] == 50 * 144
+
+
+def test_error_behaviour(tree, catalogue_bytes):
+    L = _lib.lib()
+    cfg = _lib.make_config(scenes.with_res(scenes.DEFAULT, 8, 8))
+    out = np.zeros(8 * 8 * 3)
+    assert L.bs_render(tree.handle, C.byref(cfg), out.ctypes.data, out.size - 1) == -1 and b"too small" in L.bs_last_error()
+    assert L.bs_render(None, C.byref(cfg), out.ctypes.data, out.size) == -1
+    bad = _lib.make_config(scenes.with_res(scenes.DEFAULT, 0, 8))
+    assert L.bs_render(tree.handle, C.byref(bad), out.ctypes.data, out.size) == -1
+    hue = dict(scenes.with_res(scenes.DEFAULT, 8, 8), disk_hsi=(1.0, 0.1, 1.0))  # hue 360 deg: reference raises an error
+    assert L.bs_render(tree.handle, C.byref(_lib.make_config(hue)), out.ctypes.data, out.size) == -1
+    assert b"not properly scaled" in L.bs_last_error()
+    stars = bs.read_map(catalogue_bytes).copy()
+    stars["hue"][3] = 1.5
+    with pytest.raises(bs._lib.BlackstarError):
+        bs.StarTree(stars)
+    assert not L.bs_create(99, None, 0)
+
+
+def test_render_device_matches_render_and_batch(tree):
+    import torch
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 64, 36)
+    ref = bs.render(cfg, tree)
+    out = torch.zeros((36, 64, 3), dtype=torch.float64, device="cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        bs.render_device(cfg, tree, out.data_ptr(), out.numel(), s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    # batch mode: frames round-robin over contexts (one here)
+    L = _lib.lib()
+    cfgs = (_lib.BsConfig * 3)(*[_lib.make_config(scenes.with_res(scenes.ani_frame(i, 600), 40, 24)) for i in (0, 300, 599)])
+    outs = [np.zeros((24, 40, 3)) for _ in range(3)]
+    ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in outs])
+    ctxs = (C.c_void_p * 1)(tree.handle)
+    _lib.check(L.bs_render_batch(ctxs, 1, cfgs, 3, ptrs), "bs_render_batch")
+    for i, f in enumerate((0, 300, 599)):
+        assert np.array_equal(outs[i], bs.render(scenes.with_res(scenes.ani_frame(f, 600), 40, 24), tree))
+
+
+def test_c2_full_size_vs_oracle(tree_empty, oracle, oracle_index_empty):
+    """BASELINE configs[1]: default.yaml 1920x1080, no starmap -- whole frame against the threaded oracle."""
+    cfg = scenes.DEFAULT
+    img = bs.render(cfg, tree_empty)
+    st = tree_empty.stats()
+    ref, ost = oracle.render(cfg, oracle_index_empty, threads=0)
+    assert st["steps"] == ost["steps"] and st["horizon"] == ost["horizon"] and st["escaped"] == ost["escaped"]
+    assert st["disk_hits"] == ost["disk_hits"] and st["capped"] == 0
+    bad = np.abs(img - ref) > ATOL_STRICT + RTOL_STRICT * np.abs(ref)
+    assert bad.sum() == 0
+
+
+def test_c3_c4_full_size_properties(oracle):
+    """BASELINE configs[2], [3] at full size through size-independent properties: sampled rays bit-exact vs the
+    oracle, FAST vs STRICT within the north_star tolerance on every pixel, equal step checksums."""
+    stars = bs.read_map(synthetic.ppm_catalogue_bytes())
+    t = bs.StarTree(stars)
+    ix = oracle.Index(oracle.read_ppm(synthetic.ppm_catalogue_bytes()))
+    rng = np.random.default_rng(2026)
+    for cfg in (scenes.DEFAULT_AA, scenes.with_res(scenes.LENSING_DISK, 3840, 2160)):
+        wt, ht = 2 * cfg["width"], 2 * cfg["height"]
+        ys, xs = rng.integers(0, ht, 4096), rng.integers(0, wt, 4096)
+        rec = bs.trace_rays(cfg, t, ys, xs)
+        orc = oracle.trace_rays(cfg, ix, ys, xs)
+        for k in ("steps", "fate", "disk_hits", "star_hits", "vel", "pos"):
+            assert np.array_equal(rec[k], orc[k]), k
+        np.testing.assert_allclose(rec["rgba"], orc["rgba"], rtol=RTOL_STRICT, atol=ATOL_STRICT)
+        strict = bs.render(cfg, t)
+        st_s = t.stats()
+        t.set_mode(_lib.BS_MODE_FAST)
+        fast = bs.render(cfg, t)
+        st_f = t.stats()
+        t.set_mode(_lib.BS_MODE_STRICT)
+        assert st_s["rays"] == wt * ht and st_s["capped"] == 0
+        assert (st_s["horizon"], st_s["escaped"]) == (st_f["horizon"], st_f["escaped"])
+        assert abs(int(st_s["steps"]) - int(st_f["steps"])) <= 8
+        bad = np.abs(fast - strict) > ATOL_FAST + RTOL_FAST * np.abs(strict)
+        assert bad.sum() == 0, f"{bad.sum()} values of {bad.size} outside 1e-4"
+        assert np.isfinite(strict).all() and strict.min() >= 0
+    t.close()

@@ -1,0 +1,116 @@
+"""CPU tests of the host logic and of the C-ABI library (load + exported symbols; no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import blackstar_amd as bs
+from blackstar_amd import _lib, synthetic
+from conftest import ROOT
+from oracle import scenes
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "blackstar_gpu.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(bs_[a-z0-9_]+)\s*\(", text))
+    assert {"bs_create", "bs_render", "bs_render_device", "bs_destroy", "bs_stats", "bs_last_error"} <= declared
+    L = _lib.lib()
+    for sym in sorted(declared):
+        assert hasattr(L, sym), f"{sym} declared in include/blackstar_gpu.h but not exported"
+    assert set(_lib.SYMBOLS) <= declared
+    assert L.bs_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.BsConfig) == 19 * 8 + 4 * 4
+    assert _lib.STAR_DTYPE.itemsize == 48 and _lib.RECORD_DTYPE.itemsize == 96
+    assert ctypes.sizeof(_lib.BsStats) == 9 * 8
+
+
+def test_no_cpu_backend():
+    L = _lib.lib()
+    assert not L.bs_create(-1, None, 0)
+    assert b"no CPU backend" in L.bs_last_error()
+
+
+def test_scene_files_resolve_to_appendix_c():
+    for fn, exp in (("default.yaml", scenes.DEFAULT), ("default-aa.yaml", scenes.DEFAULT_AA), ("lensing-disk.yaml", scenes.LENSING_DISK)):
+        got = bs.Config.from_file(os.path.join(ROOT, "scenes", fn)).to_bs_config()
+        assert got == exp, fn
+    c = bs.Config.from_file(os.path.join(ROOT, "scenes", "default.yaml"))
+    assert (c.scene.bloomStrength, c.scene.bloomDivider) == (0.15, 25)
+    assert c.with_resolution(640, 480).to_bs_config()["width"] == 640
+
+
+def test_config_defaults_and_errors():
+    c = bs.Config.from_yaml("camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1}\nscene: {}\n")
+    s = c.scene  # src/ConfigFile.hs:66-79
+    assert (s.stepSize, s.bloomStrength, s.bloomDivider, s.starIntensity, s.starSaturation) == (0.3, 0.4, 25, 0.7, 0.7)
+    assert s.diskColor == (0.16, 0.1, 0.95) and (s.diskOpacity, s.diskInner, s.diskOuter) == (0.0, 3.0, 12.0)
+    assert s.resolution == (1280, 720) and s.supersampling is False and s.safeDistance == 0.0
+    for bad in ("scene: {}\n", "camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0]}\nscene: {}\n",
+                "camera: {position: [1,2], lookAt: [0,0,0], upVec: [0,1,0], fov: 1}\nscene: {}\n",
+                "camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1}\nscene: 3\n", "- 1\n", ": : :"):
+        with pytest.raises(bs.ConfigError):
+            bs.Config.from_yaml(bad)
+    c2 = bs.Config.from_yaml(c.to_yaml())  # ToJSON round trip (hue * 360 and back)
+    assert c2.to_bs_config() == pytest.approx(c.to_bs_config())
+    p = bs.prepare_scene(bs.Config.from_file(os.path.join(ROOT, "scenes", "default.yaml")), True)  # app/Main.hs:93-103
+    assert p.scene.resolution == (300, 168) and p.scene.supersampling is False and p.scene.bloomStrength == 0
+
+
+def test_animation_frames_match_independent_restatement():
+    a = bs.Animation.from_file(os.path.join(ROOT, "animations", "default-ani.yaml"))
+    assert a.nFrames == 375 and len(a.keyframes) == 2
+    assert a.scene.diskColor == (0.16, 0.1, 0.95)  # 'diskHSV' is not a parsed key -> default
+    bs.validate_keyframes(a.keyframes)
+    a.nFrames = 600
+    frames = bs.generate_frames(a)
+    assert len(frames) == 600
+    for i in (0, 1, 299, 300, 598, 599):
+        assert frames[i].to_bs_config() == scenes.ani_frame(i, 600)
+    with pytest.raises(bs.ConfigError):
+        bs.validate_keyframes(a.keyframes[:1])
+    a.keyframes[1].time = 0.9
+    with pytest.raises(bs.ConfigError):
+        bs.validate_keyframes(a.keyframes)
+
+
+def test_synthetic_catalogue_layout_and_reader(catalogue_bytes, oracle):
+    data = synthetic.ppm_catalogue_bytes(2000, synthetic.SEED + 1)
+    assert data == catalogue_bytes  # vectorised generator == the scalar one that made the fixture
+    stars = bs.read_map(data)
+    assert len(stars) == 2000
+    assert stars.tobytes() == oracle.read_ppm(data).tobytes()  # product reader vs oracle reader, bit for bit
+    g = np.load(os.path.join(ROOT, "tests", "golden", "catalogue_2000_parsed.npz"))["stars"]
+    for i, k in enumerate(("x", "y", "z", "hue", "sat")):
+        assert np.array_equal(stars[k], g[:, i])
+    assert np.array_equal(stars["mag"], g[:, 5].astype(np.int32))
+    np.testing.assert_allclose(stars["x"] ** 2 + stars["y"] ** 2 + stars["z"] ** 2, 1.0, rtol=1e-15)
+    assert (stars["mag"] >= 500).all() and (stars["mag"] <= 1200).all()
+    with pytest.raises(bs.BlackstarError if hasattr(bs, "BlackstarError") else Exception):
+        bs.read_map(b"too short")
+    assert len(bs.read_map(bytes(28))) == 0
+
+
+def test_host_hsi_matches_oracle(oracle):
+    L = _lib.lib()
+    out = np.zeros(3)
+    for h, s, i in ((0.5, 0.1, 1.05), (0.16, 0.1, 0.95), (0.631, 0.585, 0.4), (0.0, 0.0, 0.3), (0.999, 0.5, 0.2)):
+        assert L.bs_hsi_to_rgb(h, s, i, out.ctypes.data) == 0
+        assert np.array_equal(out, oracle.hsi_to_rgb(h, s, i))
+    assert L.bs_hsi_to_rgb(1.0, 0.1, 0.5, out.ctypes.data) == -1
+    assert L.bs_hsi_to_rgb(-0.1, 0.1, 0.5, out.ctypes.data) == -1
+
+
+def test_tree_serialisation_roundtrip(tmp_path, catalogue_bytes):
+    stars = bs.read_map(catalogue_bytes)
+    blob = bs.tree_to_byte_string(stars)
+    assert blob[:5] == b"BSKD1" and len(blob) == 16 + 48 * len(stars)
+    p = tmp_path / "stars.bskd"
+    p.write_bytes(blob[:-1])
+    with pytest.raises(Exception):
+        bs.read_tree_from_file(str(p))

@@ -1,0 +1,176 @@
+"""CPU tests that pin the oracle (the reference has no tests and cannot be built here -- 'parity unpinned'):
+C restatement vs golden vectors from the independent numpy restatement, vs 50-digit mpmath, vs physics and
+colour known-answers."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import IMAGE_GOLDENS, TRACE_GOLDENS, load_golden
+from oracle import np_oracle, scenes
+
+
+@pytest.mark.parametrize("name", IMAGE_GOLDENS)
+def test_c_oracle_matches_golden_images(name, oracle, oracle_index, oracle_index_empty):
+    g = load_golden("image_" + name)
+    ix = oracle_index_empty if "nostars" in name else oracle_index
+    img, st = oracle.render(g["cfg"], ix, threads=2)
+    assert st["steps"] == int(g["total_steps"])
+    assert [st["horizon"], st["escaped"], st["capped"]] == list(g["fate_counts"])
+    assert st["disk_hits"] == int(g["disk_hits"]) and st["star_hits"] == int(g["star_hits"])
+    # both are binary64 restatements of the same operation order: transcendental libm calls are the only
+    # place they may differ (they do not, here), so demand near-bit equality
+    np.testing.assert_allclose(img, g["img"], rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", TRACE_GOLDENS)
+def test_c_oracle_matches_golden_traces(name, oracle, oracle_index):
+    g = load_golden("trace_" + name)
+    rec = oracle.trace_rays(g["cfg"], oracle_index, g["ys"], g["xs"])
+    assert np.array_equal(rec["steps"], g["steps"])
+    assert np.array_equal(rec["fate"], g["fate"])
+    assert np.array_equal(rec["disk_hits"], g["disk_hits"])
+    assert np.array_equal(rec["star_hits"], g["star_hits"])
+    assert np.array_equal(rec["vel"], g["vel"]) and np.array_equal(rec["pos"], g["pos"])  # bit-exact trajectories
+    np.testing.assert_allclose(rec["rgba"], g["rgba"], rtol=1e-13, atol=1e-15)
+    for k in range(0, len(g["ys"]), 37):
+        v, p = oracle.generate_ray(g["cfg"], int(g["ys"][k]), int(g["xs"][k]))
+        assert np.array_equal(v, g["vel0"][k])
+
+
+def test_mpmath_pins_discrete_map(oracle, oracle_index_empty):
+    from oracle import mp_oracle
+    g = load_golden("trace_c3")
+    cfg = g["cfg"]
+    sc = np_oracle.derive(cfg)
+    pick = list(range(0, 384, 29))
+    for k in pick:
+        steps, fate, v, p = mp_oracle.trace(g["vel0"][k], sc["cam"], sc["h"], sc["safe"])
+        assert steps == int(g["steps"][k]) and fate == int(g["fate"][k])
+        for a, b in zip(list(v) + list(p), list(g["vel"][k]) + list(g["pos"][k])):
+            assert abs(float(a) - b) <= 1e-11 * max(1.0, abs(b))
+
+
+def _fly(oracle, b, x0=-1000.0, h=0.3, max_steps=200000):
+    """Photon launched from (x0, b, 0) along +x; returns (captured, final velocity)."""
+    vel, pos = np.array([1.0, 0.0, 0.0]), np.array([x0, b, 0.0])
+    h2 = float(np_oracle.quadrance(np_oracle.cross(pos, vel)))
+    for _ in range(max_steps):
+        r2 = float(pos @ pos)
+        if r2 < 1:
+            return True, vel
+        if r2 > 2 * x0 * x0:
+            return False, vel
+        vel, pos = oracle.rk4(h, h2, vel, pos)
+    raise AssertionError("did not terminate")
+
+
+def test_physics_capture_threshold(oracle):
+    # critical impact parameter of the Schwarzschild photon sphere: b_c = 3*sqrt(3)/2 (r_s = 1)
+    assert math.isclose(3 * math.sqrt(3) / 2, 2.598076, rel_tol=1e-6)
+    assert _fly(oracle, 2.597)[0] is True
+    assert _fly(oracle, 2.599)[0] is False
+
+
+def test_physics_weak_field_deflection(oracle):
+    # deflection angle -> 2 r_s / b = 2/b as b -> infinity
+    for b, tol in ((50.0, 0.04), (200.0, 0.01)):
+        cap, v = _fly(oracle, b)
+        assert not cap
+        ang = math.atan2(-v[1], v[0])
+        assert abs(ang * b / 2 - 1.0) < tol
+
+
+def test_physics_angular_momentum_plane(oracle):
+    vel, pos = np.array([0.3, 0.1, 0.9486832980505138]), np.array([5.0, 1.0, -20.0])
+    L0 = np.cross(pos, vel)
+    h2 = float(L0 @ L0)
+    for _ in range(150):
+        vel, pos = oracle.rk4(0.3, h2, vel, pos)
+    L1 = np.cross(pos, vel)
+    assert np.linalg.norm(np.cross(L0, L1)) / (L0 @ L0) < 1e-9  # direction of pos x vel conserved
+
+
+def test_physics_photon_sphere_orbit(oracle):
+    # tangential launch at r = 1.5 with |v| = 1: circular orbit for the continuous ODE; the discrete h = 0.3
+    # map stays within 1e-2 of r = 1.5 for a full revolution (2*pi*1.5/0.3 ~ 31 steps)
+    vel, pos = np.array([0.0, 0.0, 1.0]), np.array([1.5, 0.0, 0.0])
+    h2 = 1.5 ** 2
+    rs = []
+    for _ in range(31):
+        vel, pos = oracle.rk4(0.3, h2, vel, pos)
+        rs.append(math.sqrt(pos @ pos))
+    assert max(abs(r - 1.5) for r in rs) < 1e-2
+
+
+def test_colour_kats(oracle):
+    # SURVEY.md 8c (5) / B.3
+    np.testing.assert_allclose(oracle.hsi_to_rgb(0.5, 0.1, 1.05), (0.945, 1.1025, 1.1025), rtol=1e-14)
+    np.testing.assert_allclose(oracle.hsi_to_rgb(0.16, 0.1, 0.95), (1.0009482357819488, 0.9940517642180511, 0.855), rtol=1e-14)
+    np.testing.assert_allclose(oracle.hsi_to_rgb(0.0, 1.0, 1 / 3), (1.0, 0.0, 0.0), atol=1e-15)
+    table = {"O": (0.631, 0.39, (0.166000, 0.298464, 0.735536)), "B": (0.628, 0.33, (0.202000, 0.320938, 0.677062)),
+             "A": (0.622, 0.21, (0.274000, 0.357919, 0.568081)), "F": (0.650, 0.03, (0.382000, 0.387544, 0.430456)),
+             "G": (0.089, 0.09, (0.451824, 0.402176, 0.346000)), "K": (0.094, 0.29, (0.561017, 0.412983, 0.226000)),
+             "M": (0.094, 0.56, (0.710930, 0.425070, 0.064000))}
+    for hue, sat, rgb in table.values():
+        np.testing.assert_allclose(oracle.hsi_to_rgb(hue, 1.5 * sat, 0.4), rgb, atol=6e-7)
+    assert np.array_equal(oracle.hsi_to_rgb(0.0, 0.0, 0.4), (0.4, 0.4, 0.4))
+    assert np.all(np.isnan(oracle.hsi_to_rgb(1.0, 0.1, 0.5)))  # reference: error "not properly scaled"
+    v = np_oracle.hsi_to_rgb(np.array([0.1, 0.4, 0.9]), 0.3, 0.7)
+    for k, h in enumerate((0.1, 0.4, 0.9)):
+        np.testing.assert_allclose(v[k], oracle.hsi_to_rgb(h, 0.3, 0.7), rtol=1e-15)
+
+
+def test_catalogue_reader_kat(oracle):
+    import struct
+    rec = [(1.0, 0.5, b"G", 650), (4.0, -1.2, b"M", -146), (0.0, 0.0, b"?", 1200)]
+    data = bytes(28) + b"".join(struct.pack(">ddcBh8x", ra, dec, sp, 0, mag) for ra, dec, sp, mag in rec) + b"\x01\x02\x03"
+    s = oracle.read_ppm(data)
+    assert len(s) == 3  # trailing partial record ignored (nBytes `div` 28)
+    assert s["mag"].tolist() == [650, -146, 1200]
+    assert (s["hue"][0], s["sat"][0]) == (0.089, 0.09) and (s["hue"][1], s["sat"][1]) == (0.094, 0.56) and (s["hue"][2], s["sat"][2]) == (0, 0)
+    for k, (ra, dec, _, _) in enumerate(rec):
+        assert s["x"][k] == math.cos(dec) * math.cos(ra) and s["y"][k] == math.cos(dec) * math.sin(ra) and s["z"][k] == math.sin(dec)
+    with pytest.raises(ValueError):
+        oracle.read_ppm(b"short")
+
+
+def test_star_lookup_grid_vs_brute_force(oracle, oracle_stars, oracle_index):
+    rng = np.random.default_rng(7)
+    dirs = rng.normal(size=(3000, 3))
+    # aim a third of the queries near actual stars so that hits occur
+    near = oracle_stars[rng.integers(0, len(oracle_stars), 1000)]
+    dirs[:1000] = np.stack([near["x"], near["y"], near["z"]], axis=1) * rng.uniform(0.5, 3, (1000, 1)) + rng.normal(scale=4e-4, size=(1000, 3))
+    nhit = 0
+    for d in dirs:
+        a, na = oracle.star_lookup(oracle_index, 0.4, 1.5, d)
+        b, nb = oracle.star_lookup(oracle_index, 0.4, 1.5, d, brute=True)
+        assert na == nb and np.array_equal(a, b)
+        nhit += na
+    assert nhit > 500
+    rgb, hits = np_oracle.star_lookup(np.load("tests/golden/catalogue_2000_parsed.npz")["stars"], 0.4, 1.5, dirs[:300])
+    for k in range(300):
+        a, na = oracle.star_lookup(oracle_index, 0.4, 1.5, dirs[k])
+        assert na == hits[k]
+        np.testing.assert_allclose(a, rgb[k], rtol=1e-14, atol=1e-16)
+
+
+def test_supersample_order(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 2, (10, 14, 3))
+    out = oracle.supersample(img)
+    exp = 0.25 * (((img[0::2, 0::2] + img[1::2, 0::2]) + img[0::2, 1::2]) + img[1::2, 1::2])
+    assert np.array_equal(out, exp)
+
+
+def test_empty_star_set_is_black_sky(oracle, oracle_index_empty):
+    cfg = scenes.with_res(scenes.DEFAULT, 32, 18)
+    cfg["disk_opacity"] = 0.0
+    img, st = oracle.render(cfg, oracle_index_empty)
+    assert st["disk_hits"] == 0 and np.all(img == 0)  # no starmap == empty star set
+
+
+def test_step_cap(oracle, oracle_index_empty):
+    cfg = scenes.with_res(scenes.DEFAULT, 16, 9)
+    img, st = oracle.render(cfg, oracle_index_empty, max_steps=50)
+    assert st["capped"] == 16 * 9 and st["steps"] == 50 * 16 * 9
