@@ -47,6 +47,30 @@ class BlackstarError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64 under torch/lib.  Two HSA
+    runtimes in one process cannot both own the device ("No HIP GPUs are available" in whichever initialises
+    second), so when a torch install is present its runtime is made the process-wide one BEFORE this library's
+    NEEDED libamdhip64.so.7 is resolved (same soname -> the loader reuses it).  Without torch (e.g. the Haskell
+    host) the library resolves /opt/rocm's runtime through its RUNPATH.  This does not import torch."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # already loaded: soname match reuses it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -54,6 +78,7 @@ def lib() -> C.CDLL:
     if not os.path.exists(SO_PATH):
         raise BlackstarError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(SO_PATH)
     vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
     L.bs_create.restype = vp
@@ -64,7 +89,7 @@ def lib() -> C.CDLL:
     L.bs_render_device.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
     L.bs_render_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.bs_trace_rays.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
-    L.bs_debug_sqrt_div.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.bs_debug_sqrt_div.argtypes = [vp, vp, vp, sz, vp, vp, C.c_int]
     L.bs_star_lookup.argtypes = [vp, dp, dp, vp, sz, vp, vp]
     L.bs_set_mode.argtypes = [vp, C.c_int]
     L.bs_get_mode.argtypes = [vp]

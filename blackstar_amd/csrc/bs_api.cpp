@@ -319,7 +319,7 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
     return BS_OK;
 }
 
-int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div)
+int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare)
 {
     if (!ctx || (n && (!a || !b || !out_sqrt || !out_div))) return fail(BS_EINVAL, "null argument");
     if (n == 0) return BS_OK;
@@ -328,7 +328,7 @@ int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, d
     HIP_TRY(hipMalloc((void **)&d, 4 * n * sizeof(double)));
     hipError_t e = hipMemcpy(d, a, n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + n, b, n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && bs::launch_sqrt_div(d, d + n, n, d + 2 * n, d + 3 * n, ctx->stream)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess && bs::launch_sqrt_div(d, d + n, n, d + 2 * n, d + 3 * n, bare, ctx->stream)) e = hipErrorLaunchFailure;
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out_sqrt, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_div, d + 3 * n, n * sizeof(double), hipMemcpyDeviceToHost);

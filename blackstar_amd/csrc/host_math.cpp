@@ -87,6 +87,9 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
     p.h = c.step_size;
     p.hh = c.step_size / 2;  // rk4: h / 2, h / 6  (:130-134)
     p.h6 = c.step_size / 6;
+    p.hh2 = p.hh * p.hh;              // FAST mode only (see trace_kernel.hip rk4<true>)
+    p.hhh = c.step_size * p.hh;
+    p.h2_6 = c.step_size * p.h6;
     double a = 50.0 * 50.0, b = 2 * quadrance(c.cam_pos);  // :59-60, max x y = if x <= y then y else x
     p.safe = (a <= b) ? b : a;
     p.in2 = c.disk_inner * c.disk_inner;   // :61

@@ -28,52 +28,87 @@ __device__ __forceinline__ double quadrance(double x, double y, double z) { retu
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
 __device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 
-// c such that the velocity derivative is -(c * pos):  c = (1.5*h2) / |pos|^5   (Raytracer.hs:127)
-template <bool FAST>
-__device__ __forceinline__ double accel_coef(double h2c, double px, double py, double pz)
+// ---- correctly rounded f64 sqrt / divide without the range scaling -------------------------------------
+// hipcc lowers f64 sqrt and '/' to exactly these FMA sequences wrapped in v_ldexp / v_div_scale /
+// v_div_fixup range handling (only active for |x| < 2^-767 or extreme exponent gaps).  In the RK4 RHS the
+// operands are r^2 in [~1e-3, ~1e4] and r^5, so the scaling never triggers and the bare sequences return
+// the same bits -- tests/test_gpu_parity.py checks both against IEEE results on 2^20 operands.
+__device__ __forceinline__ double sqrt_rn(double x)
 {
-    if constexpr (!FAST) {
-        double n = __builtin_sqrt(quadrance(px, py, pz));  // norm pos
-        double n2 = n * n;
-        double n5 = (n2 * n2) * n;  // x^5 = ((x*x)*(x*x))*x  (GHC.Real (^))
-        return h2c / n5;
-    } else {
-        // |pos|^-5 from v_rsq_f64 (~2^-26) + one cubic Newton step (-> ~1 ulp), no sqrt, no divide.
-        double q = __builtin_fma(pz, pz, __builtin_fma(py, py, px * px));
-        double y0 = __builtin_amdgcn_rsq(q);
-        double t = q * y0;
-        double e = __builtin_fma(-t, y0, 1.0);
-        double p = __builtin_fma(0.375, e, 0.5);
-        double y1 = __builtin_fma(y0 * e, p, y0);
-        double y2 = y1 * y1;
-        double y4 = y2 * y2;
-        return h2c * (y4 * y1);
-    }
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
 }
 
-// One classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134)
-template <bool FAST>
-__device__ __forceinline__ void rk4(const TraceParams &P, double h2c, const double v[3], const double p[3], double nv[3], double np[3])
+__device__ __forceinline__ double div_rn(double a, double b)
 {
-    const double h = P.h, hh = P.hh, h6 = P.h6;
-    double a1[3], a2[3], a3[3], a4[3], v2[3], v3[3], v4[3], q[3];
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// STRICT: c = (1.5*h2) / |pos|^5 with q = quadrance pos given   (Raytracer.hs:127)
+__device__ __forceinline__ double coef_strict(double h2c, double q)
+{
+    double n = sqrt_rn(q);      // norm pos
+    double n2 = n * n;
+    double n5 = (n2 * n2) * n;  // x^5 = ((x*x)*(x*x))*x  (GHC.Real (^))
+    return div_rn(h2c, n5);
+}
+
+// FAST: -(1.5*h2) * |pos|^-5 from v_rsq_f64 (~2^-26) + one cubic Newton step (-> ~1 ulp); no sqrt, no divide.
+__device__ __forceinline__ double coef_fast(double nh2c, double q)
+{
+    double y0 = __builtin_amdgcn_rsq(q);
+    double t = q * y0;
+    double e = __builtin_fma(-t, y0, 1.0);
+    double p = __builtin_fma(0.375, e, 0.5);
+    double y1 = __builtin_fma(y0 * e, p, y0);
+    double y2 = y1 * y1;
+    double y4 = y2 * y2;
+    return (nh2c * y1) * y4;
+}
+
+__device__ __forceinline__ double quadrance_fma(double x, double y, double z) { return __builtin_fma(z, z, __builtin_fma(y, y, x * x)); }
+
+// One classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134).
+// r2 = quadrance pos on entry (carried from the previous step's findColor), r2n = quadrance newPos on exit.
+template <bool FAST>
+__device__ __forceinline__ void rk4(const TraceParams &P, double h2c, double r2, const double v[3], const double p[3], double nv[3],
+                                    double np[3], double &r2n)
+{
     if constexpr (!FAST) {
-        double c = accel_coef<false>(h2c, p[0], p[1], p[2]);
+        // the reference's operation order, one IEEE operation each (this TU is compiled -ffp-contract=off)
+        const double h = P.h, hh = P.hh, h6 = P.h6;
+        double a1[3], a2[3], a3[3], a4[3], v2[3], v3[3], v4[3], q[3];
+        double c = coef_strict(h2c, r2);
 #pragma unroll
         for (int i = 0; i < 3; i++) a1[i] = -(c * p[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) { v2[i] = v[i] + a1[i] * hh; q[i] = p[i] + v[i] * hh; }
-        c = accel_coef<false>(h2c, q[0], q[1], q[2]);
+        c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
         for (int i = 0; i < 3; i++) a2[i] = -(c * q[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) { v3[i] = v[i] + a2[i] * hh; q[i] = p[i] + v2[i] * hh; }
-        c = accel_coef<false>(h2c, q[0], q[1], q[2]);
+        c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
         for (int i = 0; i < 3; i++) a3[i] = -(c * q[i]);
 #pragma unroll
         for (int i = 0; i < 3; i++) { v4[i] = v[i] + a3[i] * h; q[i] = p[i] + v3[i] * h; }
-        c = accel_coef<false>(h2c, q[0], q[1], q[2]);
+        c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
         for (int i = 0; i < 3; i++) a4[i] = -(c * q[i]);
 #pragma unroll
@@ -83,32 +118,32 @@ __device__ __forceinline__ void rk4(const TraceParams &P, double h2c, const doub
             nv[i] = v[i] + sv * h6;
             np[i] = p[i] + sp * h6;
         }
+        r2n = quadrance(np[0], np[1], np[2]);
     } else {
-        double c = -accel_coef<true>(h2c, p[0], p[1], p[2]);
+        // Same RK4, regrouped for x'' = a(x) (the RHS does not depend on vel), every multiply-add fused:
+        //   p2 = p + (h/2) v          p3 = p2 + (h^2/4) a1        p4 = (p + h v) + (h^2/2) a2
+        //   np = (p + h v) + (h^2/6)(a1 + a2 + a3)                nv = v + (h/6)(a1 + 2(a2 + a3) + a4)
+        // (algebraically identical to the reference's stage formulas; rounding differs at the 1e-16 level)
+        const double nh2c = -h2c;
+        double a1[3], a2[3], a3[3], a4[3], q0[3], q[3];
+        double c = coef_fast(nh2c, r2);
 #pragma unroll
-        for (int i = 0; i < 3; i++) a1[i] = c * p[i];
+        for (int i = 0; i < 3; i++) { a1[i] = c * p[i]; q[i] = __builtin_fma(P.hh, v[i], p[i]); }
+        c = coef_fast(nh2c, quadrance_fma(q[0], q[1], q[2]));
 #pragma unroll
-        for (int i = 0; i < 3; i++) { v2[i] = __builtin_fma(a1[i], hh, v[i]); q[i] = __builtin_fma(v[i], hh, p[i]); }
-        c = -accel_coef<true>(h2c, q[0], q[1], q[2]);
+        for (int i = 0; i < 3; i++) { a2[i] = c * q[i]; q[i] = __builtin_fma(P.hh2, a1[i], q[i]); }
+        c = coef_fast(nh2c, quadrance_fma(q[0], q[1], q[2]));
 #pragma unroll
-        for (int i = 0; i < 3; i++) a2[i] = c * q[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { v3[i] = __builtin_fma(a2[i], hh, v[i]); q[i] = __builtin_fma(v2[i], hh, p[i]); }
-        c = -accel_coef<true>(h2c, q[0], q[1], q[2]);
-#pragma unroll
-        for (int i = 0; i < 3; i++) a3[i] = c * q[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { v4[i] = __builtin_fma(a3[i], h, v[i]); q[i] = __builtin_fma(v3[i], h, p[i]); }
-        c = -accel_coef<true>(h2c, q[0], q[1], q[2]);
-#pragma unroll
-        for (int i = 0; i < 3; i++) a4[i] = c * q[i];
+        for (int i = 0; i < 3; i++) { a3[i] = c * q[i]; q0[i] = __builtin_fma(P.h, v[i], p[i]); q[i] = __builtin_fma(P.hhh, a2[i], q0[i]); }
+        c = coef_fast(nh2c, quadrance_fma(q[0], q[1], q[2]));
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            double sv = __builtin_fma(2.0, a3[i], __builtin_fma(2.0, a2[i], a1[i])) + a4[i];
-            double sp = __builtin_fma(2.0, v3[i], __builtin_fma(2.0, v2[i], v[i])) + v4[i];
-            nv[i] = __builtin_fma(sv, h6, v[i]);
-            np[i] = __builtin_fma(sp, h6, p[i]);
+            a4[i] = c * q[i];
+            double s23 = a2[i] + a3[i];
+            np[i] = __builtin_fma(P.h2_6, a1[i] + s23, q0[i]);
+            nv[i] = __builtin_fma(P.h6, __builtin_fma(2.0, s23, a1[i]) + a4[i], v[i]);
         }
+        r2n = quadrance_fma(np[0], np[1], np[2]);
     }
 }
 
@@ -195,6 +230,20 @@ struct RayResult {
     int steps, fate, disk_hits, star_hits;
 };
 
+// diskColor' (Raytracer.hs:104-111) blended under the accumulated colour (blend, :34-37).
+__device__ __forceinline__ void shade_disk(const TraceParams &P, double r2ave, double rgba[4])
+{
+    const double pi = 3.141592653589793;
+    double r = __builtin_sqrt(r2ave);
+    double t = (P.rO - r) / (P.rO - P.rI);
+    double inten = sin(pi * (t * t));
+    double om = 1 - rgba[3];  // top + layer * (1 - top_alpha), all four channels
+    rgba[0] = rgba[0] + (P.disk_rgb[0] * inten) * om;
+    rgba[1] = rgba[1] + (P.disk_rgb[1] * inten) * om;
+    rgba[2] = rgba[2] + (P.disk_rgb[2] * inten) * om;
+    rgba[3] = rgba[3] + (inten * P.disk_opacity) * om;
+}
+
 // traceRay + colorize for traced pixel (yi, xi).
 template <bool FAST>
 __device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, int yi, int xi, RayResult &res)
@@ -220,6 +269,12 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *
 
     double rgba[4] = {0, 0, 0, 0};
     int steps = 0, fate = 2, disk_hits = 0, star_hits = 0;
+    // Disk crossings are rare (~0.2 per ray) but their shading (sqrt, divide, sin) is ~150 instructions that
+    // the whole wavefront would sit through each time any lane crosses.  Crossings are therefore only
+    // RECORDED in the loop (r2ave, in order) and shaded after it, when all 64 lanes do it together.  The
+    // arithmetic and the front-to-back order are unchanged; a third pending crossing flushes in place.
+    double pend0 = 0, pend1 = 0;
+    int npend = 0;
     double r2 = quadrance(p[0], p[1], p[2]);
     const bool disk = P.disk_opacity != 0;
     while (steps < P.max_steps) {
@@ -227,30 +282,31 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *
         // findColor guards on the PRE-step position (:93-95); rk4's result is not needed when they fire.
         if (r2 < 1.0) { fate = 0; break; }
         if (r2 > P.safe) { fate = 1; break; }
-        double nv[3], np[3];
-        rk4<FAST>(P, h2c, v, p, nv, np);
-        double r2n = quadrance(np[0], np[1], np[2]);
+        double nv[3], np[3], r2n;
+        rk4<FAST>(P, h2c, r2, v, p, nv, np, r2n);
         double y = p[1], yn = np[1];
-        if (disk && signum(yn) != signum(y)) {  // :96
-            double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
-            if (r2ave > P.in2 && r2ave < P.out2) {           // :97
-                // diskColor' (:104-111)
-                const double pi = 3.141592653589793;
-                double r = __builtin_sqrt(r2ave);
-                double t = (P.rO - r) / (P.rO - P.rI);
-                double inten = sin(pi * (t * t));
-                double om = 1 - rgba[3];  // blend: top + layer * (1 - top_alpha), all four channels (:34-37)
-                rgba[0] = rgba[0] + (P.disk_rgb[0] * inten) * om;
-                rgba[1] = rgba[1] + (P.disk_rgb[1] * inten) * om;
-                rgba[2] = rgba[2] + (P.disk_rgb[2] * inten) * om;
-                rgba[3] = rgba[3] + (inten * P.disk_opacity) * om;
-                disk_hits++;
+        // signum y' /= signum y (:96) can only hold if y*y' is not > 0 (opposite signs, a zero, or NaN)
+        if (disk && !(y * yn > 0.0)) {
+            if (signum(yn) != signum(y)) {
+                double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
+                if (r2ave > P.in2 && r2ave < P.out2) {           // :97
+                    if (npend == 2) {
+                        shade_disk(P, pend0, rgba);
+                        pend0 = pend1;
+                        npend = 1;
+                    }
+                    if (npend == 0) pend0 = r2ave; else pend1 = r2ave;
+                    npend++;
+                    disk_hits++;
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
         r2 = r2n;
     }
+    if (npend > 0) shade_disk(P, pend0, rgba);
+    if (npend > 1) shade_disk(P, pend1, rgba);
     if (fate == 0) {  // Bottom (PixelRGBA 0 0 0 1)
         double om = 1 - rgba[3];
         rgba[0] = rgba[0] + 0.0 * om; rgba[1] = rgba[1] + 0.0 * om; rgba[2] = rgba[2] + 0.0 * om;
@@ -380,12 +436,17 @@ __global__ __launch_bounds__(kBlock) void star_lookup_kernel(const TraceParams P
 }
 
 // Test hook: device sqrt / divide, to check that the f64 lowerings are correctly rounded.
-__global__ void sqrt_div_kernel(const double *a, const double *b, size_t n, double *s, double *d)
+__global__ void sqrt_div_kernel(const double *a, const double *b, size_t n, double *s, double *d, int bare)
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    s[k] = __builtin_sqrt(a[k]);
-    d[k] = a[k] / b[k];
+    if (bare) {  // the scaling-free sequences the STRICT RK4 RHS uses
+        s[k] = sqrt_rn(a[k]);
+        d[k] = div_rn(a[k], b[k]);
+    } else {     // hipcc's own lowering of sqrt and '/'
+        s[k] = __builtin_sqrt(a[k]);
+        d[k] = a[k] / b[k];
+    }
 }
 
 }  // namespace
@@ -417,10 +478,10 @@ int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, dou
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, void *stream)
+int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(sqrt_div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_a, d_b, n, d_sqrt, d_div);
+    hipLaunchKernelGGL(sqrt_div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_a, d_b, n, d_sqrt, d_div, bare);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

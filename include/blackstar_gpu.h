@@ -117,8 +117,9 @@ int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n
 int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const double *dirs, size_t n, double *out_rgb, int32_t *out_hits);
 
 /* Test hook: out_sqrt[i] = sqrt(a[i]), out_div[i] = a[i] / b[i] computed on the device (host buffers);
- * proves the f64 sqrt / divide lowerings STRICT mode relies on are correctly rounded. */
-int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div);
+ * proves the f64 sqrt / divide sequences STRICT mode relies on are correctly rounded.  bare = 0: hipcc's
+ * lowering of sqrt and '/'; bare = 1: the scaling-free FMA sequences used inside the RK4 right-hand side. */
+int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare);
 
 int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_STRICT */
 int bs_get_mode(const bs_ctx *ctx);

@@ -403,6 +403,8 @@ static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     const scene_t *s = j->s;
+    orc_stats acc; /* thread-local accumulator: adjacent job_t structs would false-share a cache line */
+    memset(&acc, 0, sizeof acc);
     for (;;) {
         int y = __sync_fetch_and_add(j->next_row, 1);
         if (y >= s->ht) break;
@@ -411,15 +413,16 @@ static void *worker(void *arg)
             trace_ray(s, j->ix, y, x, j->max_steps, &r);
             double *p = &j->img[((size_t)y * s->wt + x) * 3];
             p[0] = r.rgba[0]; p[1] = r.rgba[1]; p[2] = r.rgba[2]; /* dropAlpha */
-            j->st.rays++;
-            j->st.steps += (uint64_t)r.steps;
-            j->st.capped += (r.fate == 2);
-            j->st.horizon += (r.fate == 0);
-            j->st.escaped += (r.fate == 1);
-            j->st.disk_hits += (uint64_t)r.disk_hits;
-            j->st.star_hits += (uint64_t)r.star_hits;
+            acc.rays++;
+            acc.steps += (uint64_t)r.steps;
+            acc.capped += (r.fate == 2);
+            acc.horizon += (r.fate == 0);
+            acc.escaped += (r.fate == 1);
+            acc.disk_hits += (uint64_t)r.disk_hits;
+            acc.star_hits += (uint64_t)r.star_hits;
         }
     }
+    j->st = acc;
     return NULL;
 }
 
