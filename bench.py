@@ -24,6 +24,12 @@ def cpu_baseline(cfg, star_bytes, budget_s):
     """Time the C oracle (restatement of the reference CPU path; GHC is unavailable) on a bounded sample."""
     from oracle import c_oracle, scenes
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a container CPU quota (cgroup v2 cpu.max = "<quota> <period>") caps the cores that really run
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
     ix = c_oracle.Index(c_oracle.read_ppm(star_bytes))
     probe = scenes.with_res(cfg, 96, 54)
     _, st = c_oracle.render(probe, ix, threads=threads)

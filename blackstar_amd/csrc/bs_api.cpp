@@ -319,6 +319,27 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
     return BS_OK;
 }
 
+int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr)
+{
+    if (!ctx || !out_ms || blocks <= 0 || iters <= 0) return fail(BS_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 64));
+    hipError_t e = hipSuccess;
+    if (bs::launch_ubench(kind, blocks, 16, d, ctx->stream)) e = hipErrorLaunchFailure;  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
+    if (e == hipSuccess && bs::launch_ubench(kind, blocks, iters, d, ctx->stream)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_debug_ubench: ") + hipGetErrorString(e));
+    *out_ms = ms;
+    if (out_ginstr) *out_ginstr = (double)blocks * 256.0 * iters * 32.0 / 1e9;  // lane-instructions, in 1e9
+    return BS_OK;
+}
+
 int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare)
 {
     if (!ctx || (n && (!a || !b || !out_sqrt || !out_div))) return fail(BS_EINVAL, "null argument");

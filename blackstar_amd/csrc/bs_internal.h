@@ -36,6 +36,7 @@ struct TraceParams {
     double fov, W, H;            // traced resolution as doubles (cfg' of Raytracer.hs:63)
     double h, hh, h6;            // stepSize, h/2, h/6
     double hh2, hhh, h2_6;       // FAST mode regrouping: h^2/4, h^2/2, h^2/6
+    double e1[3], rcam;          // FAST mode orbital-plane frame: cam/|cam| and |cam|
     double safe, in2, out2;      // safeDistance, diskInner^2, diskOuter^2 (Raytracer.hs:59-62)
     double rI, rO;               // sqrt in2, sqrt out2 (Raytracer.hs:107-108)
     double disk_rgb[3];          // toPixelRGB diskColor (:65)
@@ -66,6 +67,7 @@ void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nod
 int launch_trace(const TraceParams &p, int mode, void *stream);
 int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, size_t n_rays, bs_ray_record *d_out, void *stream);
 int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, double *d_rgb, int32_t *d_hits, void *stream);
+int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
 int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);
 
 }  // namespace bs

@@ -90,6 +90,8 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
     p.hh2 = p.hh * p.hh;              // FAST mode only (see trace_kernel.hip rk4<true>)
     p.hhh = c.step_size * p.hh;
     p.h2_6 = c.step_size * p.h6;
+    p.rcam = std::sqrt(quadrance(c.cam_pos));
+    for (int i = 0; i < 3; i++) p.e1[i] = p.rcam > 0 ? c.cam_pos[i] / p.rcam : (i == 0 ? 1.0 : 0.0);
     double a = 50.0 * 50.0, b = 2 * quadrance(c.cam_pos);  // :59-60, max x y = if x <= y then y else x
     p.safe = (a <= b) ? b : a;
     p.in2 = c.disk_inner * c.disk_inner;   // :61

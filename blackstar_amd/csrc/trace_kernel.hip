@@ -22,6 +22,9 @@ namespace bs {
 namespace {
 
 constexpr int kBlock = 256;  // 4 wavefronts; each wavefront owns one 8x8 tile of traced pixels
+#ifndef BS_MIN_WAVES
+#define BS_MIN_WAVES 1  // __launch_bounds__ minimum waves per SIMD (tuning knob; see DESIGN.md "Occupancy")
+#endif
 
 __device__ __forceinline__ double quadrance(double x, double y, double z) { return (x * x + y * y) + z * z; }
 
@@ -81,70 +84,70 @@ __device__ __forceinline__ double coef_fast(double nh2c, double q)
     return (nh2c * y1) * y4;
 }
 
-__device__ __forceinline__ double quadrance_fma(double x, double y, double z) { return __builtin_fma(z, z, __builtin_fma(y, y, x * x)); }
-
-// One classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134).
+// STRICT: one classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134), the
+// reference's operation order, one IEEE operation each (this TU is compiled -ffp-contract=off).
 // r2 = quadrance pos on entry (carried from the previous step's findColor), r2n = quadrance newPos on exit.
-template <bool FAST>
-__device__ __forceinline__ void rk4(const TraceParams &P, double h2c, double r2, const double v[3], const double p[3], double nv[3],
-                                    double np[3], double &r2n)
+__device__ __forceinline__ void rk4_strict(const TraceParams &P, double h2c, double r2, const double v[3], const double p[3], double nv[3],
+                                           double np[3], double &r2n)
 {
-    if constexpr (!FAST) {
-        // the reference's operation order, one IEEE operation each (this TU is compiled -ffp-contract=off)
-        const double h = P.h, hh = P.hh, h6 = P.h6;
-        double a1[3], a2[3], a3[3], a4[3], v2[3], v3[3], v4[3], q[3];
-        double c = coef_strict(h2c, r2);
+    const double h = P.h, hh = P.hh, h6 = P.h6;
+    double a1[3], a2[3], a3[3], a4[3], v2[3], v3[3], v4[3], q[3];
+    double c = coef_strict(h2c, r2);
 #pragma unroll
-        for (int i = 0; i < 3; i++) a1[i] = -(c * p[i]);
+    for (int i = 0; i < 3; i++) a1[i] = -(c * p[i]);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { v2[i] = v[i] + a1[i] * hh; q[i] = p[i] + v[i] * hh; }
-        c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
+    for (int i = 0; i < 3; i++) { v2[i] = v[i] + a1[i] * hh; q[i] = p[i] + v[i] * hh; }
+    c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
-        for (int i = 0; i < 3; i++) a2[i] = -(c * q[i]);
+    for (int i = 0; i < 3; i++) a2[i] = -(c * q[i]);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { v3[i] = v[i] + a2[i] * hh; q[i] = p[i] + v2[i] * hh; }
-        c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
+    for (int i = 0; i < 3; i++) { v3[i] = v[i] + a2[i] * hh; q[i] = p[i] + v2[i] * hh; }
+    c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
-        for (int i = 0; i < 3; i++) a3[i] = -(c * q[i]);
+    for (int i = 0; i < 3; i++) a3[i] = -(c * q[i]);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { v4[i] = v[i] + a3[i] * h; q[i] = p[i] + v3[i] * h; }
-        c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
+    for (int i = 0; i < 3; i++) { v4[i] = v[i] + a3[i] * h; q[i] = p[i] + v3[i] * h; }
+    c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
-        for (int i = 0; i < 3; i++) a4[i] = -(c * q[i]);
+    for (int i = 0; i < 3; i++) a4[i] = -(c * q[i]);
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            double sv = ((a1[i] + a2[i] * 2) + a3[i] * 2) + a4[i];  // sumK = ((k1 + 2 k2) + 2 k3) + k4
-            double sp = ((v[i] + v2[i] * 2) + v3[i] * 2) + v4[i];
-            nv[i] = v[i] + sv * h6;
-            np[i] = p[i] + sp * h6;
-        }
-        r2n = quadrance(np[0], np[1], np[2]);
-    } else {
-        // Same RK4, regrouped for x'' = a(x) (the RHS does not depend on vel), every multiply-add fused:
-        //   p2 = p + (h/2) v          p3 = p2 + (h^2/4) a1        p4 = (p + h v) + (h^2/2) a2
-        //   np = (p + h v) + (h^2/6)(a1 + a2 + a3)                nv = v + (h/6)(a1 + 2(a2 + a3) + a4)
-        // (algebraically identical to the reference's stage formulas; rounding differs at the 1e-16 level)
-        const double nh2c = -h2c;
-        double a1[3], a2[3], a3[3], a4[3], q0[3], q[3];
-        double c = coef_fast(nh2c, r2);
-#pragma unroll
-        for (int i = 0; i < 3; i++) { a1[i] = c * p[i]; q[i] = __builtin_fma(P.hh, v[i], p[i]); }
-        c = coef_fast(nh2c, quadrance_fma(q[0], q[1], q[2]));
-#pragma unroll
-        for (int i = 0; i < 3; i++) { a2[i] = c * q[i]; q[i] = __builtin_fma(P.hh2, a1[i], q[i]); }
-        c = coef_fast(nh2c, quadrance_fma(q[0], q[1], q[2]));
-#pragma unroll
-        for (int i = 0; i < 3; i++) { a3[i] = c * q[i]; q0[i] = __builtin_fma(P.h, v[i], p[i]); q[i] = __builtin_fma(P.hhh, a2[i], q0[i]); }
-        c = coef_fast(nh2c, quadrance_fma(q[0], q[1], q[2]));
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            a4[i] = c * q[i];
-            double s23 = a2[i] + a3[i];
-            np[i] = __builtin_fma(P.h2_6, a1[i] + s23, q0[i]);
-            nv[i] = __builtin_fma(P.h6, __builtin_fma(2.0, s23, a1[i]) + a4[i], v[i]);
-        }
-        r2n = quadrance_fma(np[0], np[1], np[2]);
+    for (int i = 0; i < 3; i++) {
+        double sv = ((a1[i] + a2[i] * 2) + a3[i] * 2) + a4[i];  // sumK = ((k1 + 2 k2) + 2 k3) + k4
+        double sp = ((v[i] + v2[i] * 2) + v3[i] * 2) + v4[i];
+        nv[i] = v[i] + sv * h6;
+        np[i] = p[i] + sp * h6;
     }
+    r2n = quadrance(np[0], np[1], np[2]);
+}
+
+// FAST: the same RK4 map evaluated in the ray's orbital plane.  f(pos) = c(|pos|) pos is rotation-covariant,
+// so every RK4 stage stays in span{pos, vel}: with an orthonormal basis (e1, e2) of that plane the 6-vector
+// map reduces EXACTLY (in real arithmetic) to a 4-vector one -- 2/3 of the vector work.  The stages are also
+// regrouped for x'' = a(x) (the RHS does not depend on vel) and every multiply-add is fused:
+//   p2 = p + (h/2) v          p3 = p2 + (h^2/4) a1        p4 = (p + h v) + (h^2/2) a2
+//   np = (p + h v) + (h^2/6)(a1 + a2 + a3)                nv = v + (h/6)(a1 + 2(a2 + a3) + a4)
+// Rounding differs from the reference's order at the 1e-16 level per operation (tests: <= 1e-10 on the
+// terminal direction, 1e-4 relative on every pixel of the BASELINE frames).
+__device__ __forceinline__ void rk4_planar(const TraceParams &P, double nh2c, double r2, double &x, double &y, double &vx, double &vy, double &r2n)
+{
+    double c = coef_fast(nh2c, r2);
+    double a1x = c * x, a1y = c * y;
+    double qx = __builtin_fma(P.hh, vx, x), qy = __builtin_fma(P.hh, vy, y);
+    c = coef_fast(nh2c, __builtin_fma(qy, qy, qx * qx));
+    double a2x = c * qx, a2y = c * qy;
+    qx = __builtin_fma(P.hh2, a1x, qx); qy = __builtin_fma(P.hh2, a1y, qy);
+    c = coef_fast(nh2c, __builtin_fma(qy, qy, qx * qx));
+    double a3x = c * qx, a3y = c * qy;
+    double q0x = __builtin_fma(P.h, vx, x), q0y = __builtin_fma(P.h, vy, y);
+    qx = __builtin_fma(P.hhh, a2x, q0x); qy = __builtin_fma(P.hhh, a2y, q0y);
+    c = coef_fast(nh2c, __builtin_fma(qy, qy, qx * qx));
+    double a4x = c * qx, a4y = c * qy;
+    double sx = a2x + a3x, sy = a2y + a3y;
+    x = __builtin_fma(P.h2_6, a1x + sx, q0x);
+    y = __builtin_fma(P.h2_6, a1y + sy, q0y);
+    vx = __builtin_fma(P.h6, __builtin_fma(2.0, sx, a1x) + a4x, vx);
+    vy = __builtin_fma(P.h6, __builtin_fma(2.0, sy, a1y) + a4y, vy);
+    r2n = __builtin_fma(y, y, x * x);
 }
 
 // massiv-io Graphics.ColorSpace toPixelRGB (PixelHSI h' s i), h' in [0,1)  (recalled)
@@ -244,49 +247,35 @@ __device__ __forceinline__ void shade_disk(const TraceParams &P, double r2ave, d
     rgba[3] = rgba[3] + (inten * P.disk_opacity) * om;
 }
 
-// traceRay + colorize for traced pixel (yi, xi).
-template <bool FAST>
-__device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, int yi, int xi, RayResult &res)
+// generateRay (Raytracer.hs:40-51); look-at basis hoisted to the host (identical arithmetic, once per frame).
+__device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int xi, double v[3])
 {
-    // generateRay (Raytracer.hs:40-51); basis hoisted to the host (identical arithmetic, once per frame).
     double v0 = P.fov * ((double)xi / P.W - 0.5);
     double v1 = P.fov * (0.5 - (double)yi / P.H) * P.H / P.W;
-    double d[3], v[3], p[3];
+    double d[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = (P.xa[i] * v0 + P.ya[i] * v1) + P.za[i];  // (-za_i) * (-1) == za_i exactly
     double l = quadrance(d[0], d[1], d[2]);
-    if (fabs(l) <= 1e-12 || fabs(1.0 - l) <= 1e-12) {
+    if (fabs(l) <= 1e-12 || fabs(1.0 - l) <= 1e-12) {  // linear.normalize shortcut
         v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
     } else {
         double s = __builtin_sqrt(l);
         v[0] = d[0] / s; v[1] = d[1] / s; v[2] = d[2] / s;
     }
-    p[0] = P.cam[0]; p[1] = P.cam[1]; p[2] = P.cam[2];
-    // h2 = quadrance (pos `cross` vel)   (:73)
-    double cx = p[1] * v[2] - p[2] * v[1], cy = p[2] * v[0] - p[0] * v[2], cz = p[0] * v[1] - p[1] * v[0];
-    double h2 = quadrance(cx, cy, cz);
-    double h2c = 1.5 * h2;
+}
 
-    double rgba[4] = {0, 0, 0, 0};
-    int steps = 0, fate = 2, disk_hits = 0, star_hits = 0;
-    // Disk crossings are rare (~0.2 per ray) but their shading (sqrt, divide, sin) is ~150 instructions that
-    // the whole wavefront would sit through each time any lane crosses.  Crossings are therefore only
-    // RECORDED in the loop (r2ave, in order) and shaded after it, when all 64 lanes do it together.  The
-    // arithmetic and the front-to-back order are unchanged; a third pending crossing flushes in place.
+// Disk crossings are rare (~0.2 per ray) but their shading (sqrt, divide, sin) is ~150 instructions that the
+// whole wavefront would sit through each time any lane crosses.  Crossings are therefore only RECORDED in
+// the loop (r2ave, in order) and shaded after it, when all 64 lanes do it together.  The arithmetic and
+// the front-to-back order are unchanged; a third pending crossing flushes the oldest in place.
+struct DiskQueue {
     double pend0 = 0, pend1 = 0;
-    int npend = 0;
-    double r2 = quadrance(p[0], p[1], p[2]);
-    const bool disk = P.disk_opacity != 0;
-    while (steps < P.max_steps) {
-        steps++;
-        // findColor guards on the PRE-step position (:93-95); rk4's result is not needed when they fire.
-        if (r2 < 1.0) { fate = 0; break; }
-        if (r2 > P.safe) { fate = 1; break; }
-        double nv[3], np[3], r2n;
-        rk4<FAST>(P, h2c, r2, v, p, nv, np, r2n);
-        double y = p[1], yn = np[1];
-        // signum y' /= signum y (:96) can only hold if y*y' is not > 0 (opposite signs, a zero, or NaN)
-        if (disk && !(y * yn > 0.0)) {
+    int npend = 0, hits = 0;
+    // findColor's disk guard (:96-98) for the step (y, r2) -> (yn, r2n)
+    __device__ __forceinline__ void test(const TraceParams &P, double y, double yn, double r2, double r2n, double rgba[4])
+    {
+        // signum y' /= signum y can only hold if y*y' is not > 0 (opposite signs, a zero, or NaN)
+        if (!(y * yn > 0.0)) {
             if (signum(yn) != signum(y)) {
                 double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
                 if (r2ave > P.in2 && r2ave < P.out2) {           // :97
@@ -297,32 +286,104 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *
                     }
                     if (npend == 0) pend0 = r2ave; else pend1 = r2ave;
                     npend++;
-                    disk_hits++;
+                    hits++;
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
-        r2 = r2n;
     }
-    if (npend > 0) shade_disk(P, pend0, rgba);
-    if (npend > 1) shade_disk(P, pend1, rgba);
+    __device__ __forceinline__ void flush(const TraceParams &P, double rgba[4])
+    {
+        if (npend > 0) shade_disk(P, pend0, rgba);
+        if (npend > 1) shade_disk(P, pend1, rgba);
+    }
+};
+
+// The terminal `Bottom` layer of colorize (:84, :93-95) under whatever the disk left transparent.
+__device__ __forceinline__ int finish_ray(const TraceParams &P, const StarNode *lds_nodes, int fate, const double v[3], double rgba[4])
+{
+    int star_hits = 0;
     if (fate == 0) {  // Bottom (PixelRGBA 0 0 0 1)
         double om = 1 - rgba[3];
         rgba[0] = rgba[0] + 0.0 * om; rgba[1] = rgba[1] + 0.0 * om; rgba[2] = rgba[2] + 0.0 * om;
         rgba[3] = rgba[3] + 1.0 * om;
-    } else if (fate == 1) {  // Bottom . addAlpha 1 $ starLookup ... vel   (OLD vel, :94-95)
+    } else if (fate == 1) {  // Bottom . addAlpha 1 $ starLookup ... vel   (the PRE-step vel, :94-95)
         double sr, sg, sb;
         star_hits = star_lookup(P, lds_nodes, v[0], v[1], v[2], sr, sg, sb);
         double om = 1 - rgba[3];
         rgba[0] = rgba[0] + sr * om; rgba[1] = rgba[1] + sg * om; rgba[2] = rgba[2] + sb * om;
         rgba[3] = rgba[3] + 1.0 * om;
     }
+    return star_hits;
+}
+
+// traceRay + colorize for traced pixel (yi, xi).
+template <bool FAST>
+__device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, int yi, int xi, RayResult &res)
+{
+    double v[3], p[3];
+    generate_ray(P, yi, xi, v);
+    p[0] = P.cam[0]; p[1] = P.cam[1]; p[2] = P.cam[2];
+    double rgba[4] = {0, 0, 0, 0};
+    int steps = 0, fate = 2;
+    DiskQueue dq;
+    const bool disk = P.disk_opacity != 0;
+
+    if constexpr (!FAST) {
+        // h2 = quadrance (pos `cross` vel)   (:73)
+        double cx = p[1] * v[2] - p[2] * v[1], cy = p[2] * v[0] - p[0] * v[2], cz = p[0] * v[1] - p[1] * v[0];
+        double h2c = 1.5 * quadrance(cx, cy, cz);
+        double r2 = quadrance(p[0], p[1], p[2]);
+        while (steps < P.max_steps) {
+            steps++;
+            // findColor guards on the PRE-step position (:93-95); rk4's result is not needed when they fire.
+            if (r2 < 1.0) { fate = 0; break; }
+            if (r2 > P.safe) { fate = 1; break; }
+            double nv[3], np[3], r2n;
+            rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
+            if (disk) dq.test(P, p[1], np[1], r2, r2n, rgba);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
+            r2 = r2n;
+        }
+    } else {
+        // Orbital-plane frame: e1 = pos/|pos| (the camera direction, wave-uniform, from the host),
+        // e2 = the unit vector along the part of vel orthogonal to e1 (per lane).
+        double vr = __builtin_fma(v[2], P.e1[2], __builtin_fma(v[1], P.e1[1], v[0] * P.e1[0]));
+        double w[3] = {__builtin_fma(-vr, P.e1[0], v[0]), __builtin_fma(-vr, P.e1[1], v[1]), __builtin_fma(-vr, P.e1[2], v[2])};
+        double vt2 = quadrance(w[0], w[1], w[2]);
+        double vt = __builtin_sqrt(vt2);
+        double ivt = vt > 0 ? 1.0 / vt : 0.0;  // purely radial ray: e2 is irrelevant (y stays 0)
+        double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
+        double x = P.rcam, y = 0.0, vx = vr, vy = vt;
+        double L = x * vy;  // |pos x vel| in the plane
+        double nh2c = -1.5 * (L * L);
+        double r2 = x * x;
+        double Y = p[1];  // the 3-D y coordinate (disk plane normal), Y = x e1.y + y e2.y
+        while (steps < P.max_steps) {
+            steps++;
+            if (r2 < 1.0) { fate = 0; break; }
+            if (r2 > P.safe) { fate = 1; break; }
+            double r2n;
+            rk4_planar(P, nh2c, r2, x, y, vx, vy, r2n);
+            double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
+            if (disk) dq.test(P, Y, Yn, r2, r2n, rgba);
+            r2 = r2n;
+            Y = Yn;
+        }
+        // NOTE: on a guard exit the planar state is still the PRE-step one (the guards fire before rk4_planar).
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            v[i] = __builtin_fma(vx, P.e1[i], vy * e2[i]);
+            p[i] = __builtin_fma(x, P.e1[i], y * e2[i]);
+        }
+    }
+    dq.flush(P, rgba);
+    int star_hits = finish_ray(P, lds_nodes, fate, v, rgba);
 #pragma unroll
     for (int i = 0; i < 3; i++) { res.vel[i] = v[i]; res.pos[i] = p[i]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) res.rgba[i] = rgba[i];
-    res.steps = steps; res.fate = fate; res.disk_hits = disk_hits; res.star_hits = star_hits;
+    res.steps = steps; res.fate = fate; res.disk_hits = dq.hits; res.star_hits = star_hits;
 }
 
 __device__ __forceinline__ void stage_tree(const TraceParams &P, StarNode *s_nodes)
@@ -343,7 +404,7 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 // p(2y,2x), p(2y+1,2x), p(2y,2x+1), p(2y+1,2x+1) of ImageFilters.hs:94-96, and are reduced with lane
 // shuffles so only the h x w image is ever written.
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void trace_frame_kernel(const TraceParams P)
+__global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const TraceParams P)
 {
     __shared__ StarNode s_nodes[kLdsNodes];
     stage_tree(P, s_nodes);
@@ -440,7 +501,10 @@ __global__ void sqrt_div_kernel(const double *a, const double *b, size_t n, doub
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    if (bare) {  // the scaling-free sequences the STRICT RK4 RHS uses
+    if (bare == 2) {  // raw hardware seeds (precision probe for FAST mode's Newton step)
+        s[k] = __builtin_amdgcn_rsq(a[k]);
+        d[k] = __builtin_amdgcn_rcp(b[k]);
+    } else if (bare) {  // the scaling-free sequences the STRICT RK4 RHS uses
         s[k] = sqrt_rn(a[k]);
         d[k] = div_rn(a[k], b[k]);
     } else {     // hipcc's own lowering of sqrt and '/'
@@ -449,7 +513,49 @@ __global__ void sqrt_div_kernel(const double *a, const double *b, size_t n, doub
     }
 }
 
+// Roofline probe: 8 independent dependency chains per lane of one FP64 VALU instruction kind.
+// kind 0: v_fma_f64   1: v_mul_f64   2: v_add_f64   3: v_rsq_f64   4: v_rcp_f64
+template <int KIND>
+__global__ __launch_bounds__(256) void ubench_kernel(double *out, int iters, double a, double b)
+{
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = 1.0 + 1e-3 * (threadIdx.x + i);
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if constexpr (KIND == 0) x[i] = __builtin_fma(x[i], a, b);
+                if constexpr (KIND == 1) x[i] = x[i] * a;
+                if constexpr (KIND == 2) x[i] = x[i] + b;
+                if constexpr (KIND == 3) x[i] = __builtin_amdgcn_rsq(x[i]);
+                if constexpr (KIND == 4) x[i] = __builtin_amdgcn_rcp(x[i]);
+            }
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += x[i];
+    if (s == 12345.678) out[0] = s;  // keep the chains live without a store on the common path
+}
+
 }  // namespace
+
+int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((unsigned)blocks), b(256);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(ubench_kernel<0>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 1: hipLaunchKernelGGL(ubench_kernel<1>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 2: hipLaunchKernelGGL(ubench_kernel<2>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 3: hipLaunchKernelGGL(ubench_kernel<3>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 4: hipLaunchKernelGGL(ubench_kernel<4>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int launch_trace(const TraceParams &p, int mode, void *stream)
 {

@@ -121,6 +121,11 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
  * lowering of sqrt and '/'; bare = 1: the scaling-free FMA sequences used inside the RK4 right-hand side. */
 int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare);
 
+/* Roofline probe: times `iters` x 32 dependent-chain FP64 VALU instructions per lane (8 independent chains)
+ * on `blocks` x 256 lanes.  kind 0 v_fma_f64, 1 v_mul_f64, 2 v_add_f64, 3 v_rsq_f64, 4 v_rcp_f64.
+ * out_ginstr = lane-instructions executed / 1e9 (so rate = out_ginstr / out_ms * 1e3 Ginstr/s). */
+int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr);
+
 int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_STRICT */
 int bs_get_mode(const bs_ctx *ctx);
 int bs_set_max_steps(bs_ctx *ctx, int max_steps); /* safety cap; the reference has none (src/Raytracer.hs:80-86). default 100000 */

@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""FP64 VALU roofline probe on the box: measured issue rates of v_fma/mul/add/rsq/rcp_f64 (SURVEY 8d asks for
+a v_fma_f64 microbenchmark because the local guide lists only the FP32 vector peak)."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blackstar_amd as bs  # noqa: E402
+from blackstar_amd import _lib  # noqa: E402
+
+t = bs.StarTree(None)
+L = _lib.lib()
+res = {}
+for kind, name in enumerate(("v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64", "v_rcp_f64")):
+    ms, gi = C.c_double(), C.c_double()
+    best = 0.0
+    for _ in range(3):
+        _lib.check(L.bs_debug_ubench(t.handle, kind, 256 * 8, 20000 if kind < 3 else 5000, C.byref(ms), C.byref(gi)), "ubench")
+        best = max(best, gi.value / ms.value * 1e3)
+    res[name] = {"Ginstr_per_s": best, "TFLOPs_if_fma": best * 2 / 1e3, "cycles_per_wave_instr_at_2.4GHz": 256 * 4 * 64 * 2.4 / best}
+print(json.dumps(res, indent=1))

@@ -55,6 +55,18 @@ def test_device_sqrt_and_divide_are_correctly_rounded(tree_empty):
         assert np.array_equal(d, a / b), f"divide not correctly rounded (bare={bare})"
 
 
+def test_hardware_rsq_seed_precision(tree_empty):
+    """FAST mode refines v_rsq_f64 with one cubic Newton step (error ~ e^3): the seed must be good to ~2^-20."""
+    rng = np.random.default_rng(12)
+    n = 1 << 18
+    a = np.exp(rng.uniform(np.log(1e-4), np.log(1e5), n))
+    s = np.zeros(n); d = np.zeros(n)
+    _lib.check(_lib.lib().bs_debug_sqrt_div(tree_empty.handle, a.ctypes.data, a.ctypes.data, n, s.ctypes.data, d.ctypes.data, 2), "rsq")
+    rel = np.abs(s * np.sqrt(a) - 1.0).max()
+    print(f"v_rsq_f64 max rel err {rel:.3e} (2^{np.log2(rel):.1f}); v_rcp_f64 {np.abs(d * a - 1).max():.3e}")
+    assert rel < 2.0 ** -20
+
+
 @pytest.mark.parametrize("name", TRACE_GOLDENS)
 def test_strict_trajectories_bit_exact_vs_golden_and_oracle(name, tree, oracle, oracle_index):
     g = load_golden("trace_" + name)
