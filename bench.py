@@ -130,6 +130,7 @@ def main():
                        "mode": args.mode, "frames_per_step_per_gpu": 1, "parallelism": f"frame-sharded x{world}",
                        "image": "RGB f64 resident in HBM (no D2H in the timed region)"},
             "rays_per_s": frames * st["rays"] / dt, "steps_per_ray": st["steps"] / st["rays"],
+            "lane_efficiency": st["steps"] / (64.0 * st["wave_iters"]),
             "kernel_ms": kernel_ms, "kernel_ms_last_hipevent": st["kernel_ms"],
             "roofline": {"bound": "valu", "detail": "FP64 VALU issue (scalar ODE per lane; HBM and MFMA are not the bound)",
                          "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS,

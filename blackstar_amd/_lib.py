@@ -26,7 +26,7 @@ class BsConfig(C.Structure):
 
 class BsStats(C.Structure):
     """struct bs_stats_t."""
-    _fields_ = [(k, C.c_uint64) for k in ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")] + \
+    _fields_ = [(k, C.c_uint64) for k in ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits", "wave_iters")] + \
                [("kernel_ms", C.c_double), ("wall_ms", C.c_double)]
 
 

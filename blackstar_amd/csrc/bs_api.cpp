@@ -36,7 +36,7 @@ int fail(int code, const std::string &msg)
 
 struct bs_ctx {
     int device = -1;
-    int mode = BS_MODE_STRICT;
+    int mode = BS_MODE_FAST;
     int max_steps = 100000;
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;
@@ -104,6 +104,7 @@ int resolve_stats(bs_ctx *ctx)
     st.escaped = ctx->h_counters[3];
     st.disk_hits = ctx->h_counters[4];
     st.star_hits = ctx->h_counters[5];
+    st.wave_iters = ctx->h_counters[6];
     st.kernel_ms = ms;
     st.wall_ms = ctx->last_wall_ms;
     ctx->pending = false;

@@ -456,7 +456,11 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     unsigned s_esc = wave_sum(res.fate == 1 ? 1u : 0u);
     unsigned s_disk = wave_sum((unsigned)res.disk_hits);
     unsigned s_star = wave_sum((unsigned)res.star_hits);
+    unsigned w_iters = (unsigned)res.steps;  // iterations this wavefront ran = its slowest lane
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) w_iters = max(w_iters, (unsigned)__shfl_xor(w_iters, o, 64));
     if (lane == 0) {
+        atomicAdd(&P.counters[6], (unsigned long long)w_iters);
         atomicAdd(&P.counters[0], (unsigned long long)s_steps);
         if (s_cap) atomicAdd(&P.counters[1], (unsigned long long)s_cap);
         if (s_hor) atomicAdd(&P.counters[2], (unsigned long long)s_hor);

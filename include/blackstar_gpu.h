@@ -72,6 +72,7 @@ typedef struct bs_stats_t {
     uint64_t escaped;   /* rays ended by r^2 > safeDistance (:94) */
     uint64_t disk_hits; /* Layer blends (:96-98) */
     uint64_t star_hits; /* stars summed by starLookup (src/StarMap.hs:104) */
+    uint64_t wave_iters; /* sum over wavefronts of the iterations of their slowest lane: lane efficiency = steps / (64 * wave_iters) */
     double kernel_ms;   /* hipEvent time of the kernels of the last render */
     double wall_ms;     /* host wall time of the last bs_render call (H2D params + kernels + D2H image) */
 } bs_stats_t;
@@ -126,7 +127,7 @@ int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, d
  * out_ginstr = lane-instructions executed / 1e9 (so rate = out_ginstr / out_ms * 1e3 Ginstr/s). */
 int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr);
 
-int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_STRICT */
+int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST (env BLACKSTAR_MODE=strict|fast overrides at bs_create) */
 int bs_get_mode(const bs_ctx *ctx);
 int bs_set_max_steps(bs_ctx *ctx, int max_steps); /* safety cap; the reference has none (src/Raytracer.hs:80-86). default 100000 */
 int bs_stats(bs_ctx *ctx, bs_stats_t *out);       /* synchronises the context's last render first */

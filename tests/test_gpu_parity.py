@@ -25,6 +25,7 @@ RTOL_FAST, ATOL_FAST = 1e-4, 1e-7  # BASELINE.json north_star / SURVEY 8d "Parit
 @pytest.fixture(scope="module")
 def tree(catalogue_bytes):
     t = bs.StarTree(bs.read_map(catalogue_bytes), device=0)
+    t.set_mode(_lib.BS_MODE_STRICT)
     yield t
     t.close()
 
@@ -32,6 +33,7 @@ def tree(catalogue_bytes):
 @pytest.fixture(scope="module")
 def tree_empty():
     t = bs.StarTree(None, device=0)
+    t.set_mode(_lib.BS_MODE_STRICT)
     yield t
     t.close()
 
@@ -237,11 +239,17 @@ def test_c2_full_size_vs_oracle(tree_empty, oracle, oracle_index_empty):
     assert bad.sum() == 0
 
 
+def L_mode(tree):
+    return _lib.lib().bs_get_mode(tree.handle)
+
+
 def test_c3_c4_full_size_properties(oracle):
     """BASELINE configs[2], [3] at full size through size-independent properties: sampled rays bit-exact vs the
     oracle, FAST vs STRICT within the north_star tolerance on every pixel, equal step checksums."""
     stars = bs.read_map(synthetic.ppm_catalogue_bytes())
     t = bs.StarTree(stars)
+    assert L_mode(t) == _lib.BS_MODE_FAST  # the shipped default
+    t.set_mode(_lib.BS_MODE_STRICT)
     ix = oracle.Index(oracle.read_ppm(synthetic.ppm_catalogue_bytes()))
     rng = np.random.default_rng(2026)
     for cfg in (scenes.DEFAULT_AA, scenes.with_res(scenes.LENSING_DISK, 3840, 2160)):
@@ -259,6 +267,7 @@ def test_c3_c4_full_size_properties(oracle):
         st_f = t.stats()
         t.set_mode(_lib.BS_MODE_STRICT)
         assert st_s["rays"] == wt * ht and st_s["capped"] == 0
+        assert 0.9 < st_s["steps"] / (64.0 * st_s["wave_iters"]) <= 1.0  # lane efficiency of the 8x8 tiling
         assert (st_s["horizon"], st_s["escaped"]) == (st_f["horizon"], st_f["escaped"])
         assert abs(int(st_s["steps"]) - int(st_f["steps"])) <= 8
         bad = np.abs(fast - strict) > ATOL_FAST + RTOL_FAST * np.abs(strict)

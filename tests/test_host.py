@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.BsConfig) == 19 * 8 + 4 * 4
     assert _lib.STAR_DTYPE.itemsize == 48 and _lib.RECORD_DTYPE.itemsize == 96
-    assert ctypes.sizeof(_lib.BsStats) == 9 * 8
+    assert ctypes.sizeof(_lib.BsStats) == 10 * 8
 
 
 def test_no_cpu_backend():
