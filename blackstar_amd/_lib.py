@@ -38,7 +38,7 @@ RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4
 # every symbol include/blackstar_gpu.h declares
 SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
            "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
-           "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench")
+           "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots")
 
 _lib = None
 
@@ -90,6 +90,8 @@ def lib() -> C.CDLL:
     L.bs_render_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.bs_trace_rays.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
     L.bs_debug_sqrt_div.argtypes = [vp, vp, vp, sz, vp, vp, C.c_int]
+    if hasattr(L, "bs_debug_set_disk_slots"):  # absent in older A/B builds loaded through BLACKSTAR_LIB
+        L.bs_debug_set_disk_slots.argtypes = [vp, C.c_int]
     L.bs_debug_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.bs_star_lookup.argtypes = [vp, dp, dp, vp, sz, vp, vp]
     L.bs_set_mode.argtypes = [vp, C.c_int]

@@ -38,6 +38,7 @@ struct bs_ctx {
     int device = -1;
     int mode = BS_MODE_FAST;
     int max_steps = 100000;
+    int disk_slots = 4;
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;
     bs::StarColor *d_colors = nullptr;
@@ -61,6 +62,7 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
     std::memset(&p, 0, sizeof p);
     if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
     p.max_steps = ctx->max_steps;
+    p.disk_slots = ctx->disk_slots;
     p.n_stars = (int32_t)ctx->n_stars;
     p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
     p.nodes = ctx->d_nodes;
@@ -200,6 +202,13 @@ int bs_set_max_steps(bs_ctx *ctx, int max_steps)
 {
     if (!ctx || max_steps <= 0) return fail(BS_EINVAL, "bad max_steps");
     ctx->max_steps = max_steps;
+    return BS_OK;
+}
+
+int bs_debug_set_disk_slots(bs_ctx *ctx, int slots)
+{
+    if (!ctx || slots < 0 || slots > 4) return fail(BS_EINVAL, "bad slots");
+    ctx->disk_slots = slots;
     return BS_OK;
 }
 

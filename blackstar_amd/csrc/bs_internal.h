@@ -25,8 +25,8 @@ struct alignas(16) StarColor {
     double hue, sat;  // starColor' (StarMap.hs:61-72), indexed like StarNode
 };
 
-constexpr int kLdsLevels = 9;                       // top levels of the k-d array staged in LDS
-constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 511 nodes * 32 B = 16352 B per workgroup
+constexpr int kLdsLevels = 8;                       // top levels of the k-d array staged in LDS
+constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 255 nodes * 32 B = 8160 B per workgroup (LDS budget: 4 workgroups/CU with the per-lane scratch)
 constexpr int kCounters = 8;                        // steps, capped, horizon, escaped, disk_hits, star_hits
 
 // Everything the trace kernel needs, passed by value as the kernel argument (lands in SGPRs / kernarg).
@@ -49,6 +49,7 @@ struct TraceParams {
     int32_t max_steps;
     int32_t n_stars;
     int32_t lds_nodes;           // min(n_stars, kLdsNodes)
+    int32_t disk_slots;          // LDS crossing-queue depth in use (<= 4; tests shrink it to force the overflow path)
     const StarNode *nodes;       // device, n_stars + 1 entries (entry 0 unused)
     const StarColor *colors;     // device, n_stars + 1 entries
     double *out;                 // device, out_h * out_w * 3

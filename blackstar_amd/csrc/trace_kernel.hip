@@ -28,6 +28,10 @@ constexpr int kBlock = 256;  // 4 wavefronts; each wavefront owns one 8x8 tile o
 
 __device__ __forceinline__ double quadrance(double x, double y, double z) { return (x * x + y * y) + z * z; }
 
+// Wave-level predicates straight from the lane mask (HIP's __ballot/__any take an int and cost a
+// v_cndmask + v_cmp round trip per call; these compile to the SGPR mask the compare already produced).
+__device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
 __device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 
@@ -264,39 +268,52 @@ __device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int x
     }
 }
 
+// ---- per-lane LDS scratch --------------------------------------------------------------------------------
+// The stepping loop is ~100% VALU-issue bound.  Any value that is live OUT of it, or conditionally modified
+// inside it, costs register copies EVERY iteration (exit merges become phis in blocks all lanes run; and a
+// partially masked body cannot update state in place because the compiler's liveness is per register, not
+// per lane).  So: nothing leaves the loop through registers.  When a lane's guard fires it writes its
+// terminal state and step count to its LDS column (a rare block placed BEFORE the RK4 body) and is marked
+// inactive; the body itself runs UNMASKED for all 64 lanes -- a finished lane just keeps stepping, its later
+// values are never looked at (f64 VALU has no slow path for the inf/NaN a captured lane can produce) -- and
+// updates the state in place.  The code after the loop reloads everything from LDS.
+// Layout: [word][thread] -- consecutive lanes touch consecutive 8-byte words: conflict-free.
+constexpr int kDiskSlots = 4;
+constexpr int kSnapDoubles = 7;  // STRICT: vel[3], pos[3], r2; FAST: x, y, vx, vy, r2
+constexpr int kLaneLdsDoubles = (kSnapDoubles + kDiskSlots) * kBlock;
+
+struct LaneLds {
+    double *col;  // this lane's column: col[word * kBlock]
+    int *ints;    // this lane's ints: ints[0] crossing count (or kOverflow), ints[kBlock] steps
+    __device__ __forceinline__ LaneLds(double *area, int *iarea) : col(area + threadIdx.x), ints(iarea + threadIdx.x) {}
+    __device__ __forceinline__ double &snap(int k) const { return col[k * kBlock]; }
+    __device__ __forceinline__ double &slot(int k) const { return col[(kSnapDoubles + k) * kBlock]; }
+    __device__ __forceinline__ int &count() const { return ints[0]; }
+    __device__ __forceinline__ int &steps() const { return ints[kBlock]; }
+};
+
 // Disk crossings are rare (~0.2 per ray) but their shading (sqrt, divide, sin) is ~150 instructions that the
 // whole wavefront would sit through each time any lane crosses.  Crossings are therefore only RECORDED in
-// the loop (r2ave, in order) and shaded after it, when all 64 lanes do it together.  The arithmetic and
-// the front-to-back order are unchanged; a third pending crossing flushes the oldest in place.
-struct DiskQueue {
-    double pend0 = 0, pend1 = 0;
-    int npend = 0, hits = 0;
-    // findColor's disk guard (:96-98) for the step (y, r2) -> (yn, r2n)
-    __device__ __forceinline__ void test(const TraceParams &P, double y, double yn, double r2, double r2n, double rgba[4])
-    {
-        // signum y' /= signum y can only hold if y*y' is not > 0 (opposite signs, a zero, or NaN)
-        if (!(y * yn > 0.0)) {
-            if (signum(yn) != signum(y)) {
-                double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
-                if (r2ave > P.in2 && r2ave < P.out2) {           // :97
-                    if (npend == 2) {
-                        shade_disk(P, pend0, rgba);
-                        pend0 = pend1;
-                        npend = 1;
-                    }
-                    if (npend == 0) pend0 = r2ave; else pend1 = r2ave;
-                    npend++;
-                    hits++;
-                }
-            }
+// the stepping loop (r2ave, in order, kDiskSlots per lane) and shaded after it, when all 64 lanes do it
+// together -- same arithmetic, same front-to-back order.  A ray with more crossings than slots (possible
+// only when the disk reaches inside the photon sphere) is flagged and re-traced by trace_ray_simple.
+constexpr int kOverflow = 1 << 20;
+
+// findColor's disk guard (:96-98) for the step (y, r2) -> (yn, r2n).  Callers have already established that
+// y*yn is not > 0 (the only way signum y' /= signum y can hold).  Returns false if the queue overflowed.
+__device__ __forceinline__ bool record_crossing(const TraceParams &P, const LaneLds &lds, double y, double yn, double r2, double r2n)
+{
+    if (signum(yn) != signum(y)) {
+        double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
+        if (r2ave > P.in2 && r2ave < P.out2) {           // :97
+            int n = lds.count();
+            if (n >= P.disk_slots) { lds.count() = kOverflow; return false; }
+            lds.slot(n) = r2ave;
+            lds.count() = n + 1;
         }
     }
-    __device__ __forceinline__ void flush(const TraceParams &P, double rgba[4])
-    {
-        if (npend > 0) shade_disk(P, pend0, rgba);
-        if (npend > 1) shade_disk(P, pend1, rgba);
-    }
-};
+    return true;
+}
 
 // The terminal `Bottom` layer of colorize (:84, :93-95) under whatever the disk left transparent.
 __device__ __forceinline__ int finish_ray(const TraceParams &P, const StarNode *lds_nodes, int fate, const double v[3], double rgba[4])
@@ -316,74 +333,177 @@ __device__ __forceinline__ int finish_ray(const TraceParams &P, const StarNode *
     return star_hits;
 }
 
-// traceRay + colorize for traced pixel (yi, xi).
+// Plain per-lane restatement of traceRay/colorize with the disk shaded inside the loop.  Only used for the
+// (rare) rays whose crossings overflow the LDS queue; same arithmetic as the fast path.
 template <bool FAST>
-__device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, int yi, int xi, RayResult &res)
+__device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, int xi, double *out /* vel[3] pos[3] rgba[4] */, int *iout /* steps fate crossings */)
 {
-    double v[3], p[3];
+    double v[3], p[3], rgba[4] = {0, 0, 0, 0};
     generate_ray(P, yi, xi, v);
     p[0] = P.cam[0]; p[1] = P.cam[1]; p[2] = P.cam[2];
-    double rgba[4] = {0, 0, 0, 0};
-    int steps = 0, fate = 2;
-    DiskQueue dq;
-    const bool disk = P.disk_opacity != 0;
-
+    int steps = 0, fate = 2, ncross = 0;
     if constexpr (!FAST) {
-        // h2 = quadrance (pos `cross` vel)   (:73)
         double cx = p[1] * v[2] - p[2] * v[1], cy = p[2] * v[0] - p[0] * v[2], cz = p[0] * v[1] - p[1] * v[0];
-        double h2c = 1.5 * quadrance(cx, cy, cz);
+        const double h2c = 1.5 * quadrance(cx, cy, cz);
         double r2 = quadrance(p[0], p[1], p[2]);
         while (steps < P.max_steps) {
             steps++;
-            // findColor guards on the PRE-step position (:93-95); rk4's result is not needed when they fire.
             if (r2 < 1.0) { fate = 0; break; }
             if (r2 > P.safe) { fate = 1; break; }
             double nv[3], np[3], r2n;
             rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
-            if (disk) dq.test(P, p[1], np[1], r2, r2n, rgba);
-#pragma unroll
+            double y = p[1], yn = np[1];
+            if (P.disk_opacity != 0 && signum(yn) != signum(y)) {
+                double r2ave = (yn * r2 - y * r2n) / (yn - y);
+                if (r2ave > P.in2 && r2ave < P.out2) { shade_disk(P, r2ave, rgba); ncross++; }
+            }
             for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
             r2 = r2n;
         }
     } else {
-        // Orbital-plane frame: e1 = pos/|pos| (the camera direction, wave-uniform, from the host),
-        // e2 = the unit vector along the part of vel orthogonal to e1 (per lane).
         double vr = __builtin_fma(v[2], P.e1[2], __builtin_fma(v[1], P.e1[1], v[0] * P.e1[0]));
         double w[3] = {__builtin_fma(-vr, P.e1[0], v[0]), __builtin_fma(-vr, P.e1[1], v[1]), __builtin_fma(-vr, P.e1[2], v[2])};
-        double vt2 = quadrance(w[0], w[1], w[2]);
-        double vt = __builtin_sqrt(vt2);
-        double ivt = vt > 0 ? 1.0 / vt : 0.0;  // purely radial ray: e2 is irrelevant (y stays 0)
-        double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
-        double x = P.rcam, y = 0.0, vx = vr, vy = vt;
-        double L = x * vy;  // |pos x vel| in the plane
-        double nh2c = -1.5 * (L * L);
-        double r2 = x * x;
-        double Y = p[1];  // the 3-D y coordinate (disk plane normal), Y = x e1.y + y e2.y
+        double vt = __builtin_sqrt(quadrance(w[0], w[1], w[2]));
+        double ivt = vt > 0 ? 1.0 / vt : 0.0;
+        const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
+        const double L = P.rcam * vt;
+        const double nh2c = -1.5 * (L * L);
+        double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam, Y = p[1];
         while (steps < P.max_steps) {
             steps++;
             if (r2 < 1.0) { fate = 0; break; }
             if (r2 > P.safe) { fate = 1; break; }
             double r2n;
-            rk4_planar(P, nh2c, r2, x, y, vx, vy, r2n);
-            double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
-            if (disk) dq.test(P, Y, Yn, r2, r2n, rgba);
+            const double r2o = r2;
+            rk4_planar(P, nh2c, r2o, x, y, vx, vy, r2n);
+            const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
+            if (P.disk_opacity != 0 && signum(Yn) != signum(Y)) {
+                double r2ave = (Yn * r2o - Y * r2n) / (Yn - Y);
+                if (r2ave > P.in2 && r2ave < P.out2) { shade_disk(P, r2ave, rgba); ncross++; }
+            }
             r2 = r2n;
             Y = Yn;
         }
-        // NOTE: on a guard exit the planar state is still the PRE-step one (the guards fire before rk4_planar).
+        for (int i = 0; i < 3; i++) {
+            v[i] = __builtin_fma(vx, P.e1[i], vy * e2[i]);
+            p[i] = __builtin_fma(x, P.e1[i], y * e2[i]);
+        }
+    }
+    for (int i = 0; i < 3; i++) { out[i] = v[i]; out[3 + i] = p[i]; }
+    for (int i = 0; i < 4; i++) out[6 + i] = rgba[i];
+    iout[0] = steps; iout[1] = fate; iout[2] = ncross;
+}
+
+// traceRay + colorize for traced pixel (yi, xi).  `live` = this lane has a ray (tile lanes outside the image do not).
+//
+// Every lane of a wavefront starts its ray at iteration 0 together, so the iteration counter is a scalar
+// register and a lane's step count (iterations of colorize', :80-86) is simply its value when the lane's
+// guard fires.  See "per-lane LDS scratch" above for why the loop looks the way it does.
+template <bool FAST>
+__device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, const LaneLds &lds, bool live, int yi, int xi,
+                                          RayResult &res, unsigned &wave_iters)
+{
+    double v[3], p[3];
+    generate_ray(P, yi, xi, v);
+    p[0] = P.cam[0]; p[1] = P.cam[1]; p[2] = P.cam[2];
+    const bool disk = P.disk_opacity != 0;
+    lds.count() = 0;
+    lds.steps() = 0;
+    bool active = live;
+    int it = 0;  // iterations of colorize' entered so far (wave-uniform)
+    double r2t;  // r^2 fed to the terminating findColor call (read back from LDS)
+
+    if constexpr (!FAST) {
+        // h2 = quadrance (pos `cross` vel)   (:73)
+        double cx = p[1] * v[2] - p[2] * v[1], cy = p[2] * v[0] - p[0] * v[2], cz = p[0] * v[1] - p[1] * v[0];
+        const double h2c = 1.5 * quadrance(cx, cy, cz);
+        double r2 = quadrance(p[0], p[1], p[2]);
+        // one iteration of colorize'; returns false once no lane of the wavefront is stepping
+        auto step = [&]() -> bool {
+            // findColor guards on the PRE-step position (:93-95); the cap is ours (the reference has none)
+            const bool go = active && it < P.max_steps && !(r2 < 1.0) && !(r2 > P.safe);
+            if (active && !go) {  // guard fired: snapshot the state fed to the terminating findColor call
+#pragma unroll
+                for (int i = 0; i < 3; i++) { lds.snap(i) = v[i]; lds.snap(3 + i) = p[i]; }
+                lds.snap(6) = r2;
+                lds.steps() = it < P.max_steps ? it + 1 : it;
+            }
+            active = go;
+            if (!wave_any(go)) return false;
+            double nv[3], np[3], r2n;
+            rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
+            if (disk && go && !(p[1] * np[1] > 0.0)) active = record_crossing(P, lds, p[1], np[1], r2, r2n);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
+            r2 = r2n;
+            ++it;
+            return true;
+        };
+        // unrolled by two: the state ping-pongs between two register sets instead of being copied back at the latch
+        while (step() && step()) {}
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v[i] = lds.snap(i); p[i] = lds.snap(3 + i); }
+        r2t = lds.snap(6);
+    } else {
+        // Orbital-plane frame: e1 = pos/|pos| (the camera direction, wave-uniform, from the host),
+        // e2 = the unit vector along the part of vel orthogonal to e1 (per lane).
+        double vr = __builtin_fma(v[2], P.e1[2], __builtin_fma(v[1], P.e1[1], v[0] * P.e1[0]));
+        double w[3] = {__builtin_fma(-vr, P.e1[0], v[0]), __builtin_fma(-vr, P.e1[1], v[1]), __builtin_fma(-vr, P.e1[2], v[2])};
+        double vt = __builtin_sqrt(quadrance(w[0], w[1], w[2]));
+        double ivt = vt > 0 ? 1.0 / vt : 0.0;  // purely radial ray: e2 is irrelevant (y stays 0)
+        const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
+        const double L = P.rcam * vt;  // |pos x vel| in the plane
+        const double nh2c = -1.5 * (L * L);
+        double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam;
+        double Y = p[1];  // the 3-D y coordinate (disk plane normal), Y = x e1.y + y e2.y
+        auto step = [&]() -> bool {
+            const bool go = active && it < P.max_steps && !(r2 < 1.0) && !(r2 > P.safe);
+            if (active && !go) {
+                lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = vx; lds.snap(3) = vy; lds.snap(4) = r2;
+                lds.steps() = it < P.max_steps ? it + 1 : it;
+            }
+            active = go;
+            if (!wave_any(go)) return false;
+            double r2n;
+            const double r2o = r2;
+            rk4_planar(P, nh2c, r2o, x, y, vx, vy, r2n);
+            const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
+            if (disk && go && !(Y * Yn > 0.0)) active = record_crossing(P, lds, Y, Yn, r2o, r2n);
+            r2 = r2n;
+            Y = Yn;
+            ++it;
+            return true;
+        };
+        while (step() && step()) {}
+        // the snapshot is the PRE-step planar state of the terminating iteration (guards precede rk4)
+        x = lds.snap(0); y = lds.snap(1); vx = lds.snap(2); vy = lds.snap(3); r2t = lds.snap(4);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             v[i] = __builtin_fma(vx, P.e1[i], vy * e2[i]);
             p[i] = __builtin_fma(x, P.e1[i], y * e2[i]);
         }
     }
-    dq.flush(P, rgba);
+    int steps = lds.steps();
+    int ncross = lds.count();
+    int fate = !live ? -1 : (r2t < 1.0 ? 0 : (r2t > P.safe ? 1 : 2));
+    double rgba[4] = {0, 0, 0, 0};  // colorize' starts from PixelRGBA 0 0 0 0 (:86)
+    if (ncross < kOverflow) {
+        for (int k = 0; k < ncross; k++) shade_disk(P, lds.slot(k), rgba);  // blend the recorded layers, oldest first
+    } else if (live) {  // more crossings than slots: the simple restatement redoes this ray
+        double out[10];
+        int iout[3];
+        trace_ray_simple<FAST>(P, yi, xi, out, iout);
+        for (int i = 0; i < 3; i++) { v[i] = out[i]; p[i] = out[3 + i]; }
+        for (int i = 0; i < 4; i++) rgba[i] = out[6 + i];
+        steps = iout[0]; fate = iout[1]; ncross = iout[2];
+    }
     int star_hits = finish_ray(P, lds_nodes, fate, v, rgba);
 #pragma unroll
     for (int i = 0; i < 3; i++) { res.vel[i] = v[i]; res.pos[i] = p[i]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) res.rgba[i] = rgba[i];
-    res.steps = steps; res.fate = fate; res.disk_hits = dq.hits; res.star_hits = star_hits;
+    res.steps = steps; res.fate = fate; res.disk_hits = ncross; res.star_hits = star_hits;
+    wave_iters = (unsigned)it;
 }
 
 __device__ __forceinline__ void stage_tree(const TraceParams &P, StarNode *s_nodes)
@@ -407,7 +527,10 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const TraceParams P)
 {
     __shared__ StarNode s_nodes[kLdsNodes];
+    __shared__ double s_lane[kLaneLdsDoubles];
+    __shared__ int s_ints[2 * kBlock];
     stage_tree(P, s_nodes);
+    const LaneLds lds(s_lane, s_ints);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -426,9 +549,8 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     const bool inb = xi < P.wt && yi < P.ht;
 
     RayResult res;
-    res.rgba[0] = res.rgba[1] = res.rgba[2] = res.rgba[3] = 0;
-    res.steps = 0; res.fate = -1; res.disk_hits = 0; res.star_hits = 0;
-    if (inb) trace_ray<FAST>(P, s_nodes, yi, xi, res);
+    unsigned w_iters;  // iterations the wavefront ran (= the step count of its slowest lane)
+    trace_ray<FAST>(P, s_nodes, lds, inb, yi, xi, res, w_iters);
 
     if (P.ss) {
         const int base = lane & ~3;
@@ -451,14 +573,14 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     }
 
     unsigned s_steps = wave_sum((unsigned)res.steps);
+    w_iters = (unsigned)res.steps;  // iterations the wavefront ran = the step count of its slowest lane
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) w_iters = max(w_iters, (unsigned)__shfl_xor(w_iters, o, 64));
     unsigned s_cap = wave_sum(res.fate == 2 ? 1u : 0u);
     unsigned s_hor = wave_sum(res.fate == 0 ? 1u : 0u);
     unsigned s_esc = wave_sum(res.fate == 1 ? 1u : 0u);
     unsigned s_disk = wave_sum((unsigned)res.disk_hits);
     unsigned s_star = wave_sum((unsigned)res.star_hits);
-    unsigned w_iters = (unsigned)res.steps;  // iterations this wavefront ran = its slowest lane
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) w_iters = max(w_iters, (unsigned)__shfl_xor(w_iters, o, 64));
     if (lane == 0) {
         atomicAdd(&P.counters[6], (unsigned long long)w_iters);
         atomicAdd(&P.counters[0], (unsigned long long)s_steps);
@@ -475,11 +597,16 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams P, const int32_t *yx, size_t n_rays, bs_ray_record *out)
 {
     __shared__ StarNode s_nodes[kLdsNodes];
+    __shared__ double s_lane[kLaneLdsDoubles];
+    __shared__ int s_ints[2 * kBlock];
     stage_tree(P, s_nodes);
+    const LaneLds lds(s_lane, s_ints);
     size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n_rays) return;
+    const bool live = k < n_rays;
     RayResult res;
-    trace_ray<FAST>(P, s_nodes, yx[2 * k], yx[2 * k + 1], res);
+    unsigned w_iters;
+    trace_ray<FAST>(P, s_nodes, lds, live, live ? yx[2 * k] : 0, live ? yx[2 * k + 1] : 0, res, w_iters);
+    if (!live) return;
     bs_ray_record r;
     for (int i = 0; i < 3; i++) { r.vel[i] = res.vel[i]; r.pos[i] = res.pos[i]; }
     for (int i = 0; i < 4; i++) r.rgba[i] = res.rgba[i];

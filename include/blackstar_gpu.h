@@ -122,6 +122,10 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
  * lowering of sqrt and '/'; bare = 1: the scaling-free FMA sequences used inside the RK4 right-hand side. */
 int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare);
 
+/* Test hook: depth (0..4, default 4) of the per-lane LDS queue of disk crossings; a ray with more crossings
+ * takes the kernel's simple re-trace path, which tests force by shrinking the queue. */
+int bs_debug_set_disk_slots(bs_ctx *ctx, int slots);
+
 /* Roofline probe: times `iters` x 32 dependent-chain FP64 VALU instructions per lane (8 independent chains)
  * on `blocks` x 256 lanes.  kind 0 v_fma_f64, 1 v_mul_f64, 2 v_add_f64, 3 v_rsq_f64, 4 v_rcp_f64.
  * out_ginstr = lane-instructions executed / 1e9 (so rate = out_ginstr / out_ms * 1e3 Ginstr/s). */

@@ -11,13 +11,13 @@ for kname in ["trace_frame_kernelILb1E", "trace_frame_kernelILb0E"]:
     start = [i for i, l in enumerate(S) if l.startswith("_ZN2bs12_GLOBAL__N_118" + kname)][0]
     end = [i for i in range(start, len(S)) if "s_endpgm" in S[i]][0]
     body = S[start:end]
-    for h in [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]:
+    for h in [i for i, l in enumerate(body) if "Loop Header: Depth=" in l]:
         lab = body[h].split(":")[0].strip()
         tag = "Header=" + lab.replace(".L", "")
         idx = [i for i, l in enumerate(body) if tag in l] + [h]
         br = [i for i, l in enumerate(body) if "s_cbranch" in l and lab in l]
         region = body[min(idx):max(idx + br) + 1]
-        if sum("v_rsq_f64" in l for l in region) < 3:
+        if sum("v_rsq_f64" in l for l in region) < 3 or any("Loop Header" in l and i > 0 for i, l in enumerate(body[h + 1:max(idx + br) + 1])):
             continue
         print(kname, lab)
         blocks = []

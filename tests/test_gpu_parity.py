@@ -170,6 +170,36 @@ def test_ragged_resolutions(w, h, ss, tree, oracle, oracle_index):
     assert tree.stats()["steps"] == st["steps"]
 
 
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("slots", [0, 1, 2])
+def test_crossing_queue_overflow_path(slots, mode, tree, oracle, oracle_index):
+    """Rays with more disk crossings than LDS queue slots are re-traced by the kernel's simple path: shrink the
+    queue so that ordinary rays (1-3 crossings) take it, and demand the same image and counters."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 96, 54)
+    cfg["disk_inner"] = 1.05
+    ref, ost = oracle.render(cfg, oracle_index, threads=0)
+    L = _lib.lib()
+    tree.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+    _lib.check(L.bs_debug_set_disk_slots(tree.handle, slots), "set_disk_slots")
+    try:
+        img = bs.render(cfg, tree)
+        st = tree.stats()
+        ys, xs = np.mgrid[0:108:3, 0:192:3]
+        rec = bs.trace_rays(cfg, tree, ys.ravel(), xs.ravel())
+    finally:
+        _lib.check(L.bs_debug_set_disk_slots(tree.handle, 4), "set_disk_slots")
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    orc = oracle.trace_rays(cfg, oracle_index, ys.ravel(), xs.ravel())
+    assert orc["disk_hits"].max() >= 2
+    assert st["steps"] == ost["steps"] and st["disk_hits"] == ost["disk_hits"] and st["star_hits"] == ost["star_hits"]
+    for k in ("steps", "fate", "disk_hits", "star_hits"):
+        assert np.array_equal(rec[k], orc[k]), k
+    rtol, atol = (RTOL_FAST, ATOL_FAST) if mode == "fast" else (RTOL_STRICT, ATOL_STRICT)
+    assert (np.abs(img - ref) <= atol + rtol * np.abs(ref)).all()
+    if mode == "strict":
+        assert np.array_equal(rec["vel"], orc["vel"]) and np.array_equal(rec["pos"], orc["pos"])
+
+
 def test_empty_star_set_and_transparent_disk(tree_empty):
     cfg = scenes.with_res(scenes.DEFAULT, 64, 36)
     cfg["disk_opacity"] = 0.0
