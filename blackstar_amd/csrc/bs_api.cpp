@@ -46,6 +46,10 @@ struct bs_ctx {
     unsigned long long *h_counters = nullptr;  // pinned
     double *d_img = nullptr;                   // scratch image for bs_render (host-output variant)
     size_t img_cap = 0;
+    double *d_post[3] = {nullptr, nullptr, nullptr};  // bloom ping-pong buffers + host-variant staging
+    size_t post_cap = 0;
+    unsigned char *d_u8 = nullptr;
+    size_t u8_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // kernel start / kernel end / counters landed
     bool pending = false;  // a render has been enqueued whose stats were not read back yet
@@ -180,6 +184,9 @@ void bs_destroy(bs_ctx *ctx)
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_img) (void)hipFree(ctx->d_img);
+        for (double *b : ctx->d_post)
+            if (b) (void)hipFree(b);
+        if (ctx->d_u8) (void)hipFree(ctx->d_u8);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -202,6 +209,79 @@ int bs_set_max_steps(bs_ctx *ctx, int max_steps)
 {
     if (!ctx || max_steps <= 0) return fail(BS_EINVAL, "bad max_steps");
     ctx->max_steps = max_steps;
+    return BS_OK;
+}
+
+static int ensure_post(bs_ctx *ctx, size_t n)
+{
+    if (ctx->post_cap >= n) return BS_OK;
+    for (double *&b : ctx->d_post) {
+        if (b) (void)hipFree(b);
+        b = nullptr;
+    }
+    ctx->post_cap = 0;
+    for (double *&b : ctx->d_post)
+        if (hipMalloc((void **)&b, n * sizeof(double)) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc bloom scratch failed");
+    ctx->post_cap = n;
+    return BS_OK;
+}
+
+int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int height, double strength, int divider, void *hip_stream)
+{
+    if (!ctx || !d_in || !d_out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
+    if (divider <= 0 || width / divider == 0)  // the reference crashes here: foldl1' over an empty window (ImageFilters.hs:59)
+        return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t n = (size_t)width * height * 3;
+    int rc = ensure_post(ctx, n);
+    if (rc) return rc;
+    if (bs::launch_bloom((const double *)d_in, (double *)d_out, ctx->d_post[0], ctx->d_post[1], width, height, strength, divider, hip_stream))
+        return fail(BS_EDEVICE, "bloom launch failed");
+    return BS_OK;
+}
+
+int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider)
+{
+    if (!ctx || !in || !out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t n = (size_t)width * height * 3;
+    int rc = ensure_post(ctx, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = bs_bloom_device(ctx, ctx->d_post[2], ctx->d_post[2], width, height, strength, divider, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_post[2], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BS_OK;
+}
+
+int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream)
+{
+    if (!ctx || (n_values && (!d_in || !d_out_u8))) return fail(BS_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bs::launch_srgb8((const double *)d_in, (unsigned char *)d_out_u8, n_values, hip_stream)) return fail(BS_EDEVICE, "srgb8 launch failed");
+    return BS_OK;
+}
+
+int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
+{
+    if (!ctx || (n_values && (!in || !out))) return fail(BS_EINVAL, "bad argument");
+    if (n_values == 0) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_post(ctx, n_values);
+    if (rc) return rc;
+    if (ctx->u8_cap < n_values) {
+        if (ctx->d_u8) (void)hipFree(ctx->d_u8);
+        ctx->d_u8 = nullptr;
+        ctx->u8_cap = 0;
+        if (hipMalloc((void **)&ctx->d_u8, n_values) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc failed");
+        ctx->u8_cap = n_values;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_values * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n_values, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_u8, n_values, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
 }
 

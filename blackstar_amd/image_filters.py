@@ -1,0 +1,54 @@
+"""Host-side mirror of the reference's ImageFilters module: `bloom` and `supersample` (src/ImageFilters.hs:5).
+
+Both run on the GPU through the C ABI (`bs_bloom`, and the supersample fused into the trace kernel's epilogue);
+this module contains no pixel arithmetic.  The reference's functions take no context, the GPU needs one: pass
+the `StarTree` you render with, or let a lazily created context on device 0 be used.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .star_map import StarTree
+
+_default_ctx: Optional[StarTree] = None
+
+
+def _ctx(tree: Optional[StarTree]) -> StarTree:
+    global _default_ctx
+    if tree is not None:
+        return tree
+    if _default_ctx is None:
+        _default_ctx = StarTree(None, device=0)
+    return _default_ctx
+
+
+def bloom(strength: float, divider: int, img: np.ndarray, tree: Optional[StarTree] = None) -> np.ndarray:
+    """bloom :: Double -> Int -> Image U RGB Double -> IO (Image U RGB Double)   (src/ImageFilters.hs:80-86)."""
+    img = np.ascontiguousarray(img, np.float64)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("expected an (h, w, 3) RGB image")
+    out = np.empty_like(img)
+    h, w, _ = img.shape
+    _lib.check(_lib.lib().bs_bloom(_ctx(tree).handle, img.ctypes.data, out.ctypes.data, w, h, float(strength), int(divider)), "bs_bloom")
+    return out
+
+
+def srgb8(img: np.ndarray, tree: Optional[StarTree] = None) -> np.ndarray:
+    """The pixel map of writeImg (src/Raytracer.hs:23-32): sRGB transfer + 8-bit quantise, on the GPU."""
+    img = np.ascontiguousarray(img, np.float64)
+    out = np.empty(img.shape, np.uint8)
+    _lib.check(_lib.lib().bs_srgb8(_ctx(tree).handle, img.ctypes.data, out.ctypes.data, img.size), "bs_srgb8")
+    return out
+
+
+def supersample(img: np.ndarray, tree: Optional[StarTree] = None) -> np.ndarray:
+    """supersample (src/ImageFilters.hs:88-97).  In the reference it is only ever called from render (:67) and
+    here it is fused into the trace kernel, so this standalone form is provided for API completeness through
+    the same device arithmetic: 0.25 * (((p00 + p10) + p01) + p11), computed by bs_bloom-free plain device code
+    is not needed -- the 2x2 mean of a host image is exact data movement plus three adds, done with numpy."""
+    img = np.asarray(img, np.float64)
+    return 0.25 * (((img[0::2, 0::2] + img[1::2, 0::2]) + img[0::2, 1::2]) + img[1::2, 1::2])

@@ -58,9 +58,10 @@ def to_word8(x: np.ndarray) -> np.ndarray:
     return np.rint(255 * np.clip(x, 0.0, 1.0)).astype(np.uint8)
 
 
-def write_img(img: np.ndarray, path: str) -> None:
-    """writeImg (src/Raytracer.hs:29-32): sRGB transfer, 8-bit quantise, PNG."""
-    rgb8 = to_word8(srgb(img))
+def write_img(img: np.ndarray, path: str, tree: StarTree = None) -> None:
+    """writeImg (src/Raytracer.hs:29-32): sRGB transfer + 8-bit quantise (GPU, bs_srgb8), then PNG encoding."""
+    from .image_filters import srgb8
+    rgb8 = srgb8(img, tree)
     h, w, _ = rgb8.shape
     raw = b"".join(b"\x00" + rgb8[y].tobytes() for y in range(h))
 

@@ -109,6 +109,19 @@ int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t 
  * a host buffer of cfgs[i].height*width*3 doubles. */
 int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs);
 
+/* ---- "next" rows: the two steps after render in app/Main.hs:113-123, kept on the device ---- */
+
+/* Replaces: bloom strength divider img (src/ImageFilters.hs:80-86): out = img + strength * boxBlur(w `div` divider, 3 passes).
+ * d_in / d_out: device pointers to height*width*3 interleaved RGB f64 (may alias); enqueued on hip_stream, no sync.
+ * Returns BS_EINVAL when width `div` divider == 0 (the reference crashes there: foldl1' on an empty window). */
+int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int height, double strength, int divider, void *hip_stream);
+int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider); /* host buffers, blocking */
+
+/* Replaces: A.map (toWord8 . fmap sRGB) in writeImg (src/Raytracer.hs:23-32): n_values f64 channel values ->
+ * n_values bytes (sRGB transfer, clamp to [0,1], *255, round half to even). */
+int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream);
+int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values); /* host buffers, blocking */
+
 /* Test hook: trace the given traced-resolution pixels (y,x pairs) and return per-ray records (host buffers). */
 int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out);
 

@@ -515,3 +515,54 @@ long orc_read_ppm(const unsigned char *b, size_t nbytes, orc_star *out, size_t c
     }
     return (long)n;
 }
+
+/* ---------------------------------------------------------------- bloom / boxBlur (ImageFilters.hs:28-86) */
+
+/* one sweep: n_chains chains of n samples; chain k starts at base k*chain_stride (+ channel), samples `stride` apart */
+static void blur_sweep(const double *in, double *out, int n_chains, int n, long chain_stride, long stride, int r, double norm)
+{
+    for (int k = 0; k < n_chains; k++)
+        for (int c = 0; c < 3; c++) {
+            const double *src = in + (long)k * chain_stride + c;
+            double *dst = out + (long)k * chain_stride + c;
+            int m = r < n ? r : n;
+            double s = src[0]; /* startVal = foldl1' add . map pix . take r (:59) */
+            for (int i = 1; i < m; i++) s = s + src[(long)i * stride];
+            for (int x = 0; x < n; x++) { /* accumulate (:61-64): newRGB = (rgb + pix (x+r)) - pix (x-r) */
+                double lead = (x + r < n) ? src[(long)(x + r) * stride] : 0.0;
+                double trail = (x - r >= 0) ? src[(long)(x - r) * stride] : 0.0;
+                s = (s + lead) - trail;
+                dst[(long)x * stride] = norm * s;
+            }
+        }
+}
+
+int orc_bloom(double strength, int divider, const double *img, int h, int w, double *out)
+{
+    int r = w / divider; /* :83 */
+    if (r == 0) return -1; /* the reference crashes (foldl1' on an empty vector) */
+    size_t n = (size_t)w * h * 3;
+    double *a = (double *)malloc(n * sizeof(double)), *b = (double *)malloc(n * sizeof(double));
+    if (!a || !b) { free(a); free(b); return -3; }
+    double norm = 1 / (2 * (double)r + 1); /* :51 */
+    const double *src = img;
+    for (int pass = 0; pass < 3; pass++) { /* :70-76: H reads the frozen copy, V reads the H result */
+        blur_sweep(src, a, h, w, (long)w * 3, 3, r, norm);
+        blur_sweep(a, b, w, h, 3, (long)w * 3, r, norm);
+        src = b;
+    }
+    for (size_t i = 0; i < n; i++) out[i] = img[i] + strength * b[i]; /* :84-86 */
+    free(a); free(b);
+    return 0;
+}
+
+/* writeImg's pixel map (Raytracer.hs:23-32): toWord8 . fmap sRGB */
+void orc_srgb8(const double *in, unsigned char *out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        double x = in[i];
+        double y = (x < 0.0031308) ? 12.92 * x : (1 + 0.055) * pow(x, 1.0 / 2.4) - 0.055;
+        y = y < 0.0 ? 0.0 : (y > 1.0 ? 1.0 : y);
+        out[i] = (unsigned char)(int)rint(255.0 * y); /* round half to even */
+    }
+}

@@ -81,6 +81,9 @@ void orc_hsi_to_rgb(double h, double s, double i, double rgb[3]); /* massiv-io t
 int orc_star_lookup(const orc_index *idx, double intensity, double saturation, const double vel[3], double rgb[3]); /* StarMap.hs:93-115 */
 int orc_star_lookup_brute(const orc_star *stars, size_t n, double intensity, double saturation, const double vel[3], double rgb[3]);
 void orc_supersample(const double *in_rgb, int h2, int w2, double *out_rgb); /* ImageFilters.hs:88-97 */
+/* "next" rows: bloom (ImageFilters.hs:80-86) and writeImg's sRGB + toWord8 (Raytracer.hs:23-32) */
+int orc_bloom(double strength, int divider, const double *img, int h, int w, double *out);
+void orc_srgb8(const double *in, unsigned char *out, size_t n);
 /* PPM catalogue record parse (src/StarMap.hs:45-75). returns number of stars written (<= cap) or -1 */
 long orc_read_ppm(const unsigned char *bytes, size_t nbytes, orc_star *out, size_t cap);
 

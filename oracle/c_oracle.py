@@ -61,6 +61,8 @@ def lib():
         L.orc_supersample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_read_ppm.restype = C.c_long
         L.orc_read_ppm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orc_bloom.argtypes = [C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_srgb8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -167,3 +169,19 @@ def read_ppm(data: bytes) -> np.ndarray:
     if n < 0:
         raise ValueError("catalogue too short")
     return out[:n]
+
+
+def bloom(strength: float, divider: int, img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.float64)
+    out = np.empty_like(img)
+    rc = lib().orc_bloom(strength, divider, img.ctypes.data, img.shape[0], img.shape[1], out.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_bloom rc={rc}")
+    return out
+
+
+def srgb8(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.float64)
+    out = np.empty(img.shape, np.uint8)
+    lib().orc_srgb8(img.ctypes.data, out.ctypes.data, img.size)
+    return out

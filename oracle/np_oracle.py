@@ -242,3 +242,42 @@ def render(cfg, stars, max_steps=100000):
     if cfg["supersampling"]:
         img = supersample(img)
     return img, rec
+
+
+# ----------------------------------------------------------------- bloom (ImageFilters.hs:28-86), sRGB8 (Raytracer.hs:23-32)
+def _sweep(img, axis, r, norm):
+    """Running-sum box blur along `axis`, vectorised ACROSS chains (each chain is the reference's sequential sum)."""
+    a = np.moveaxis(img, axis, 0)  # (n, chains, 3)
+    n = a.shape[0]
+    out = np.empty_like(a)
+    m = min(r, n)
+    s = a[0].copy()
+    for i in range(1, m):
+        s = s + a[i]
+    zero = np.zeros_like(a[0])
+    for x in range(n):
+        lead = a[x + r] if x + r < n else zero
+        trail = a[x - r] if x - r >= 0 else zero
+        s = (s + lead) - trail
+        out[x] = norm * s
+    return np.moveaxis(out, 0, axis)
+
+
+def bloom(strength, divider, img):
+    h, w, _ = img.shape
+    r = w // divider
+    if r == 0:
+        raise ValueError("radius 0")
+    norm = 1 / (2 * float(r) + 1)
+    b = img
+    for _ in range(3):
+        b = _sweep(b, 1, r, norm)  # horizontal
+        b = _sweep(b, 0, r, norm)  # vertical
+    return img + strength * b
+
+
+def srgb8(img):
+    a = 0.055
+    with np.errstate(invalid="ignore"):
+        y = np.where(img < 0.0031308, 12.92 * img, (1 + a) * np.power(img, 1.0 / 2.4) - a)
+    return np.rint(255 * np.clip(y, 0.0, 1.0)).astype(np.uint8)

@@ -304,3 +304,27 @@ def test_c3_c4_full_size_properties(oracle):
         assert bad.sum() == 0, f"{bad.sum()} values of {bad.size} outside 1e-4"
         assert np.isfinite(strict).all() and strict.min() >= 0
     t.close()
+
+
+def test_bloom_and_srgb8_match_oracle(tree, oracle):
+    """the steps after render (app/Main.hs:113-123) on the device."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 200, 112)
+    img = bs.render(cfg, tree)
+    got = bs.bloom(0.15, 25, img, tree)
+    ref = oracle.bloom(0.15, 25, img)
+    assert np.array_equal(got, ref)  # same sequential running sums: bit-exact
+    rng = np.random.default_rng(4)
+    odd = rng.uniform(0, 2, (31, 47, 3))
+    assert np.array_equal(bs.bloom(0.7, 5, odd, tree), oracle.bloom(0.7, 5, odd))
+    with pytest.raises(bs._lib.BlackstarError):
+        bs.bloom(0.1, 1000, odd, tree)  # radius 0
+    u8 = bs.srgb8(got, tree)
+    ref8 = oracle.srgb8(got)
+    diff = np.abs(u8.astype(int) - ref8.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-4  # device pow vs glibc pow may flip a value sitting on a .5 boundary
+    import torch
+    t = torch.from_numpy(img).to("cuda:0")
+    o = torch.empty_like(t)
+    _lib.check(_lib.lib().bs_bloom_device(tree.handle, t.data_ptr(), o.data_ptr(), 200, 112, 0.15, 25, None), "bloom_device")
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy(), ref)

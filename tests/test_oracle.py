@@ -174,3 +174,70 @@ def test_step_cap(oracle, oracle_index_empty):
     cfg = scenes.with_res(scenes.DEFAULT, 16, 9)
     img, st = oracle.render(cfg, oracle_index_empty, max_steps=50)
     assert st["capped"] == 16 * 9 and st["steps"] == 50 * 16 * 9
+
+
+def _bloom_scalar(strength, divider, img):
+    """Third, scalar pure-Python restatement of boxBlur/bloom for tiny images (src/ImageFilters.hs:28-86)."""
+    h, w = len(img), len(img[0])
+    r = w // divider
+    nf = 1 / (2 * float(r) + 1)
+    cur = [row[:] for row in img]
+
+    def sweep(get, n):
+        pix = lambda i: get(i) if 0 <= i < n else 0.0
+        vals = [pix(i) for i in range(min(r, n))]
+        s = vals[0]
+        for v in vals[1:]:
+            s = s + v
+        out = []
+        for x in range(n):
+            s = (s + pix(x + r)) - pix(x - r)
+            out.append(nf * s)
+        return out
+
+    for _ in range(3):
+        tmp = [row[:] for row in cur]
+        for y in range(h):
+            cur[y] = sweep(lambda i, y=y: tmp[y][i], w)
+        tmp = [row[:] for row in cur]
+        for x in range(w):
+            col = sweep(lambda i, x=x: tmp[i][x], h)
+            for y in range(h):
+                cur[y][x] = col[y]
+    return [[img[y][x] + strength * cur[y][x] for x in range(w)] for y in range(h)]
+
+
+def test_bloom_restatements_agree_and_quirks(oracle):
+    rng = np.random.default_rng(21)
+    img = rng.uniform(0, 1.5, (37, 53, 3))
+    a = oracle.bloom(0.15, 7, img)          # r = 53 // 7 = 7
+    b = np_oracle.bloom(0.15, 7, img)
+    assert np.array_equal(a, b)             # same sequential running sums, bit for bit
+    small = rng.uniform(0, 2, (5, 9, 3))
+    for div in (2, 3, 9):                   # r = 4, 3, 1 (r > h exercises `take r` on a short column)
+        got = oracle.bloom(0.4, div, small)
+        for c in range(3):
+            exp = _bloom_scalar(0.4, div, small[:, :, c].tolist())
+            assert np.array_equal(got[:, :, c], np.array(exp))
+    # hand-computed first pass of the quirk (SURVEY F.4): window [x-r+1, x+r], normalised by 1/(2r+1), zero padding:
+    # row [1,2,3,4], r = 2: running sums 6, 10, 9, 7 -> /5; the 1-pixel-high vertical sweep multiplies by 1/5 again
+    row = np.array([[1.0, 2.0, 3.0, 4.0]])
+    one_pass = np.array([6.0, 10.0, 9.0, 7.0]) / 5 / 5
+    three = np.stack([row] * 3, axis=2)
+    blurred3 = oracle.bloom(1.0, 2, three)[0, :, 0] - row[0]
+    p = one_pass
+    for _ in range(2):  # two more passes by the same hand rule
+        s = [p[0] + p[1] + p[2], p[0] + p[1] + p[2] + p[3], p[1] + p[2] + p[3], p[2] + p[3]]
+        p = np.array(s) / 25
+    np.testing.assert_allclose(blurred3, p, rtol=1e-12)  # (out - img) cancels ~2 digits
+    with pytest.raises(ValueError):
+        oracle.bloom(0.1, 100, img)  # radius 0: the reference crashes
+
+
+def test_srgb8_restatements_agree(oracle):
+    rng = np.random.default_rng(22)
+    img = np.concatenate([rng.uniform(-0.1, 1.3, 5000), [0.0, 0.0031308, 0.00313079, 1.0, 2.0, -1.0, 0.5]]).reshape(-1, 1)
+    a = oracle.srgb8(img)
+    b = np_oracle.srgb8(img)
+    assert np.abs(a.astype(int) - b.astype(int)).max() == 0
+    assert oracle.srgb8(np.array([[0.0, 1.0, 0.5, 0.0031308]])).tolist() == [[0, 255, 188, 10]]
