@@ -1,0 +1,140 @@
+// blackstar_gpu.hpp -- C++ host mirror of the reference's interface for the hot path, header-only, over the
+// C ABI of blackstar_gpu.h.  The reference is compiled Haskell and its toolchain is absent here, so this is the
+// compiled-language host side: same names and argument meaning as the reference's modules --
+//   ConfigFile: Config{scene, camera}   (src/ConfigFile.hs:16-38, defaults :66-79)
+//   StarMap:    StarTree, readMapFromFile (src/StarMap.hs:25-26, 77-80)
+//   Raytracer:  render :: Config -> StarTree -> Image   (src/Raytracer.hs:53)
+//   ImageFilters: bloom (src/ImageFilters.hs:80)
+// Errors surface as std::runtime_error carrying bs_last_error() (the reference's Either String / error calls).
+#pragma once
+
+#include <array>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "blackstar_gpu.h"
+
+namespace blackstar {
+
+using V3 = std::array<double, 3>;
+
+struct Camera {  // src/ConfigFile.hs:34-38
+    V3 position{}, lookAt{}, upVec{};
+    double fov = 1.0;
+};
+
+struct Scene {  // src/ConfigFile.hs:20-32 with the defaults of :66-79
+    double safeDistance = 0;  // never read from YAML; render derives it (src/Raytracer.hs:59-60)
+    double stepSize = 0.3, bloomStrength = 0.4;
+    int bloomDivider = 25;
+    double starIntensity = 0.7, starSaturation = 0.7;
+    V3 diskColor{0.16, 0.1, 0.95};  // PixelHSI, hue in [0,1)
+    double diskOpacity = 0, diskInner = 3, diskOuter = 12;
+    std::pair<int, int> resolution{1280, 720};
+    bool supersampling = false;
+};
+
+struct Config {  // src/ConfigFile.hs:16-18
+    Scene scene;
+    Camera camera;
+    bs_config to_bs_config() const
+    {
+        bs_config c{};
+        for (int i = 0; i < 3; i++) {
+            c.cam_pos[i] = camera.position[i];
+            c.cam_lookat[i] = camera.lookAt[i];
+            c.cam_up[i] = camera.upVec[i];
+            c.disk_hsi[i] = scene.diskColor[i];
+        }
+        c.fov = camera.fov;
+        c.step_size = scene.stepSize;
+        c.star_intensity = scene.starIntensity;
+        c.star_saturation = scene.starSaturation;
+        c.disk_opacity = scene.diskOpacity;
+        c.disk_inner = scene.diskInner;  // as parsed: un-squared
+        c.disk_outer = scene.diskOuter;
+        c.width = scene.resolution.first;
+        c.height = scene.resolution.second;
+        c.supersampling = scene.supersampling ? 1 : 0;
+        return c;
+    }
+};
+
+// Image U RGB Double: h x w interleaved RGB f64, linear light.
+struct Image {
+    int width = 0, height = 0;
+    std::vector<double> rgb;
+    double &at(int y, int x, int c) { return rgb[((size_t)y * width + x) * 3 + c]; }
+};
+
+using Star = bs_star;  // (V3 position, (mag, hue, sat)) after starColor'
+
+// readMapFromFile (+ starColor'): PPM catalogue file -> stars
+inline std::vector<Star> readMapFromFile(const std::string &path)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<unsigned char> buf;
+    unsigned char tmp[1 << 16];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    std::fclose(f);
+    long cnt = bs_read_ppm(buf.data(), buf.size(), nullptr, 0);
+    if (cnt < 0) throw std::runtime_error("too few bytes");
+    std::vector<Star> stars((size_t)cnt);
+    bs_read_ppm(buf.data(), buf.size(), stars.data(), stars.size());
+    return stars;
+}
+
+// The StarTree argument of render: the star set resident on one GPU (built once, reused for every scene).
+class StarTree {
+public:
+    explicit StarTree(const std::vector<Star> &stars, int device = 0) : ctx_(bs_create(device, stars.data(), stars.size()))
+    {
+        if (!ctx_) throw std::runtime_error(std::string("bs_create: ") + bs_last_error());
+    }
+    StarTree(const StarTree &) = delete;
+    StarTree &operator=(const StarTree &) = delete;
+    ~StarTree() { bs_destroy(ctx_); }
+    bs_ctx *handle() const { return ctx_; }
+
+private:
+    bs_ctx *ctx_;
+};
+
+inline StarTree buildStarTree(const std::vector<Star> &stars, int device = 0) { return StarTree(stars, device); }
+
+// render :: Config -> StarTree -> Image U RGB Double
+inline Image render(const Config &cfg, const StarTree &tree)
+{
+    bs_config c = cfg.to_bs_config();
+    if (c.width <= 0 || c.height <= 0) throw std::runtime_error("bs_render: resolution must be positive");
+    Image img;
+    img.width = c.width;
+    img.height = c.height;
+    img.rgb.resize((size_t)c.width * c.height * 3);
+    if (bs_render(tree.handle(), &c, img.rgb.data(), img.rgb.size())) throw std::runtime_error(std::string("bs_render: ") + bs_last_error());
+    return img;
+}
+
+// bloom :: Double -> Int -> Image U RGB Double -> IO (Image U RGB Double)
+inline Image bloom(double strength, int divider, const Image &img, const StarTree &tree)
+{
+    Image out = img;
+    if (bs_bloom(tree.handle(), img.rgb.data(), out.rgb.data(), img.width, img.height, strength, divider))
+        throw std::runtime_error(std::string("bs_bloom: ") + bs_last_error());
+    return out;
+}
+
+// the pixel map of writeImg: toWord8 . fmap sRGB
+inline std::vector<unsigned char> toSRGB8(const Image &img, const StarTree &tree)
+{
+    std::vector<unsigned char> out(img.rgb.size());
+    if (bs_srgb8(tree.handle(), img.rgb.data(), out.data(), out.size())) throw std::runtime_error(std::string("bs_srgb8: ") + bs_last_error());
+    return out;
+}
+
+}  // namespace blackstar

@@ -1,0 +1,42 @@
+// Test driver for include/blackstar_gpu.hpp: plain C++ (g++, no HIP headers, no Python, no torch) linked against
+// libblackstar_gpu.so.  Usage: host_render CATALOGUE.ppm OUT.f64 [bloom]   -- renders the default-aa camera at
+// 96x54 (the golden fixture image_c3_default_aa_96x54) through blackstar::render and dumps raw doubles.
+#include <cstdio>
+#include <cstring>
+
+#include "blackstar_gpu.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: host_render CATALOGUE.ppm OUT.f64 [bloom]\n"); return 2; }
+    try {
+        using namespace blackstar;
+        Config cfg;  // scenes/default-aa.yaml (reference scenes/default-aa.yaml:1-16) at 96x54
+        cfg.camera = Camera{{0, 1, -20}, {2, 0, 0}, {-0.2, 1, 0}, 1.5};
+        cfg.scene.resolution = {96, 54};
+        cfg.scene.bloomStrength = 0.15;
+        cfg.scene.starIntensity = 0.4;
+        cfg.scene.starSaturation = 1.5;
+        cfg.scene.diskColor = {180.0 / 360, 0.1, 1.05};
+        cfg.scene.diskOpacity = 0.95;
+        cfg.scene.diskInner = 1.8;
+        cfg.scene.diskOuter = 13;
+        cfg.scene.supersampling = true;
+        StarTree tree = buildStarTree(readMapFromFile(argv[1]), 0);
+        bs_set_mode(tree.handle(), BS_MODE_STRICT);
+        Image img = render(cfg, tree);
+        if (argc > 3 && !std::strcmp(argv[3], "bloom")) img = bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img, tree);
+        FILE *f = std::fopen(argv[2], "wb");
+        if (!f) return 3;
+        std::fwrite(img.rgb.data(), sizeof(double), img.rgb.size(), f);
+        std::fclose(f);
+        // error behaviour: a bad hue is rejected with the reference's message, not rendered
+        cfg.scene.diskColor[0] = 1.0;
+        try { render(cfg, tree); return 4; } catch (const std::runtime_error &e) { if (!std::strstr(e.what(), "not properly scaled")) return 5; }
+        std::printf("ok %dx%d\n", img.width, img.height);
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

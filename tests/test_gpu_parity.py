@@ -328,3 +328,21 @@ def test_bloom_and_srgb8_match_oracle(tree, oracle):
     _lib.check(_lib.lib().bs_bloom_device(tree.handle, t.data_ptr(), o.data_ptr(), 200, 112, 0.15, 25, None), "bloom_device")
     torch.cuda.synchronize()
     assert np.array_equal(o.cpu().numpy(), ref)
+
+
+def test_cpp_host_mirror(tmp_path, oracle):
+    """include/blackstar_gpu.hpp (the compiled-language host mirror of render/bloom) from a plain g++ program."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host_render"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "host_render.cpp"),
+                           "-o", str(exe), "-L" + os.path.join(root, "blackstar_amd"), "-lblackstar_gpu",
+                           "-Wl,-rpath," + os.path.join(root, "blackstar_amd")])
+    g = load_golden("image_c3_default_aa_96x54")
+    out = tmp_path / "img.f64"
+    subprocess.check_call([str(exe), os.path.join(root, "tests", "golden", "catalogue_2000.ppm"), str(out)])
+    img = np.fromfile(out, np.float64).reshape(54, 96, 3)
+    np.testing.assert_allclose(img, g["img"], rtol=RTOL_STRICT, atol=ATOL_STRICT)
+    subprocess.check_call([str(exe), os.path.join(root, "tests", "golden", "catalogue_2000.ppm"), str(out), "bloom"])
+    bl = np.fromfile(out, np.float64).reshape(54, 96, 3)
+    assert np.array_equal(bl, oracle.bloom(0.15, 25, img))

@@ -114,3 +114,18 @@ def test_tree_serialisation_roundtrip(tmp_path, catalogue_bytes):
     p.write_bytes(blob[:-1])
     with pytest.raises(Exception):
         bs.read_tree_from_file(str(p))
+
+
+def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """The C++ host mirror builds with plain g++ against the C ABI; without a HIP device it must fail, not fall back."""
+    import subprocess
+    exe = tmp_path / "host_render"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_render.cpp"),
+                           "-o", str(exe), "-L" + os.path.join(ROOT, "blackstar_amd"), "-lblackstar_gpu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "blackstar_amd")])
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_parity.py::test_cpp_host_mirror")
+    r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "catalogue_2000.ppm"), str(tmp_path / "o.f64")], capture_output=True, text=True)
+    assert r.returncode == 1 and "bs_create" in r.stderr
+    assert not (tmp_path / "o.f64").exists()
