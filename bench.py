@@ -46,6 +46,21 @@ def cpu_baseline(cfg, star_bytes, budget_s):
                       f"C restatement of the reference CPU path (oracle/blackstar_oracle.c, -O2, pthreads over rows)"}
 
 
+def pmc_traffic(mode):
+    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950 -- an upper
+    bound here, since that calibration is for wide coalesced reads and this kernel's reads are 32-byte k-d nodes)."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(fn)).get(mode, {})
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["strict", "fast"], default=os.environ.get("BLACKSTAR_BENCH_MODE", "fast"))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
-    ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes/launch from a separate rocprofv3 --pmc pass")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes/launch from separate rocprofv3 --pmc passes (default: read profiles/*_pmc_summary.json)")
     args = ap.parse_args()
 
     import numpy as np
@@ -121,6 +137,7 @@ def main():
         flops = FLOP_PER_STEP * executed
         achieved = flops / (kernel_ms * 1e-3) / 1e12  # mean launch duration over the timed region (HIP events on the launch stream)
         alg_bytes = 24.0 * W * H
+        traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes is not None else pmc_traffic(args.mode)
         res = {
             "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml", "value": value, "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -135,7 +152,7 @@ def main():
             "roofline": {"bound": "valu", "detail": "FP64 VALU issue (scalar ODE per lane; HBM and MFMA are not the bound)",
                          "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS,
                          "flop_per_launch": flops, "flop_per_step": FLOP_PER_STEP, "rk4_steps_executed": executed,
-                         "traffic": args.traffic_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                                  "peak_GBs": PEAK_HBM_GBS, "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
         }
