@@ -285,6 +285,38 @@ int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
     return BS_OK;
 }
 
+int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_rgb8, size_t out_bytes)
+{
+    if (!ctx || !cfg || !out_rgb8) return fail(BS_EINVAL, "null argument");
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t n = (size_t)cfg->width * cfg->height * 3;
+    if (out_bytes < n) return fail(BS_EINVAL, "output buffer too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_post(ctx, n);
+    if (rc) return rc;
+    if (ctx->u8_cap < n) {
+        if (ctx->d_u8) (void)hipFree(ctx->d_u8);
+        ctx->d_u8 = nullptr;
+        ctx->u8_cap = 0;
+        if (hipMalloc((void **)&ctx->d_u8, n) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc failed");
+        ctx->u8_cap = n;
+    }
+    // doRender (app/Main.hs:105-123): render -> bloom if bloomStrength /= 0 -> writeImg's sRGB + toWord8, all in HBM
+    rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
+    if (rc) return rc;
+    if (bloom_strength != 0) {
+        rc = bs_bloom_device(ctx, ctx->d_post[2], ctx->d_post[2], cfg->width, cfg->height, bloom_strength, bloom_divider, ctx->stream);
+        if (rc) return rc;
+    }
+    rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return BS_OK;
+}
+
 int bs_debug_set_disk_slots(bs_ctx *ctx, int slots)
 {
     if (!ctx || slots < 0 || slots > 4) return fail(BS_EINVAL, "bad slots");

@@ -7,7 +7,8 @@
 // boxBlur is a RUNNING sum in the reference -- S <- (S + pix(x+r)) - pix(x-r), out = S/(2r+1) -- so each
 // row (column) is a sequential floating-point chain; reproducing its bits means walking it in order.  The
 // parallelism is across chains: one lane per (row, channel) for the horizontal sweep, one per (column,
-// channel) for the vertical one.  Quirks preserved: the window is [x-r+1, x+r] (2r
+// channel) for the vertical one.  Both run as a sweep along the slow axis of a row-major array (the
+// horizontal one on a transposed copy) so that adjacent lanes touch adjacent doubles.  Quirks preserved: the window is [x-r+1, x+r] (2r
 // samples) but the normalisation is 1/(2r+1); out-of-range pixels read as 0; each pass is H then V with V
 // reading the H result; 3 passes.
 #include <hip/hip_runtime.h>
@@ -17,24 +18,63 @@
 namespace bs {
 namespace {
 
-// One chain = `n` samples `stride` doubles apart starting at in + base (same addressing for out).
-__global__ __launch_bounds__(256) void box_blur_sweep(const double *in, double *out, int n_chains, int n, long chain_stride, long stride, int chan,
-                                                      int r, double norm)
+// Sweep along the slow axis of a row-major [n][chains] array of doubles (chains = pixels_per_row * 3): lane k
+// owns the chain { a[i][k] : i = 0..n-1 }.  Adjacent lanes touch adjacent doubles -> every load and store is a
+// fully coalesced 512-B wave access.  The chain itself is sequential by definition (a running sum), so the
+// only latency hiding is memory-level: the next kUnroll leading / trailing samples are fetched ahead of the
+// add-subtract chain that consumes them.
+constexpr int kUnroll = 8;
+
+__global__ __launch_bounds__(64) void box_blur_sweep(const double *__restrict__ in, double *__restrict__ out, int chains, int n, int r, double norm)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_chains * chan) return;
-    long base = (long)(k / chan) * chain_stride + (k % chan);
-    const double *src = in + base;
-    double *dst = out + base;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= chains) return;
+    const double *src = in + k;
+    double *dst = out + k;
+    const long stride = chains;
     // startVal = foldl1' add (pix <$> take r crds)                       (ImageFilters.hs:59)
-    int m = r < n ? r : n;
+    const int m = r < n ? r : n;
     double s = src[0];
     for (int i = 1; i < m; i++) s = s + src[(long)i * stride];
-    for (int x = 0; x < n; x++) {  // accumulate (:61-64)
-        double lead = (x + r < n) ? src[(long)(x + r) * stride] : 0.0;   // ixh / ixv: out of bounds -> black
+    int x = 0;
+    for (; x + kUnroll <= n; x += kUnroll) {  // accumulate (:61-64), kUnroll samples per trip
+        double lead[kUnroll], trail[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const int xl = x + u + r, xt = x + u - r;
+            lead[u] = (xl < n) ? src[(long)xl * stride] : 0.0;   // ixh / ixv: out of bounds -> black
+            trail[u] = (xt >= 0) ? src[(long)xt * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            s = (s + lead[u]) - trail[u];
+            dst[(long)(x + u) * stride] = norm * s;
+        }
+    }
+    for (; x < n; x++) {
+        double lead = (x + r < n) ? src[(long)(x + r) * stride] : 0.0;
         double trail = (x - r >= 0) ? src[(long)(x - r) * stride] : 0.0;
         s = (s + lead) - trail;
         dst[(long)x * stride] = norm * s;
+    }
+}
+
+// [rows][cols] pixels of 3 doubles -> [cols][rows]; 32x32-pixel tiles through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void transpose_rgb(const double *__restrict__ in, double *__restrict__ out, int rows, int cols)
+{
+    __shared__ double tile[32][32 * 3 + 1];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * 96; i += 256) {
+        int rr = i / 96, cc = i % 96;  // cc indexes doubles within the tile row (pixel cc/3, channel cc%3)
+        int r = r0 + rr, c = c0 + cc / 3;
+        if (r < rows && c < cols) tile[rr][cc] = in[((size_t)r * cols + c0) * 3 + cc];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 96; i += 256) {
+        int cc = i / 96, rr3 = i % 96;  // output row = input column c0+cc; within it pixel rr3/3 (= input row), channel rr3%3
+        int rr = rr3 / 3, ch = rr3 % 3;
+        int r = r0 + rr, c = c0 + cc;
+        if (r < rows && c < cols) out[((size_t)c * rows + r0) * 3 + rr3] = tile[rr][cc * 3 + ch];
     }
 }
 
@@ -64,15 +104,19 @@ int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, in
     const int r = w / divider;  // boxBlur (w `div` divider) 3 img   (ImageFilters.hs:83)
     const double norm = 1 / (2 * (double)r + 1);
     const size_t n = (size_t)w * h * 3;
+    const dim3 tgrid_hw((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32));  // transposing an h x w image
+    const dim3 tgrid_wh((unsigned)((h + 31) / 32), (unsigned)((w + 31) / 32));  // transposing a  w x h image
     const double *src = d_in;
     for (int pass = 0; pass < 3; pass++) {
-        // horizontal: one chain per row, samples 3 doubles apart; reads src, writes A
-        hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((h * 3 + 255) / 256)), dim3(256), 0, s, src, d_a, h, w, (long)w * 3, 3L, 3, r, norm);
-        // vertical: one chain per column, samples one row apart; reads A, writes B
-        hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((w * 3 + 255) / 256)), dim3(256), 0, s, (const double *)d_a, d_b, w, h, 3L, (long)w * 3, 3,
-                           r, norm);
+        // horizontal sweep = transpose, sweep along the slow axis (coalesced), transpose back.  Same per-chain arithmetic.
+        hipLaunchKernelGGL(transpose_rgb, tgrid_hw, dim3(256), 0, s, src, d_a, h, w);                                     // src (h x w) -> A (w x h)
+        hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((h * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, h * 3, w, r, norm);  // A -> B
+        hipLaunchKernelGGL(transpose_rgb, tgrid_wh, dim3(256), 0, s, (const double *)d_b, d_a, w, h);                     // B (w x h) -> A (h x w)
+        // vertical sweep reads the H result (ImageFilters.hs:75-76)
+        hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((w * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);  // A -> B
         src = d_b;
     }
+    // NOTE: pass p+1 transposes B into A while B is still the source -- A and B never alias, so this is safe.
     hipLaunchKernelGGL(bloom_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (const double *)d_b, d_out, n, strength);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

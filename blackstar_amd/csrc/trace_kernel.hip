@@ -75,14 +75,23 @@ __device__ __forceinline__ double coef_strict(double h2c, double q)
     return div_rn(h2c, n5);
 }
 
-// FAST: -(1.5*h2) * |pos|^-5 from v_rsq_f64 (~2^-26) + one cubic Newton step (-> ~1 ulp); no sqrt, no divide.
+// FAST: -(1.5*h2) * |pos|^-5 from v_rsq_f64 (measured seed error 2^-24.2) + one cubic Newton step
+// (error ~ e^3 -> ~1 ulp); no sqrt, no divide.  BS_NEWTON=2 is the quadratic step (3/8 e^2 ~ 4e-15 relative,
+// one FMA cheaper) kept as an A/B knob; the shipped build uses the cubic one.
+#ifndef BS_NEWTON
+#define BS_NEWTON 3
+#endif
 __device__ __forceinline__ double coef_fast(double nh2c, double q)
 {
     double y0 = __builtin_amdgcn_rsq(q);
     double t = q * y0;
     double e = __builtin_fma(-t, y0, 1.0);
+#if BS_NEWTON == 3
     double p = __builtin_fma(0.375, e, 0.5);
     double y1 = __builtin_fma(y0 * e, p, y0);
+#else
+    double y1 = __builtin_fma(y0 * e, 0.5, y0);
+#endif
     double y2 = y1 * y1;
     double y4 = y2 * y2;
     return (nh2c * y1) * y4;
@@ -644,9 +653,11 @@ __global__ void sqrt_div_kernel(const double *a, const double *b, size_t n, doub
     }
 }
 
-// Roofline probe: 8 independent dependency chains per lane of one FP64 VALU instruction kind.
-// kind 0: v_fma_f64   1: v_mul_f64   2: v_add_f64   3: v_rsq_f64   4: v_rcp_f64
-template <int KIND>
+// Roofline probe: NCH independent dependency chains per lane of one FP64 VALU instruction kind (32 instructions
+// per lane per trip).  kind 0: v_fma_f64   1: v_mul_f64   2: v_add_f64   3: v_rsq_f64   4: v_rcp_f64, 8 chains
+// (issue rate); kind 5/6/7: v_fma_f64 with 1/2/4 chains, kind 8: v_rsq_f64 with 1 chain (dependent latency when
+// launched at one wave per SIMD).
+template <int KIND, int NCH>
 __global__ __launch_bounds__(256) void ubench_kernel(double *out, int iters, double a, double b)
 {
     double x[8];
@@ -654,9 +665,9 @@ __global__ __launch_bounds__(256) void ubench_kernel(double *out, int iters, dou
     for (int i = 0; i < 8; i++) x[i] = 1.0 + 1e-3 * (threadIdx.x + i);
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 32 / NCH; u++) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < NCH; i++) {
                 if constexpr (KIND == 0) x[i] = __builtin_fma(x[i], a, b);
                 if constexpr (KIND == 1) x[i] = x[i] * a;
                 if constexpr (KIND == 2) x[i] = x[i] + b;
@@ -678,11 +689,15 @@ int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
     hipStream_t s = (hipStream_t)stream;
     dim3 g((unsigned)blocks), b(256);
     switch (kind) {
-    case 0: hipLaunchKernelGGL(ubench_kernel<0>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
-    case 1: hipLaunchKernelGGL(ubench_kernel<1>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
-    case 2: hipLaunchKernelGGL(ubench_kernel<2>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
-    case 3: hipLaunchKernelGGL(ubench_kernel<3>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
-    case 4: hipLaunchKernelGGL(ubench_kernel<4>, g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 0: hipLaunchKernelGGL((ubench_kernel<0, 8>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 1: hipLaunchKernelGGL((ubench_kernel<1, 8>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 2: hipLaunchKernelGGL((ubench_kernel<2, 8>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 3: hipLaunchKernelGGL((ubench_kernel<3, 8>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 4: hipLaunchKernelGGL((ubench_kernel<4, 8>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 5: hipLaunchKernelGGL((ubench_kernel<0, 1>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 6: hipLaunchKernelGGL((ubench_kernel<0, 2>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 7: hipLaunchKernelGGL((ubench_kernel<0, 4>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 8: hipLaunchKernelGGL((ubench_kernel<3, 1>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

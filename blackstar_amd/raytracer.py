@@ -36,6 +36,29 @@ def render_device(cfg, startree: StarTree, d_out_ptr: int, out_doubles: int, str
     _lib.check(_lib.lib().bs_render_device(startree.handle, C.byref(c), d_out_ptr, out_doubles, stream_ptr or None), "bs_render_device")
 
 
+def render_rgb8(cfg: Config, startree: StarTree) -> np.ndarray:
+    """doRender's pipeline (app/Main.hs:105-123) on the device: render, bloom if scene.bloomStrength /= 0, sRGB + 8-bit.
+    Returns (h, w, 3) uint8 -- what writeImg hands to the PNG encoder."""
+    c = _bs_config(cfg)
+    out = np.empty((c.height, c.width, 3), np.uint8)
+    _lib.check(_lib.lib().bs_render_rgb8(startree.handle, C.byref(c), float(cfg.scene.bloomStrength), int(cfg.scene.bloomDivider),
+                                         out.ctypes.data, out.size), "bs_render_rgb8")
+    return out
+
+
+def write_png(rgb8: np.ndarray, path: str) -> None:
+    """PNG-encode an (h, w, 3) uint8 image (host I/O; the reference uses JuicyPixels via massiv-io)."""
+    h, w, _ = rgb8.shape
+    raw = b"".join(b"\x00" + rgb8[y].tobytes() for y in range(h))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def trace_rays(cfg, startree: StarTree, ys, xs) -> np.ndarray:
     """Test hook: per-ray terminal records for traced-resolution pixels (ys, xs)."""
     c = _bs_config(cfg)
@@ -61,13 +84,4 @@ def to_word8(x: np.ndarray) -> np.ndarray:
 def write_img(img: np.ndarray, path: str, tree: StarTree = None) -> None:
     """writeImg (src/Raytracer.hs:29-32): sRGB transfer + 8-bit quantise (GPU, bs_srgb8), then PNG encoding."""
     from .image_filters import srgb8
-    rgb8 = srgb8(img, tree)
-    h, w, _ = rgb8.shape
-    raw = b"".join(b"\x00" + rgb8[y].tobytes() for y in range(h))
-
-    def chunk(tag: bytes, data: bytes) -> bytes:
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
-
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
-                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    write_png(srgb8(img, tree), path)

@@ -122,6 +122,11 @@ int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, 
 int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream);
 int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values); /* host buffers, blocking */
 
+/* Replaces: the body of doRender (app/Main.hs:105-123) up to the PNG encoder -- render, bloom when bloom_strength != 0,
+ * then writeImg's pixel map -- with the f64 image never leaving HBM: only height*width*3 BYTES come back (6.2 MB
+ * instead of 49.8 MB at 1080p).  Blocking.  out_rgb8: interleaved RGB8, row-major. */
+int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_rgb8, size_t out_bytes);
+
 /* Test hook: trace the given traced-resolution pixels (y,x pairs) and return per-ray records (host buffers). */
 int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out);
 
@@ -140,7 +145,8 @@ int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, d
 int bs_debug_set_disk_slots(bs_ctx *ctx, int slots);
 
 /* Roofline probe: times `iters` x 32 dependent-chain FP64 VALU instructions per lane (8 independent chains)
- * on `blocks` x 256 lanes.  kind 0 v_fma_f64, 1 v_mul_f64, 2 v_add_f64, 3 v_rsq_f64, 4 v_rcp_f64.
+ * on `blocks` x 256 lanes.  kind 0 v_fma_f64, 1 v_mul_f64, 2 v_add_f64, 3 v_rsq_f64, 4 v_rcp_f64 (8 chains:
+ * issue rate); 5/6/7 v_fma_f64 with 1/2/4 chains, 8 v_rsq_f64 with 1 chain (dependent latency at 1 wave/SIMD).
  * out_ginstr = lane-instructions executed / 1e9 (so rate = out_ginstr / out_ms * 1e3 Ginstr/s). */
 int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr);
 

@@ -346,3 +346,62 @@ def test_cpp_host_mirror(tmp_path, oracle):
     subprocess.check_call([str(exe), os.path.join(root, "tests", "golden", "catalogue_2000.ppm"), str(out), "bloom"])
     bl = np.fromfile(out, np.float64).reshape(54, 96, 3)
     assert np.array_equal(bl, oracle.bloom(0.15, 25, img))
+
+
+def test_render_rgb8_pipeline(tree, oracle, tmp_path):
+    """bs_render_rgb8 = doRender (app/Main.hs:105-123) minus the PNG encoder: must equal the composition of its parts."""
+    cfg = bs.Config.from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "default-aa.yaml")).with_resolution(160, 90)
+    got = bs.render_rgb8(cfg, tree)
+    img = bs.render(cfg, tree)
+    exp = oracle.srgb8(oracle.bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img))
+    d = np.abs(got.astype(int) - exp.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert got.max() > 100 and got.shape == (90, 160, 3)
+    cfg.scene.bloomStrength = 0.0  # no bloom branch
+    d = np.abs(bs.render_rgb8(cfg, tree).astype(int) - oracle.srgb8(img).astype(int))
+    assert d.max() <= 1
+    bs.write_png(got, str(tmp_path / "o.png"))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png")), got)
+
+
+EDGE_CASES = {
+    "camera_in_disk_plane_radial_centre_ray": dict(cam_pos=(0.0, 0.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 1.0, 0.0)),
+    "camera_inside_horizon": dict(cam_pos=(0.0, 0.5, 0.3)),
+    "camera_far_away_safe_distance_from_camera": dict(cam_pos=(0.0, 10.0, -100.0)),
+    "small_steps": dict(step_size=0.05),
+    "large_steps": dict(step_size=0.9),
+    "transparent_disk": dict(disk_opacity=0.0),
+    "opaque_wide_disk_inside_photon_sphere": dict(disk_opacity=1.0, disk_inner=1.01, disk_outer=30.0),
+    "narrow_fov": dict(fov=0.05),
+    "wide_fov_grey_stars": dict(fov=6.0, star_intensity=1.0, star_saturation=0.0),
+    "up_vector_parallel_to_view": dict(cam_pos=(0.0, 0.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 0.0, 1.0)),
+    "looking_away_from_the_hole": dict(cam_lookat=(0.0, 1.0, -40.0)),
+}
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_edge_case_scenes(case, mode, tree, oracle, oracle_index):
+    cfg = dict(scenes.with_res(scenes.DEFAULT_AA, 32, 18), **EDGE_CASES[case])
+    if case == "small_steps":
+        cfg = scenes.with_res(cfg, 16, 10)
+    ref, ost = oracle.render(cfg, oracle_index, threads=0, max_steps=20000)
+    tree.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+    tree.set_max_steps(20000)
+    try:
+        img = bs.render(cfg, tree)
+        st = tree.stats()
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+        tree.set_max_steps(100000)
+    finite = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(img), finite), "NaN/inf pattern differs from the oracle"
+    if mode == "strict":
+        assert (st["steps"], st["horizon"], st["escaped"], st["capped"], st["disk_hits"]) == \
+               (ost["steps"], ost["horizon"], ost["escaped"], ost["capped"], ost["disk_hits"])
+        assert (np.abs(img - ref)[finite] <= ATOL_STRICT + RTOL_STRICT * np.abs(ref[finite])).all()
+    else:
+        assert (st["horizon"], st["escaped"], st["capped"]) == (ost["horizon"], ost["escaped"], ost["capped"])
+        bad = np.abs(img - ref)[finite] > ATOL_FAST + RTOL_FAST * np.abs(ref[finite])
+        assert bad.sum() == 0, f"{bad.sum()} of {bad.size} values outside 1e-4 (max abs {np.abs(img - ref)[finite].max():.3e})"
