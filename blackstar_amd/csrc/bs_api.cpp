@@ -39,9 +39,12 @@ struct bs_ctx {
     int mode = BS_MODE_FAST;
     int max_steps = 100000;
     int disk_slots = 4;
+    int n_cu = 256;
+    int stagger_cycles = 16000;  // first-tile phase offset per SIMD slot (env BLACKSTAR_STAGGER overrides; 0 = off)
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;
     bs::StarColor *d_colors = nullptr;
+    double *d_splits = nullptr;
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;  // pinned
     double *d_img = nullptr;                   // scratch image for bs_render (host-output variant)
@@ -67,10 +70,17 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
     if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
     p.max_steps = ctx->max_steps;
     p.disk_slots = ctx->disk_slots;
+    {
+        const long tiles = (long)((p.wt + 7) / 8) * ((p.ht + 7) / 8);
+        const long waves = (long)ctx->n_cu * 16;  // 4 workgroups of 4 wavefronts per CU (VGPR/LDS-limited residency)
+        p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
+        p.stagger_cycles = tiles >= 8 * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs many tiles
+    }
     p.n_stars = (int32_t)ctx->n_stars;
     p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
+    p.splits = ctx->d_splits;
     p.counters = ctx->d_counters;
     return BS_OK;
 }
@@ -144,24 +154,32 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     if (!ctx) { fail(BS_ENOMEM, "out of host memory"); return nullptr; }
     ctx->device = device;
     ctx->n_stars = n_stars;
+    if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
     if (const char *m = std::getenv("BLACKSTAR_MODE")) {
         if (!std::strcmp(m, "fast")) ctx->mode = BS_MODE_FAST;
         else if (!std::strcmp(m, "strict")) ctx->mode = BS_MODE_STRICT;
     }
     std::vector<bs::StarNode> nodes;
     std::vector<bs::StarColor> colors;
-    bs::build_star_index(stars, n_stars, nodes, colors);
+    std::vector<double> splits;
+    bs::build_star_index(stars, n_stars, nodes, colors, splits);
     auto ok = [&](hipError_t r, const char *what) {
         if (r == hipSuccess) return true;
         fail(BS_EDEVICE, std::string(what) + ": " + hipGetErrorString(r));
         return false;
     };
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    }
     bool good = ok(hipSetDevice(device), "hipSetDevice") &&
                 ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
                 ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev1), "hipEventCreate") &&
                 ok(hipEventCreate(&ctx->ev2), "hipEventCreate") &&
                 ok(hipMalloc((void **)&ctx->d_nodes, nodes.size() * sizeof(bs::StarNode)), "hipMalloc nodes") &&
                 ok(hipMalloc((void **)&ctx->d_colors, colors.size() * sizeof(bs::StarColor)), "hipMalloc colors") &&
+                ok(hipMalloc((void **)&ctx->d_splits, splits.size() * sizeof(double)), "hipMalloc splits") &&
+                ok(hipMemcpy(ctx->d_splits, splits.data(), splits.size() * sizeof(double), hipMemcpyHostToDevice), "upload splits") &&
                 ok(hipMalloc((void **)&ctx->d_counters, bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
                 ok(hipHostMalloc((void **)&ctx->h_counters, bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
                 ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
@@ -182,6 +200,7 @@ void bs_destroy(bs_ctx *ctx)
         (void)hipDeviceSynchronize();
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
+        if (ctx->d_splits) (void)hipFree(ctx->d_splits);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_img) (void)hipFree(ctx->d_img);
         for (double *b : ctx->d_post)
@@ -425,6 +444,7 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
     p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
+    p.splits = ctx->d_splits;
     HIP_TRY(hipSetDevice(ctx->device));
     double *d = nullptr;
     int32_t *dh = nullptr;

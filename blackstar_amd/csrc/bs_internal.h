@@ -25,9 +25,13 @@ struct alignas(16) StarColor {
     double hue, sat;  // starColor' (StarMap.hs:61-72), indexed like StarNode
 };
 
-constexpr int kLdsLevels = 8;                       // top levels of the k-d array staged in LDS
-constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 255 nodes * 32 B = 8160 B per workgroup (LDS budget: 4 workgroups/CU with the per-lane scratch)
-constexpr int kCounters = 8;                        // steps, capped, horizon, escaped, disk_hits, star_hits
+// The traversal only ever needs a node's SPLIT coordinate (8 B); they live in their own Eytzinger-ordered f64
+// array (3.8 MB for 470 k stars -> resident in each XCD's 4 MB L2, where the 15 MB node array is not), and the
+// top kLdsLevels levels of it are staged in LDS.  The full 32-B node is read only when the query ball reaches
+// the node's splitting plane.
+constexpr int kLdsLevels = 10;                      // top levels of the split array staged in LDS
+constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 1023 splits * 8 B = 8184 B per workgroup (4 workgroups/CU with the per-lane scratch)
+constexpr int kCounters = 8;                        // steps, capped, horizon, escaped, disk_hits, star_hits, wave_iters, tile queue head
 
 // Everything the trace kernel needs, passed by value as the kernel argument (lands in SGPRs / kernarg).
 struct TraceParams {
@@ -49,8 +53,11 @@ struct TraceParams {
     int32_t max_steps;
     int32_t n_stars;
     int32_t lds_nodes;           // min(n_stars, kLdsNodes)
+    int32_t grid_blocks;         // persistent workgroups launched (<= 4 per CU)
+    int32_t stagger_cycles;      // first-tile phase offset per SIMD slot, in shader cycles (0 = off)
     int32_t disk_slots;          // LDS crossing-queue depth in use (<= 4; tests shrink it to force the overflow path)
     const StarNode *nodes;       // device, n_stars + 1 entries (entry 0 unused)
+    const double *splits;        // device, n_stars + 1 entries: the coordinate of node i along axis depth(i) % 3
     const StarColor *colors;     // device, n_stars + 1 entries
     double *out;                 // device, out_h * out_w * 3
     unsigned long long *counters;  // device, kCounters
@@ -62,7 +69,7 @@ void host_hsi_to_rgb(double hue, double s, double i, double rgb[3], bool *ok);
 bool derive_params(const bs_config &cfg, TraceParams &p, std::string &err);
 
 // star_index.cpp: build the 1-based Eytzinger left-balanced k-d array from the caller's stars.
-void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors);
+void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors, std::vector<double> &splits);
 
 // trace_kernel.hip launchers (enqueue on `stream`, no sync).
 int launch_trace(const TraceParams &p, int mode, void *stream);

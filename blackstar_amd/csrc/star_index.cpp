@@ -64,15 +64,23 @@ struct Builder {
 
 }  // namespace
 
-void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors)
+void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors, std::vector<double> &splits)
 {
     nodes.assign(n + 1, StarNode{0, 0, 0, 0, -1});
     colors.assign(n + 1, StarColor{0, 0});
+    splits.assign(n + 1, 0.0);
     if (n == 0) return;
     Builder b{stars, {}, &nodes, &colors};
     b.order.resize(n);
     std::iota(b.order.begin(), b.order.end(), 0u);
     b.build(1, 0, n, 0);
+    // split coordinate of node i = its point's coordinate along axis depth(i) % 3, depth(i) = floor(log2 i)
+    for (size_t i = 1; i <= n; i++) {
+        int depth = 0;
+        for (size_t t = i; t > 1; t >>= 1) depth++;
+        const StarNode &nd = nodes[i];
+        splits[i] = depth % 3 == 0 ? nd.x : (depth % 3 == 1 ? nd.y : nd.z);
+    }
 }
 
 }  // namespace bs

@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kBlock = 256;  // 4 wavefronts; each wavefront owns one 8x8 tile of traced pixels
 #ifndef BS_MIN_WAVES
-#define BS_MIN_WAVES 1  // __launch_bounds__ minimum waves per SIMD (tuning knob; see DESIGN.md "Occupancy")
+#define BS_MIN_WAVES 4  // __launch_bounds__ minimum waves per SIMD: 4 workgroups per CU is what the LDS budget admits
 #endif
 
 __device__ __forceinline__ double quadrance(double x, double y, double z) { return (x * x + y * y) + z * z; }
@@ -182,16 +182,42 @@ __device__ __forceinline__ void hsi_to_rgb(double hp, double s, double i, double
     b = k == 0 ? second : (k == 1 ? third : first);
 }
 
+// Per-star colour of starLookup's renderPixel (StarMap.hs:105-114), added to the running sum.
+__device__ __forceinline__ void add_star(const TraceParams &P, unsigned i, double d2, double &accR, double &accG, double &accB)
+{
+    const double w = 0.0005;
+    const double two_w2 = 2 * (w * w);
+    const int mag = P.nodes[i].mag;
+    const StarColor sc = P.colors[i];
+    double e = exp(P.star_a * (950.0 - (double)mag) - d2 / two_w2);
+    double m = (1.0 <= e) ? 1.0 : e;  // min 1
+    double val = m * P.star_intensity;
+    double cr, cg, cb;
+    hsi_to_rgb(sc.hue, P.star_saturation * sc.sat, val, cr, cg, cb);
+    accR = accR + cr; accG = accG + cg; accB = accB + cb;
+}
+
 // starLookup (StarMap.hs:93-115) over the flat k-d array.  Stackless depth-first traversal: `pending`
 // holds one bit per depth whose far child is still to be visited; the path itself is the node index.
 // Returns the number of stars within the radius; rgb = min 1 (sum of per-star colours).
-__device__ __forceinline__ int star_lookup(const TraceParams &P, const StarNode *lds_nodes, double vx, double vy, double vz, double &R,
-                                           double &G, double &B)
+//
+// What makes it cheap (it was 10 % of the frame, all of it VALU issue, none of it memory latency):
+//   * a visit reads only the node's SPLIT coordinate (8 B, from LDS for the top kLdsLevels levels, else from the
+//     L2-resident split array); the point itself can only be within the radius if it is within the radius
+//     along that axis, so the full 32-B node and the distance test are touched only when
+//     |q_axis - split| <= radius -- the same condition that makes the far child worth visiting;
+//   * hits (0.25 per lookup) are only RECORDED during the traversal (node index + d^2 into the lane's LDS
+//     column, in traversal order) and shaded afterwards -- exp, two cos, a divide, ~300 instructions that the
+//     wavefront would otherwise execute at every iteration in which any lane happens to hit.
+constexpr int kHitSlots = 5;  // per lane, in the snapshot/queue columns (free by the time the lookup runs)
+
+__device__ __forceinline__ int star_lookup(const TraceParams &P, const double *lds_splits, double *lane_col, double vx, double vy, double vz,
+                                           double &R, double &G, double &B)
 {
     const double w = 0.0005;
     const double radius = 3 * w;            // StarMap.hs:104  inRadius starmap (3 * w) nvel
     const double r2 = radius * radius;      // kdt: distSqr p q <= radius * radius
-    const double two_w2 = 2 * (w * w);
+    const double rpad = radius * (1.0 + 0x1p-40);  // gate for the exact test: d2 <= r2 implies |d_axis| <= rpad in FP too
     // linear.normalize: unchanged when |l| or |1-l| <= 1e-12
     double l = quadrance(vx, vy, vz);
     double nx = vx, ny = vy, nz = vz;
@@ -207,24 +233,25 @@ __device__ __forceinline__ int star_lookup(const TraceParams &P, const StarNode 
     int depth = 0, axis = 0;
     for (;;) {
         while (i <= n) {
-            StarNode nd = (i <= nl) ? lds_nodes[i - 1] : P.nodes[i];
-            double dx = nd.x - nx, dy = nd.y - ny, dz = nd.z - nz;  // qd pos nvel = quadrance (pos - nvel)
-            double d2 = quadrance(dx, dy, dz);
-            if (d2 <= r2) {
-                StarColor sc = P.colors[i];
-                double e = exp(P.star_a * (950.0 - (double)nd.mag) - d2 / two_w2);
-                double m = (1.0 <= e) ? 1.0 : e;  // min 1
-                double val = m * P.star_intensity;
-                double cr, cg, cb;
-                hsi_to_rgb(sc.hue, P.star_saturation * sc.sat, val, cr, cg, cb);
-                accR = accR + cr; accG = accG + cg; accB = accB + cb;
-                hits++;
+            const double sa = (i <= nl) ? lds_splits[i - 1] : P.splits[i];
+            const double qa = axis == 0 ? nx : (axis == 1 ? ny : nz);
+            const double diff = qa - sa;
+            if (fabs(diff) <= rpad) {
+                pending |= 1u << (depth + 1);  // the far child intersects the ball
+                const StarNode nd = P.nodes[i];
+                double dx = nd.x - nx, dy = nd.y - ny, dz = nd.z - nz;  // qd pos nvel = quadrance (pos - nvel)
+                double d2 = quadrance(dx, dy, dz);
+                if (d2 <= r2) {
+                    if (hits < kHitSlots) {
+                        lane_col[hits * kBlock] = d2;
+                        lane_col[(kHitSlots + hits) * kBlock] = (double)i;
+                    } else {
+                        add_star(P, i, d2, accR, accG, accB);  // more hits than slots: shade in place
+                    }
+                    hits++;
+                }
             }
-            double qa = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            double sa = axis == 0 ? nd.x : (axis == 1 ? nd.y : nd.z);
-            double diff = qa - sa;
-            if (fabs(diff) <= radius) pending |= 1u << (depth + 1);  // far child intersects the ball
-            i = 2 * i + (diff <= 0 ? 0u : 1u);                        // near child
+            i = 2 * i + (diff <= 0 ? 0u : 1u);  // near child
             depth++;
             axis = (axis == 2) ? 0 : axis + 1;
         }
@@ -235,6 +262,8 @@ __device__ __forceinline__ int star_lookup(const TraceParams &P, const StarNode 
         depth = dd;
         axis = dd % 3;
     }
+    const int queued = hits < kHitSlots ? hits : kHitSlots;
+    for (int k = 0; k < queued; k++) add_star(P, (unsigned)lane_col[(kHitSlots + k) * kBlock], lane_col[k * kBlock], accR, accG, accB);
     R = (1.0 <= accR) ? 1.0 : accR;  // fmap (min 1)
     G = (1.0 <= accG) ? 1.0 : accG;
     B = (1.0 <= accB) ? 1.0 : accB;
@@ -290,6 +319,7 @@ __device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int x
 constexpr int kDiskSlots = 4;
 constexpr int kSnapDoubles = 7;  // STRICT: vel[3], pos[3], r2; FAST: x, y, vx, vy, r2
 constexpr int kLaneLdsDoubles = (kSnapDoubles + kDiskSlots) * kBlock;
+static_assert(kSnapDoubles + kDiskSlots >= 2 * kHitSlots, "the star-hit queue reuses the lane columns");
 
 struct LaneLds {
     double *col;  // this lane's column: col[word * kBlock]
@@ -325,7 +355,7 @@ __device__ __forceinline__ bool record_crossing(const TraceParams &P, const Lane
 }
 
 // The terminal `Bottom` layer of colorize (:84, :93-95) under whatever the disk left transparent.
-__device__ __forceinline__ int finish_ray(const TraceParams &P, const StarNode *lds_nodes, int fate, const double v[3], double rgba[4])
+__device__ __forceinline__ int finish_ray(const TraceParams &P, const double *lds_splits, double *lane_col, int fate, const double v[3], double rgba[4])
 {
     int star_hits = 0;
     if (fate == 0) {  // Bottom (PixelRGBA 0 0 0 1)
@@ -334,7 +364,7 @@ __device__ __forceinline__ int finish_ray(const TraceParams &P, const StarNode *
         rgba[3] = rgba[3] + 1.0 * om;
     } else if (fate == 1) {  // Bottom . addAlpha 1 $ starLookup ... vel   (the PRE-step vel, :94-95)
         double sr, sg, sb;
-        star_hits = star_lookup(P, lds_nodes, v[0], v[1], v[2], sr, sg, sb);
+        star_hits = star_lookup(P, lds_splits, lane_col, v[0], v[1], v[2], sr, sg, sb);
         double om = 1 - rgba[3];
         rgba[0] = rgba[0] + sr * om; rgba[1] = rgba[1] + sg * om; rgba[2] = rgba[2] + sb * om;
         rgba[3] = rgba[3] + 1.0 * om;
@@ -409,7 +439,7 @@ __device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, i
 // register and a lane's step count (iterations of colorize', :80-86) is simply its value when the lane's
 // guard fires.  See "per-lane LDS scratch" above for why the loop looks the way it does.
 template <bool FAST>
-__device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *lds_nodes, const LaneLds &lds, bool live, int yi, int xi,
+__device__ __forceinline__ void trace_ray(const TraceParams &P, const double *lds_splits, const LaneLds &lds, bool live, int yi, int xi,
                                           RayResult &res, unsigned &wave_iters)
 {
     double v[3], p[3];
@@ -506,18 +536,18 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const StarNode *
         for (int i = 0; i < 4; i++) rgba[i] = out[6 + i];
         steps = iout[0]; fate = iout[1]; ncross = iout[2];
     }
-    int star_hits = finish_ray(P, lds_nodes, fate, v, rgba);
+    int star_hits = finish_ray(P, lds_splits, lds.col, fate, v, rgba);
 #pragma unroll
     for (int i = 0; i < 3; i++) { res.vel[i] = v[i]; res.pos[i] = p[i]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) res.rgba[i] = rgba[i];
     res.steps = steps; res.fate = fate; res.disk_hits = ncross; res.star_hits = star_hits;
-    wave_iters = (unsigned)it;
+    wave_iters = (unsigned)it + 1u;  // iterations entered, including the one in which the last guards fired
 }
 
-__device__ __forceinline__ void stage_tree(const TraceParams &P, StarNode *s_nodes)
+__device__ __forceinline__ void stage_tree(const TraceParams &P, double *s_splits)
 {
-    for (int k = threadIdx.x; k < P.lds_nodes; k += kBlock) s_nodes[k] = P.nodes[k + 1];
+    for (int k = threadIdx.x; k < P.lds_nodes; k += kBlock) s_splits[k] = P.splits[k + 1];
     __syncthreads();
 }
 
@@ -528,23 +558,29 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
     return v;
 }
 
-// Frame kernel.  grid = (ceil(wt/16), ceil(ht/16)); block = 256 = 2x2 wavefront tiles of 8x8 traced pixels.
-// With supersampling the four rays of an output pixel sit in four adjacent lanes (quad), in the order
+// Frame kernel: PERSISTENT wavefronts.  The grid is sized to fill the chip once (P.grid_blocks workgroups of 4
+// wavefronts, <= 4 per CU); each workgroup stages the top of the split array in LDS once, then every wavefront
+// independently pulls 8x8-pixel tiles of traced rays off a device-wide counter until the frame is done -- no
+// workgroup barrier after the prologue, no per-tile dispatch, one flush of the statistics per wavefront.
+// With supersampling the four rays of an output pixel sit in four adjacent lanes (a quad), in the order
 // p(2y,2x), p(2y+1,2x), p(2y,2x+1), p(2y+1,2x+1) of ImageFilters.hs:94-96, and are reduced with lane
-// shuffles so only the h x w image is ever written.
+// shuffles, so only the h x w image is ever written.
+//
+// Why stagger: every tile costs nearly the same (lane efficiency 0.9987; step counts vary by a few percent
+// across the frame), so wavefronts that start together stay in phase and all four waves of a SIMD reach
+// their latency-bound tail (k-d lookup, shading, image write, next tile's setup) at the same time, leaving the
+// f64 pipe idle (PMC: VALU busy 91 % with stars vs 96 % without).  Delaying the first tile of the wave in
+// SIMD slot k by k/4 of a tile time keeps the four phases apart for the rest of the frame.
 template <bool FAST>
 __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const TraceParams P)
 {
-    __shared__ StarNode s_nodes[kLdsNodes];
+    __shared__ double s_nodes[kLdsNodes];
     __shared__ double s_lane[kLaneLdsDoubles];
     __shared__ int s_ints[2 * kBlock];
     stage_tree(P, s_nodes);
     const LaneLds lds(s_lane, s_ints);
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int tx = blockIdx.x * 16 + (wave & 1) * 8;
-    const int ty = blockIdx.y * 16 + (wave >> 1) * 8;
     int lx, ly;
     if (P.ss) {
         int q = lane >> 2, sub = lane & 3;
@@ -554,44 +590,61 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         lx = lane & 7;
         ly = lane >> 3;
     }
-    const int xi = tx + lx, yi = ty + ly;
-    const bool inb = xi < P.wt && yi < P.ht;
+    const int tiles_x = (P.wt + 7) >> 3;
+    const int n_tiles = tiles_x * ((P.ht + 7) >> 3);
 
-    RayResult res;
-    unsigned w_iters;  // iterations the wavefront ran (= the step count of its slowest lane)
-    trace_ray<FAST>(P, s_nodes, lds, inb, yi, xi, res, w_iters);
-
-    if (P.ss) {
-        const int base = lane & ~3;
-        double o[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double a = __shfl(res.rgba[c], base + 0, 64);
-            double b = __shfl(res.rgba[c], base + 1, 64);
-            double cc = __shfl(res.rgba[c], base + 2, 64);
-            double dd = __shfl(res.rgba[c], base + 3, 64);
-            o[c] = 0.25 * (((a + b) + cc) + dd);
-        }
-        if (inb && (lane & 3) == 0) {
-            double *dst = P.out + ((size_t)(yi >> 1) * P.out_w + (xi >> 1)) * 3;
-            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
-        }
-    } else if (inb) {
-        double *dst = P.out + ((size_t)yi * P.out_w + xi) * 3;
-        dst[0] = res.rgba[0]; dst[1] = res.rgba[1]; dst[2] = res.rgba[2];  // dropAlpha
+    // phase stagger (performance only): workgroups b, b+256, b+512, b+768 are the ones observed to share a CU
+    if (P.stagger_cycles > 0) {
+        const int slot = (int)((blockIdx.x >> 8) & 3u);
+        for (int c = 0; c < slot * P.stagger_cycles; c += 64 * 100) __builtin_amdgcn_s_sleep(100);
     }
 
-    unsigned s_steps = wave_sum((unsigned)res.steps);
-    w_iters = (unsigned)res.steps;  // iterations the wavefront ran = the step count of its slowest lane
+    unsigned a_steps = 0, a_cap = 0, a_hor = 0, a_esc = 0, a_disk = 0, a_star = 0;  // per-lane, summed over this wave's tiles
+    unsigned long long a_iters = 0;                                                  // wave-uniform
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = (int)atomicAdd(&P.counters[7], 1ull);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= n_tiles) break;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int xi = tx * 8 + lx, yi = ty * 8 + ly;
+        const bool inb = xi < P.wt && yi < P.ht;
+
+        RayResult res;
+        unsigned w_iters;
+        trace_ray<FAST>(P, s_nodes, lds, inb, yi, xi, res, w_iters);
+
+        if (P.ss) {
+            const int base = lane & ~3;
+            double o[3];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) w_iters = max(w_iters, (unsigned)__shfl_xor(w_iters, o, 64));
-    unsigned s_cap = wave_sum(res.fate == 2 ? 1u : 0u);
-    unsigned s_hor = wave_sum(res.fate == 0 ? 1u : 0u);
-    unsigned s_esc = wave_sum(res.fate == 1 ? 1u : 0u);
-    unsigned s_disk = wave_sum((unsigned)res.disk_hits);
-    unsigned s_star = wave_sum((unsigned)res.star_hits);
+            for (int c = 0; c < 3; c++) {
+                double a = __shfl(res.rgba[c], base + 0, 64);
+                double b = __shfl(res.rgba[c], base + 1, 64);
+                double cc = __shfl(res.rgba[c], base + 2, 64);
+                double dd = __shfl(res.rgba[c], base + 3, 64);
+                o[c] = 0.25 * (((a + b) + cc) + dd);
+            }
+            if (inb && (lane & 3) == 0) {
+                double *dst = P.out + ((size_t)(yi >> 1) * P.out_w + (xi >> 1)) * 3;
+                dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+            }
+        } else if (inb) {
+            double *dst = P.out + ((size_t)yi * P.out_w + xi) * 3;
+            dst[0] = res.rgba[0]; dst[1] = res.rgba[1]; dst[2] = res.rgba[2];  // dropAlpha
+        }
+        a_steps += (unsigned)res.steps;
+        a_cap += res.fate == 2 ? 1u : 0u;
+        a_hor += res.fate == 0 ? 1u : 0u;
+        a_esc += res.fate == 1 ? 1u : 0u;
+        a_disk += (unsigned)res.disk_hits;
+        a_star += (unsigned)res.star_hits;
+        a_iters += w_iters;
+    }
+    const unsigned s_steps = wave_sum(a_steps), s_cap = wave_sum(a_cap), s_hor = wave_sum(a_hor), s_esc = wave_sum(a_esc),
+                   s_disk = wave_sum(a_disk), s_star = wave_sum(a_star);
     if (lane == 0) {
-        atomicAdd(&P.counters[6], (unsigned long long)w_iters);
+        atomicAdd(&P.counters[6], a_iters);
         atomicAdd(&P.counters[0], (unsigned long long)s_steps);
         if (s_cap) atomicAdd(&P.counters[1], (unsigned long long)s_cap);
         if (s_hor) atomicAdd(&P.counters[2], (unsigned long long)s_hor);
@@ -605,7 +658,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 template <bool FAST>
 __global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams P, const int32_t *yx, size_t n_rays, bs_ray_record *out)
 {
-    __shared__ StarNode s_nodes[kLdsNodes];
+    __shared__ double s_nodes[kLdsNodes];
     __shared__ double s_lane[kLaneLdsDoubles];
     __shared__ int s_ints[2 * kBlock];
     stage_tree(P, s_nodes);
@@ -626,12 +679,13 @@ __global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams
 // starLookup over a batch of directions (same device function as the trace kernel's escape branch).
 __global__ __launch_bounds__(kBlock) void star_lookup_kernel(const TraceParams P, const double *dirs, size_t n, double *rgb, int32_t *hits)
 {
-    __shared__ StarNode s_nodes[kLdsNodes];
+    __shared__ double s_nodes[kLdsNodes];
+    __shared__ double s_lane[2 * kHitSlots * kBlock];
     stage_tree(P, s_nodes);
     size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
     double r, g, b;
-    int h = star_lookup(P, s_nodes, dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2], r, g, b);
+    int h = star_lookup(P, s_nodes, s_lane + threadIdx.x, dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2], r, g, b);
     rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b;
     if (hits) hits[k] = h;
 }
@@ -705,7 +759,7 @@ int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
 
 int launch_trace(const TraceParams &p, int mode, void *stream)
 {
-    dim3 grid((unsigned)((p.wt + 15) / 16), (unsigned)((p.ht + 15) / 16));
+    dim3 grid((unsigned)p.grid_blocks);
     hipStream_t s = (hipStream_t)stream;
     if (mode == BS_MODE_FAST) hipLaunchKernelGGL(trace_frame_kernel<true>, grid, dim3(kBlock), 0, s, p);
     else hipLaunchKernelGGL(trace_frame_kernel<false>, grid, dim3(kBlock), 0, s, p);
