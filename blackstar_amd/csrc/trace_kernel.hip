@@ -577,6 +577,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     __shared__ double s_nodes[kLdsNodes];
     __shared__ double s_lane[kLaneLdsDoubles];
     __shared__ int s_ints[2 * kBlock];
+    __shared__ unsigned s_stats[6 * kBlock];
     stage_tree(P, s_nodes);
     const LaneLds lds(s_lane, s_ints);
 
@@ -599,8 +600,11 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         for (int c = 0; c < slot * P.stagger_cycles; c += 64 * 100) __builtin_amdgcn_s_sleep(100);
     }
 
-    unsigned a_steps = 0, a_cap = 0, a_hor = 0, a_esc = 0, a_disk = 0, a_star = 0;  // per-lane, summed over this wave's tiles
-    unsigned long long a_iters = 0;                                                  // wave-uniform
+    // per-lane statistics summed over this wave's tiles live in LDS (six more registers held across trace_ray spill)
+    unsigned *stat = reinterpret_cast<unsigned *>(s_stats) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 6; k++) stat[k * kBlock] = 0u;
+    unsigned long long a_iters = 0;  // wave-uniform
     for (;;) {
         int tile = 0;
         if (lane == 0) tile = (int)atomicAdd(&P.counters[7], 1ull);
@@ -633,16 +637,16 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
             double *dst = P.out + ((size_t)yi * P.out_w + xi) * 3;
             dst[0] = res.rgba[0]; dst[1] = res.rgba[1]; dst[2] = res.rgba[2];  // dropAlpha
         }
-        a_steps += (unsigned)res.steps;
-        a_cap += res.fate == 2 ? 1u : 0u;
-        a_hor += res.fate == 0 ? 1u : 0u;
-        a_esc += res.fate == 1 ? 1u : 0u;
-        a_disk += (unsigned)res.disk_hits;
-        a_star += (unsigned)res.star_hits;
+        stat[0 * kBlock] += (unsigned)res.steps;
+        stat[1 * kBlock] += res.fate == 2 ? 1u : 0u;
+        stat[2 * kBlock] += res.fate == 0 ? 1u : 0u;
+        stat[3 * kBlock] += res.fate == 1 ? 1u : 0u;
+        stat[4 * kBlock] += (unsigned)res.disk_hits;
+        stat[5 * kBlock] += (unsigned)res.star_hits;
         a_iters += w_iters;
     }
-    const unsigned s_steps = wave_sum(a_steps), s_cap = wave_sum(a_cap), s_hor = wave_sum(a_hor), s_esc = wave_sum(a_esc),
-                   s_disk = wave_sum(a_disk), s_star = wave_sum(a_star);
+    const unsigned s_steps = wave_sum(stat[0 * kBlock]), s_cap = wave_sum(stat[1 * kBlock]), s_hor = wave_sum(stat[2 * kBlock]),
+                   s_esc = wave_sum(stat[3 * kBlock]), s_disk = wave_sum(stat[4 * kBlock]), s_star = wave_sum(stat[5 * kBlock]);
     if (lane == 0) {
         atomicAdd(&P.counters[6], a_iters);
         atomicAdd(&P.counters[0], (unsigned long long)s_steps);
