@@ -23,7 +23,7 @@ namespace {
 // fully coalesced 512-B wave access.  The chain itself is sequential by definition (a running sum), so the
 // only latency hiding is memory-level: the next kUnroll leading / trailing samples are fetched ahead of the
 // add-subtract chain that consumes them.
-constexpr int kUnroll = 8;
+constexpr int kUnroll = 16;
 
 __global__ __launch_bounds__(64) void box_blur_sweep(const double *__restrict__ in, double *__restrict__ out, int chains, int n, int r, double norm)
 {
