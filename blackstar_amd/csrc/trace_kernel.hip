@@ -7,8 +7,8 @@
 //
 // The path is scalar FP64 ODE work: ~145 flop per RK4 step per ray against <= 24 B written per ray, so the
 // bound is the FP64 VALU issue rate (v_fma_f64 / v_mul_f64 / v_add_f64 at 16 lanes/clk/SIMD), not HBM and
-// not MFMA (there is no dense contraction to feed a matrix core).  State (vel, pos), h^2 and the RGBA
-// accumulator live in VGPRs for the whole ray; nothing is spilled or re-read.
+// not MFMA (there is no dense contraction to feed a matrix core).  The ray state lives in VGPRs for the whole
+// ray; the stepping loop touches no memory at all (rare per-lane events go to LDS, see "per-lane LDS scratch").
 //
 // This translation unit is compiled with -ffp-contract=off: STRICT mode is one IEEE binary64 operation
 // per reference operation in the reference's order (f64 sqrt and / lower to correctly rounded sequences),
@@ -21,15 +21,16 @@
 namespace bs {
 namespace {
 
-constexpr int kBlock = 256;  // 4 wavefronts; each wavefront owns one 8x8 tile of traced pixels
+constexpr int kBlock = 256;  // 4 wavefronts per workgroup; each wavefront traces one 8x8 tile of traced pixels at a time
 #ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 4  // __launch_bounds__ minimum waves per SIMD: 4 workgroups per CU is what the LDS budget admits
 #endif
 
 __device__ __forceinline__ double quadrance(double x, double y, double z) { return (x * x + y * y) + z * z; }
 
-// Wave-level predicates straight from the lane mask (HIP's __ballot/__any take an int and cost a
-// v_cndmask + v_cmp round trip per call; these compile to the SGPR mask the compare already produced).
+// Wave-level "any": the ballot builtin on a bool (HIP's __any/__ballot take an int, which always costs a
+// v_cndmask + v_cmp round trip; this form is free when the operand is a fresh compare, and costs that same pair
+// only when it is a loop-carried mask).
 __device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
