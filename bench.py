@@ -86,9 +86,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # BLACKSTAR_BENCH_BACKEND=gloo lets the multi-process path be smoke-tested on a ONE-GPU box (ranks share device 0,
+    # the gather goes through host memory); the real run is one rank per GPU over RCCL.
+    backend = os.environ.get("BLACKSTAR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg_obj = bs.Config.from_file(os.path.join(ROOT, "scenes", "default-aa.yaml"))
     cfg = cfg_obj.to_bs_config()
@@ -109,8 +117,9 @@ def main():
         torch.cuda.synchronize()
 
     def gather_to_root():  # the only collective: each rank's finished frame goes to rank 0 over xGMI
-        gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
-        dist.gather(out, gathered, dst=0)
+        src = out if backend == "nccl" else out.cpu()
+        gathered = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+        dist.gather(src, gathered, dst=0)
         return gathered
 
     for _ in range(args.warmup):
@@ -132,7 +141,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # per launch incl. the 64-B counter memset/copy nodes
 
     if world > 1:
-        tdt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tdt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
 
