@@ -274,7 +274,7 @@ def L_mode(tree):
 
 
 def test_c3_c4_full_size_properties(oracle):
-    """BASELINE configs[2], [3] at full size through size-independent properties: sampled rays bit-exact vs the
+    """BASELINE configs[2], [3] and the first / last frame of configs[4] at full size through size-independent properties: sampled rays bit-exact vs the
     oracle, FAST vs STRICT within the north_star tolerance on every pixel, equal step checksums."""
     stars = bs.read_map(synthetic.ppm_catalogue_bytes())
     t = bs.StarTree(stars)
@@ -282,7 +282,7 @@ def test_c3_c4_full_size_properties(oracle):
     t.set_mode(_lib.BS_MODE_STRICT)
     ix = oracle.Index(oracle.read_ppm(synthetic.ppm_catalogue_bytes()))
     rng = np.random.default_rng(2026)
-    for cfg in (scenes.DEFAULT_AA, scenes.with_res(scenes.LENSING_DISK, 3840, 2160)):
+    for cfg in (scenes.DEFAULT_AA, scenes.with_res(scenes.LENSING_DISK, 3840, 2160), scenes.ani_frame(0, 600), scenes.ani_frame(599, 600)):
         wt, ht = 2 * cfg["width"], 2 * cfg["height"]
         ys, xs = rng.integers(0, ht, 4096), rng.integers(0, wt, 4096)
         rec = bs.trace_rays(cfg, t, ys, xs)
