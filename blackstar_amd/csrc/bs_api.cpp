@@ -40,6 +40,7 @@ struct bs_ctx {
     int max_steps = 100000;
     int disk_slots = 4;
     int n_cu = 256;
+    int blocks_per_cu = 4;       // resident workgroups per CU (VGPR/LDS-limited); env BLACKSTAR_BLOCKS_PER_CU for A/B builds
     int stagger_cycles = 16000;  // first-tile phase offset per SIMD slot (env BLACKSTAR_STAGGER overrides; 0 = off)
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;
@@ -72,7 +73,8 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
     p.disk_slots = ctx->disk_slots;
     {
         const long tiles = (long)((p.wt + 7) / 8) * ((p.ht + 7) / 8);
-        const long waves = (long)ctx->n_cu * 16;  // 4 workgroups of 4 wavefronts per CU (VGPR/LDS-limited residency)
+        const long waves = (long)ctx->n_cu * 4 * ctx->blocks_per_cu;  // resident wavefronts: blocks_per_cu workgroups of 4 per CU
+        p.blocks_per_slot = ctx->n_cu;
         p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
         p.stagger_cycles = tiles >= 8 * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs many tiles
     }
@@ -155,6 +157,7 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     ctx->device = device;
     ctx->n_stars = n_stars;
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
+    if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_MODE")) {
         if (!std::strcmp(m, "fast")) ctx->mode = BS_MODE_FAST;
         else if (!std::strcmp(m, "strict")) ctx->mode = BS_MODE_STRICT;

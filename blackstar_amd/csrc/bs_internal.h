@@ -29,7 +29,10 @@ struct alignas(16) StarColor {
 // array (3.8 MB for 470 k stars -> resident in each XCD's 4 MB L2, where the 15 MB node array is not), and the
 // top kLdsLevels levels of it are staged in LDS.  The full 32-B node is read only when the query ball reaches
 // the node's splitting plane.
-constexpr int kLdsLevels = 10;                      // top levels of the split array staged in LDS
+#ifndef BS_LDS_LEVELS
+#define BS_LDS_LEVELS 10
+#endif
+constexpr int kLdsLevels = BS_LDS_LEVELS;                      // top levels of the split array staged in LDS
 constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 1023 splits * 8 B = 8184 B per workgroup (4 workgroups/CU with the per-lane scratch)
 constexpr int kCounters = 8;                        // steps, capped, horizon, escaped, disk_hits, star_hits, wave_iters, tile queue head
 
@@ -55,6 +58,7 @@ struct TraceParams {
     int32_t lds_nodes;           // min(n_stars, kLdsNodes)
     int32_t grid_blocks;         // persistent workgroups launched (<= 4 per CU)
     int32_t stagger_cycles;      // first-tile phase offset per SIMD slot, in shader cycles (0 = off)
+    int32_t blocks_per_slot;     // workgroups per residency slot (= CUs): workgroup b sits in slot b / blocks_per_slot
     int32_t disk_slots;          // LDS crossing-queue depth in use (<= 4; tests shrink it to force the overflow path)
     const StarNode *nodes;       // device, n_stars + 1 entries (entry 0 unused)
     const double *splits;        // device, n_stars + 1 entries: the coordinate of node i along axis depth(i) % 3

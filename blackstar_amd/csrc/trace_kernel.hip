@@ -33,6 +33,13 @@ __device__ __forceinline__ double quadrance(double x, double y, double z) { retu
 // only when it is a loop-carried mask).
 __device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 
+// libm calls as REAL calls.  ocml's f64 sin / cos / exp carry a large-argument (Payne-Hanek) path that is never taken
+// here but costs ~30 VGPRs wherever it is inlined; the shading code sits outside the stepping loop, so a call is
+// free and keeps the kernel at <= 111 VGPRs with no scratch.
+__device__ __noinline__ double cos_call(double x) { return cos(x); }
+__device__ __noinline__ double sin_call(double x) { return sin(x); }
+__device__ __noinline__ double exp_call(double x) { return exp(x); }
+
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
 __device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 
@@ -176,7 +183,7 @@ __device__ __forceinline__ void hsi_to_rgb(double hp, double s, double i, double
     const int k = (h < 2 * pi / 3) ? 0 : ((h < 4 * pi / 3) ? 1 : 2);
     double a = k == 0 ? h : (k == 1 ? h - 2 * pi / 3 : h - 4 * pi / 3);
     double bb = k == 0 ? pi / 3 - h : (k == 1 ? h + pi : 2 * pi - pi / 3 - h);
-    double first = i + is * cos(a) / cos(bb);
+    double first = i + is * cos_call(a) / cos_call(bb);
     double third = i + 2 * is + second - first;
     r = k == 0 ? first : (k == 1 ? second : third);
     g = k == 0 ? third : (k == 1 ? first : second);
@@ -190,7 +197,7 @@ __device__ __forceinline__ void add_star(const TraceParams &P, unsigned i, doubl
     const double two_w2 = 2 * (w * w);
     const int mag = P.nodes[i].mag;
     const StarColor sc = P.colors[i];
-    double e = exp(P.star_a * (950.0 - (double)mag) - d2 / two_w2);
+    double e = exp_call(P.star_a * (950.0 - (double)mag) - d2 / two_w2);
     double m = (1.0 <= e) ? 1.0 : e;  // min 1
     double val = m * P.star_intensity;
     double cr, cg, cb;
@@ -210,7 +217,10 @@ __device__ __forceinline__ void add_star(const TraceParams &P, unsigned i, doubl
 //   * hits (0.25 per lookup) are only RECORDED during the traversal (node index + d^2 into the lane's LDS
 //     column, in traversal order) and shaded afterwards -- exp, two cos, a divide, ~300 instructions that the
 //     wavefront would otherwise execute at every iteration in which any lane happens to hit.
-constexpr int kHitSlots = 5;  // per lane, in the snapshot/queue columns (free by the time the lookup runs)
+#ifndef BS_HIT_SLOTS
+#define BS_HIT_SLOTS 5
+#endif
+constexpr int kHitSlots = BS_HIT_SLOTS;  // per lane, in the snapshot/queue columns (free by the time the lookup runs)
 
 __device__ __forceinline__ int star_lookup(const TraceParams &P, const double *lds_splits, double *lane_col, double vx, double vy, double vz,
                                            double &R, double &G, double &B)
@@ -282,7 +292,7 @@ __device__ __forceinline__ void shade_disk(const TraceParams &P, double r2ave, d
     const double pi = 3.141592653589793;
     double r = __builtin_sqrt(r2ave);
     double t = (P.rO - r) / (P.rO - P.rI);
-    double inten = sin(pi * (t * t));
+    double inten = sin_call(pi * (t * t));
     double om = 1 - rgba[3];  // top + layer * (1 - top_alpha), all four channels
     rgba[0] = rgba[0] + (P.disk_rgb[0] * inten) * om;
     rgba[1] = rgba[1] + (P.disk_rgb[1] * inten) * om;
@@ -318,7 +328,10 @@ __device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int x
 // updates the state in place.  The code after the loop reloads everything from LDS.
 // Layout: [word][thread] -- consecutive lanes touch consecutive 8-byte words: conflict-free.
 constexpr int kDiskSlots = 4;
-constexpr int kSnapDoubles = 7;  // STRICT: vel[3], pos[3], r2; FAST: x, y, vx, vy, r2
+#ifndef BS_SNAP
+#define BS_SNAP 7
+#endif
+constexpr int kSnapDoubles = BS_SNAP;  // STRICT: vel[3], pos[3], r2; FAST: x, y, vx, vy, r2
 constexpr int kLaneLdsDoubles = (kSnapDoubles + kDiskSlots) * kBlock;
 static_assert(kSnapDoubles + kDiskSlots >= 2 * kHitSlots, "the star-hit queue reuses the lane columns");
 
@@ -595,9 +608,9 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     const int tiles_x = (P.wt + 7) >> 3;
     const int n_tiles = tiles_x * ((P.ht + 7) >> 3);
 
-    // phase stagger (performance only): workgroups b, b+256, b+512, b+768 are the ones observed to share a CU
+    // phase stagger (performance only): workgroups b, b+#CU, b+2#CU, ... are the ones observed to share a CU
     if (P.stagger_cycles > 0) {
-        const int slot = (int)((blockIdx.x >> 8) & 3u);
+        const int slot = (int)(blockIdx.x / (unsigned)P.blocks_per_slot);
         for (int c = 0; c < slot * P.stagger_cycles; c += 64 * 100) __builtin_amdgcn_s_sleep(100);
     }
 
