@@ -51,6 +51,7 @@ def oracle_index_empty(oracle):
     return oracle.Index(None)
 
 
+C1_SUMMARY = "summary_c1_default_640x480"
 IMAGE_GOLDENS = ["c2_default_96x54_nostars", "c3_default_aa_96x54", "c4_lensing_disk_96x54", "c5_ani_frame300_80x45",
                  "odd_default_aa_37x23"]
 TRACE_GOLDENS = ["c1", "c2", "c3", "c4", "c5_f0", "c5_f599"]

@@ -97,5 +97,24 @@ def main():
         print(name, len(ys), rec["steps"].mean(), np.bincount(rec["fate"]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--c1" not in sys.argv:
     main()
+
+
+def c1_summary():
+    """BASELINE configs[0]: default.yaml at 640x480, no supersampling, full frame -- summary statistics and a 24x32 grid of
+    sampled pixels (the full image is 7 MB; the per-ray traces of trace_c1.npz cover individual rays)."""
+    cat = open(os.path.join(HERE, "catalogue_2000.ppm"), "rb").read()
+    stars = parse_catalogue(cat)
+    cfg = scenes.with_res(scenes.DEFAULT, 640, 480)
+    img, rec = no.render(cfg, stars)
+    ys, xs = np.meshgrid(np.arange(10, 480, 20), np.arange(10, 640, 20), indexing="ij")
+    np.savez_compressed(os.path.join(HERE, "summary_c1_default_640x480.npz"), cfg=json.dumps(cfg), total_steps=np.int64(rec["steps"].sum()),
+                        fate_counts=np.bincount(rec["fate"], minlength=3), disk_hits=np.int64(rec["disk_hits"].sum()),
+                        star_hits=np.int64(rec["star_hits"].sum()), ys=ys.ravel(), xs=xs.ravel(), samples=img[ys.ravel(), xs.ravel()],
+                        channel_sums=img.reshape(-1, 3).sum(axis=0), max_steps=np.int64(rec["steps"].max()))
+    print("c1", img.shape, int(rec["steps"].sum()), rec["steps"].mean())
+
+
+if __name__ == "__main__" and "--c1" in sys.argv:
+    c1_summary()

@@ -405,3 +405,14 @@ def test_edge_case_scenes(case, mode, tree, oracle, oracle_index):
         assert (st["horizon"], st["escaped"], st["capped"]) == (ost["horizon"], ost["escaped"], ost["capped"])
         bad = np.abs(img - ref)[finite] > ATOL_FAST + RTOL_FAST * np.abs(ref[finite])
         assert bad.sum() == 0, f"{bad.sum()} of {bad.size} values outside 1e-4 (max abs {np.abs(img - ref)[finite].max():.3e})"
+
+
+def test_config0_default_640x480_on_gpu(tree):
+    """BASELINE configs[0] through the GPU path against the same committed full-frame summary."""
+    g = load_golden("summary_c1_default_640x480")
+    img = bs.render(g["cfg"], tree)
+    st = tree.stats()
+    assert st["steps"] == int(g["total_steps"]) and [st["horizon"], st["escaped"], st["capped"]] == list(g["fate_counts"])
+    assert st["disk_hits"] == int(g["disk_hits"]) and st["star_hits"] == int(g["star_hits"])
+    np.testing.assert_allclose(img[g["ys"], g["xs"]], g["samples"], rtol=RTOL_STRICT, atol=ATOL_STRICT)
+    np.testing.assert_allclose(img.reshape(-1, 3).sum(axis=0), g["channel_sums"], rtol=1e-11)

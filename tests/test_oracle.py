@@ -241,3 +241,16 @@ def test_srgb8_restatements_agree(oracle):
     b = np_oracle.srgb8(img)
     assert np.abs(a.astype(int) - b.astype(int)).max() == 0
     assert oracle.srgb8(np.array([[0.0, 1.0, 0.5, 0.0031308]])).tolist() == [[0, 255, 188, 10]]
+
+
+def test_config0_default_640x480_cpu_path(oracle, oracle_index):
+    """BASELINE configs[0]: scenes/default.yaml at 640x480, no supersampling, on the CPU path (the C restatement standing
+    in for the reference's Haskell CPU path, which cannot be built here) against the numpy restatement's full-frame summary."""
+    g = load_golden("summary_c1_default_640x480")
+    img, st = oracle.render(g["cfg"], oracle_index, threads=0)
+    assert st["rays"] == 640 * 480 and st["capped"] == 0
+    assert st["steps"] == int(g["total_steps"]) and [st["horizon"], st["escaped"], st["capped"]] == list(g["fate_counts"])
+    assert st["disk_hits"] == int(g["disk_hits"]) and st["star_hits"] == int(g["star_hits"])
+    np.testing.assert_allclose(img[g["ys"], g["xs"]], g["samples"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(img.reshape(-1, 3).sum(axis=0), g["channel_sums"], rtol=1e-12)
+    assert abs(st["steps"] / st["rays"] - 224.0) < 0.1  # SURVEY Appendix D: mean 224.0 steps per ray on C1
