@@ -94,8 +94,16 @@ def tree_to_byte_string(stars: np.ndarray) -> bytes:
 
 
 def read_tree_from_file(path: str, device: int = 0) -> StarTree:
+    """readTreeFromFile (src/StarMap.hs:82-85).  Accepts this repository's flat `.bskd` file and, best effort, the
+    reference's cereal-encoded `stars.kdt` (blackstar_amd/kdt_file.py: layout recalled, unverified offline)."""
     with open(path, "rb") as f:
         data = f.read()
+    if data[:2] == b"\x00\x00" and data[:8] != _MAGIC:
+        from .kdt_file import KdtDecodeError, read_kdt
+        try:
+            return StarTree(read_kdt(data), device)
+        except KdtDecodeError as e:
+            raise BlackstarError(str(e)) from e
     if data[:8] != _MAGIC or len(data) < 16:
         raise BlackstarError("Error decoding star tree: bad magic")
     (n,) = struct.unpack("<Q", data[8:16])

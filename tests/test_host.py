@@ -129,3 +129,19 @@ def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
     r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "catalogue_2000.ppm"), str(tmp_path / "o.f64")], capture_output=True, text=True)
     assert r.returncode == 1 and "bs_create" in r.stderr
     assert not (tmp_path / "o.f64").exists()
+
+
+def test_kdt_file_roundtrip(catalogue_bytes):
+    """best-effort `stars.kdt` layout (recalled, unverified against a real file): write -> read round trip."""
+    from blackstar_amd import kdt_file
+    rec = np.frombuffer(catalogue_bytes, np.dtype([("ra", ">f8"), ("dec", ">f8"), ("sp", "u1"), ("skip", "u1"), ("mag", ">i2"), ("pad", "u1", 8)]), offset=28)[:300]
+    stars = bs.read_map(catalogue_bytes)[:300]
+    pos = np.stack([stars["x"], stars["y"], stars["z"]], axis=1)
+    blob = kdt_file.write_kdt(pos, rec["mag"].astype(int), "".join(chr(c) for c in rec["sp"]))
+    back = kdt_file.read_kdt(blob)
+    assert len(back) == 300
+    key = lambda s: sorted(map(tuple, np.stack([s["x"], s["y"], s["z"], s["hue"], s["sat"], s["mag"].astype(float)], axis=1).tolist()))
+    assert key(back) == key(stars)  # same star SET with starColor' applied (file order is the tree's in-order)
+    for bad in (blob[:-3], blob[:40], b"\x00\x00\x07", b""):
+        with pytest.raises(kdt_file.KdtDecodeError):
+            kdt_file.read_kdt(bad)
