@@ -145,3 +145,14 @@ def test_kdt_file_roundtrip(catalogue_bytes):
     for bad in (blob[:-3], blob[:40], b"\x00\x00\x07", b""):
         with pytest.raises(kdt_file.KdtDecodeError):
             kdt_file.read_kdt(bad)
+
+
+def test_header_is_c99_and_layouts_match_the_shim(tmp_path):
+    """include/blackstar_gpu.h compiled as C99 (-pedantic); struct offsets are the ones INTEGRATION.md's Haskell shim pokes."""
+    import subprocess
+    exe = tmp_path / "abi_check"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "abi_check.c"), "-o", str(exe), "-L" + os.path.join(ROOT, "blackstar_amd"),
+                           "-lblackstar_gpu", "-Wl,-rpath," + os.path.join(ROOT, "blackstar_amd")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
