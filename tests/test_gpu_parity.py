@@ -416,3 +416,22 @@ def test_config0_default_640x480_on_gpu(tree):
     assert st["disk_hits"] == int(g["disk_hits"]) and st["star_hits"] == int(g["star_hits"])
     np.testing.assert_allclose(img[g["ys"], g["xs"]], g["samples"], rtol=RTOL_STRICT, atol=ATOL_STRICT)
     np.testing.assert_allclose(img.reshape(-1, 3).sum(axis=0), g["channel_sums"], rtol=1e-11)
+
+
+def test_large_frame_8k_supersampled(tree, oracle, oracle_index):
+    """Maximum-size case: 7680x4320 output pixels, 4x supersampled = 132.7 M rays (> 2^32 total steps): counters, tiling
+    and addressing at scale; 512 output pixels spot-checked against the oracle via their four traced rays."""
+    cfg = scenes.with_res(scenes.LENSING_DISK, 7680, 4320)
+    tree.set_mode(_lib.BS_MODE_STRICT)
+    img = bs.render(cfg, tree)
+    st = tree.stats()
+    assert st["rays"] == 4 * 7680 * 4320 and st["capped"] == 0 and st["horizon"] + st["escaped"] == st["rays"]
+    assert st["steps"] > 2 ** 32 and 250 < st["steps"] / st["rays"] < 270
+    assert np.isfinite(img).all()
+    rng = np.random.default_rng(8)
+    oy, ox = rng.integers(0, 4320, 512), rng.integers(0, 7680, 512)
+    ys = np.stack([2 * oy, 2 * oy + 1, 2 * oy, 2 * oy + 1], axis=1).ravel()   # p(2y,2x), p(2y+1,2x), p(2y,2x+1), p(2y+1,2x+1)
+    xs = np.stack([2 * ox, 2 * ox, 2 * ox + 1, 2 * ox + 1], axis=1).ravel()
+    rec = oracle.trace_rays(cfg, oracle_index, ys, xs)["rgba"][:, :3].reshape(512, 4, 3)
+    exp = 0.25 * (((rec[:, 0] + rec[:, 1]) + rec[:, 2]) + rec[:, 3])
+    np.testing.assert_allclose(img[oy, ox], exp, rtol=RTOL_STRICT, atol=ATOL_STRICT)
