@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["strict", "fast"], default=os.environ.get("BLACKSTAR_BENCH_MODE", "fast"))
+    ap.add_argument("--workload", choices=["default-aa", "animation"], default="default-aa",
+                    help="default-aa = BASELINE configs[2] (the headline metric); animation = configs[4]: frames of "
+                         "animations/default-ani.yaml (nFrames overridden to 600), frame i on rank i %% N")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes/launch from separate rocprofv3 --pmc passes (default: read profiles/*_pmc_summary.json)")
@@ -107,9 +110,22 @@ def main():
 
     out = torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream()
+    frames_cfg = None
+    if args.workload == "animation":
+        anim = bs.Animation.from_file(os.path.join(ROOT, "animations", "default-ani.yaml"))
+        anim.nFrames = 600  # BASELINE configs[4] (the file itself says 375)
+        bs.validate_keyframes(anim.keyframes)
+        frames_cfg = [c.to_bs_config() for c in bs.generate_frames(anim)]
+        cfg = frames_cfg[0]
+        W, H = cfg["width"], cfg["height"]
+    counter = {"i": 0}
 
     def step():
-        bs.render_device(cfg, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
+        c = cfg
+        if frames_cfg is not None:  # frame i of the animation goes to rank i % world
+            c = frames_cfg[(counter["i"] * world + rank) % len(frames_cfg)]
+            counter["i"] += 1
+        bs.render_device(c, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
 
     def fence():
         if world > 1:
@@ -157,8 +173,10 @@ def main():
             "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml", "value": value, "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "scenes/default-aa.yaml 1920x1080, 4x supersample (8,294,400 rays/frame), 470k-star synthetic "
-                                   "PPM-layout catalogue k-d lookup (BASELINE configs[2])",
+            "config": {"workload": ("scenes/default-aa.yaml 1920x1080, 4x supersample (8,294,400 rays/frame), 470k-star synthetic "
+                                    "PPM-layout catalogue k-d lookup (BASELINE configs[2])") if frames_cfg is None else
+                                   ("animations/default-ani.yaml, nFrames=600, 1920x1080, 4x supersample, 470k-star synthetic catalogue, "
+                                    "frame i on rank i % N (BASELINE configs[4]); roofline figures refer to the LAST frame rendered"),
                        "mode": args.mode, "frames_per_step_per_gpu": 1, "parallelism": f"frame-sharded x{world}",
                        "image": "RGB f64 resident in HBM (no D2H in the timed region)"},
             "rays_per_s": frames * st["rays"] / dt, "steps_per_ray": st["steps"] / st["rays"],
