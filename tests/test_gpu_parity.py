@@ -377,6 +377,8 @@ EDGE_CASES = {
     "wide_fov_grey_stars": dict(fov=6.0, star_intensity=1.0, star_saturation=0.0),
     "up_vector_parallel_to_view": dict(cam_pos=(0.0, 0.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 0.0, 1.0)),
     "looking_away_from_the_hole": dict(cam_lookat=(0.0, 1.0, -40.0)),
+    "disk_hue_in_third_hsi_sector": dict(disk_hsi=(300.0 / 360, 0.35, 0.9)),
+    "disk_hue_zero_saturated": dict(disk_hsi=(0.0, 1.0, 0.6)),
 }
 
 
@@ -435,3 +437,27 @@ def test_large_frame_8k_supersampled(tree, oracle, oracle_index):
     rec = oracle.trace_rays(cfg, oracle_index, ys, xs)["rgba"][:, :3].reshape(512, 4, 3)
     exp = 0.25 * (((rec[:, 0] + rec[:, 1]) + rec[:, 2]) + rec[:, 3])
     np.testing.assert_allclose(img[oy, ox], exp, rtol=RTOL_STRICT, atol=ATOL_STRICT)
+
+
+def test_star_colours_in_all_three_hsi_sectors(oracle):
+    """The catalogue's spectral classes only use HSI sectors 0 and 1; a custom star set covers hue >= 240 deg as well."""
+    rng = np.random.default_rng(31)
+    n = 3000
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    stars = np.zeros(n, _lib.STAR_DTYPE)
+    stars["x"], stars["y"], stars["z"] = v[:, 0], v[:, 1], v[:, 2]
+    stars["hue"] = rng.uniform(0, 0.999, n); stars["sat"] = rng.uniform(0, 0.6, n); stars["mag"] = rng.integers(500, 1200, n)
+    t = bs.StarTree(stars)
+    ix = oracle.Index(stars.astype(oracle.STAR_DTYPE))
+    dirs = v[rng.integers(0, n, 4000)] * rng.uniform(0.3, 4, (4000, 1)) + rng.normal(scale=4e-4, size=(4000, 3))
+    rgb, hits = bs.star_lookup(t, 0.7, 1.2, dirs, return_hits=True)
+    assert hits.sum() > 2500
+    sectors = set()
+    for k in range(4000):
+        ref, nref = oracle.star_lookup(ix, 0.7, 1.2, dirs[k])
+        assert hits[k] == nref
+        np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
+    for h in stars["hue"]:
+        sectors.add(int(h * 3))
+    assert sectors == {0, 1, 2}
+    t.close()
