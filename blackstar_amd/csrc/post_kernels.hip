@@ -59,6 +59,100 @@ __global__ __launch_bounds__(64) void box_blur_sweep(const double *__restrict__ 
     }
 }
 
+// LDS-staged variant of the same sweep (used whenever the window fits): one workgroup owns kLC adjacent chains.
+// The chain is inherently sequential, so ONE wavefront (lanes 0..kLC-1) walks it -- but it never waits on
+// HBM: the other three wavefronts stream the rows it will need next into an LDS ring (each element is fetched
+// from global memory once, as the leading sample, and re-read from the ring 2r rows later as the trailing one).
+// Per tile of kLT rows: consumer processes rows [kT, kT+T) from the ring while the loaders fill the rows tile
+// k+1 will lead with; one workgroup barrier per tile.  Ring depth kLR rows must cover 2r + 2T.
+constexpr int kLC = 32;    // chains per workgroup (256-B rows)
+constexpr int kLT = 64;    // rows per tile
+static_assert(true, "");
+constexpr int kLR = 512;   // ring rows (power of two): 512 * 32 * 8 B = 128 KiB of LDS -> supports r <= (512 - 128) / 2 = 192
+
+__global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restrict__ in, double *__restrict__ out, int chains, int n, int r, double norm)
+{
+    __shared__ double ring[kLR * kLC];  // [kLR][kLC], 128 KiB static
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * kLC;
+    const long stride = chains;
+    const bool consumer = tid < 64;
+    // loader thread: element e = (tid - 64) + 192 * m of a tile (row = e / kLC, chain = e % kLC), m = 0..kPref-1
+    constexpr int kPref = (kLT * kLC + 191) / 192;
+    double pref[kPref];
+    auto fetch = [&](int row_lo) {  // issue the global loads of tile rows [row_lo, row_lo + T) into registers
+#pragma unroll
+        for (int m = 0; m < kPref; m++) {
+            const int e = tid - 64 + 192 * m, row = row_lo + e / kLC, c = e % kLC;
+            pref[m] = (e < kLT * kLC && row < n && c0 + c < chains) ? in[(long)row * stride + c0 + c] : 0.0;
+        }
+    };
+    auto commit = [&](int row_lo) {  // registers -> ring
+#pragma unroll
+        for (int m = 0; m < kPref; m++) {
+            const int e = tid - 64 + 192 * m, row = row_lo + e / kLC, c = e % kLC;
+            if (e < kLT * kLC) ring[(row & (kLR - 1)) * kLC + c] = pref[m];
+        }
+    };
+    // prologue: everything the first tile touches (rows [0, T + r)) straight into the ring, all 256 threads;
+    // the loaders also start fetching what tile 1 will lead with.
+    for (int e = tid; e < (kLT + r) * kLC; e += 256) {
+        const int row = e / kLC, c = e % kLC;
+        ring[(row & (kLR - 1)) * kLC + c] = (row < n && c0 + c < chains) ? in[(long)row * stride + c0 + c] : 0.0;
+    }
+    if (!consumer) fetch(kLT + r);
+    __syncthreads();
+    const int lane = tid;  // consumer lanes 0..kLC-1 own one chain each
+    const bool owner = consumer && lane < kLC && c0 + lane < chains;
+    double s = 0.0;
+    if (owner) {  // startVal = foldl1' add (pix <$> take r crds)   (ImageFilters.hs:59)
+        const int m = r < n ? r : n;
+        s = ring[lane];
+        for (int i = 1; i < m; i++) s = s + ring[(i & (kLR - 1)) * kLC + lane];
+    }
+    const int tiles = (n + kLT - 1) / kLT;
+    for (int k = 0; k < tiles; k++) {
+        if (consumer) {
+            if (owner) {
+                double *dst = out + c0 + lane;
+                const int x_hi = (k + 1) * kLT < n ? (k + 1) * kLT : n;
+                int x = k * kLT;
+                for (; x + 8 <= x_hi; x += 8) {  // accumulate (:61-64): fetch 8 rows' samples from the ring, then run the chain
+                    double lead[8], trail[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int xl = x + u + r, xt = x + u - r;
+                        const double a = ring[(xl & (kLR - 1)) * kLC + lane], b = ring[(xt & (kLR - 1)) * kLC + lane];
+                        lead[u] = (xl < n) ? a : 0.0;   // out of bounds -> black
+                        trail[u] = (xt >= 0) ? b : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        s = (s + lead[u]) - trail[u];
+                        dst[(long)(x + u) * stride] = norm * s;
+                    }
+                }
+                for (; x < x_hi; x++) {
+                    const int xl = x + r, xt = x - r;
+                    const double lead = (xl < n) ? ring[(xl & (kLR - 1)) * kLC + lane] : 0.0;
+                    const double trail = (xt >= 0) ? ring[(xt & (kLR - 1)) * kLC + lane] : 0.0;
+                    s = (s + lead) - trail;
+                    dst[(long)x * stride] = norm * s;
+                }
+            }
+        } else {
+            // software pipeline: what was fetched during the previous tile lands in the ring now (tile k+1 leads with it),
+            // and the loads for tile k+2 are issued -- their latency hides behind the consumer's next tile.
+            commit((k + 1) * kLT + r);
+            fetch((k + 2) * kLT + r);
+        }
+        // Tile barrier WITHOUT a memory fence: only the ring (LDS) is handed over between wavefronts, so wait for this
+        // wave's LDS traffic and rendezvous.  __syncthreads() would also drain vmcnt -- i.e. wait for the loads just
+        // issued for tile k+2 and for the consumer's stores -- which is exactly the latency this pipeline hides.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 // [rows][cols] pixels of 3 doubles -> [cols][rows]; 32x32-pixel tiles through LDS so both sides are coalesced.
 __global__ __launch_bounds__(256) void transpose_rgb(const double *__restrict__ in, double *__restrict__ out, int rows, int cols)
 {
@@ -107,13 +201,20 @@ int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, in
     const dim3 tgrid_hw((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32));  // transposing an h x w image
     const dim3 tgrid_wh((unsigned)((h + 31) / 32), (unsigned)((w + 31) / 32));  // transposing a  w x h image
     const double *src = d_in;
+    const bool staged = 2 * r + 2 * kLT <= kLR;  // the LDS ring covers the window
+    auto sweep = [&](const double *a, double *b, int chains, int n) {
+        if (staged)
+            hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((chains + kLC - 1) / kLC)), dim3(256), 0, s, a, b, chains, n,
+                               r, norm);
+        else
+            hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, s, a, b, chains, n, r, norm);
+    };
     for (int pass = 0; pass < 3; pass++) {
         // horizontal sweep = transpose, sweep along the slow axis (coalesced), transpose back.  Same per-chain arithmetic.
-        hipLaunchKernelGGL(transpose_rgb, tgrid_hw, dim3(256), 0, s, src, d_a, h, w);                                     // src (h x w) -> A (w x h)
-        hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((h * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, h * 3, w, r, norm);  // A -> B
-        hipLaunchKernelGGL(transpose_rgb, tgrid_wh, dim3(256), 0, s, (const double *)d_b, d_a, w, h);                     // B (w x h) -> A (h x w)
-        // vertical sweep reads the H result (ImageFilters.hs:75-76)
-        hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((w * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);  // A -> B
+        hipLaunchKernelGGL(transpose_rgb, tgrid_hw, dim3(256), 0, s, src, d_a, h, w);                  // src (h x w) -> A (w x h)
+        sweep(d_a, d_b, h * 3, w);                                                                      // A -> B
+        hipLaunchKernelGGL(transpose_rgb, tgrid_wh, dim3(256), 0, s, (const double *)d_b, d_a, w, h);  // B (w x h) -> A (h x w)
+        sweep(d_a, d_b, w * 3, h);                                                                      // vertical sweep reads the H result (ImageFilters.hs:75-76)
         src = d_b;
     }
     // NOTE: pass p+1 transposes B into A while B is still the source -- A and B never alias, so this is safe.
