@@ -64,3 +64,32 @@ def render_sharded(n_frames: int, render_frame: Callable[[int], "object"], rank:
     if gather_to is None or rank == gather_to:
         return out
     return None
+
+
+def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: Optional[int] = 0, out_dir: Optional[str] = None,
+                     basename: str = "frame", dist=None):
+    """BASELINE configs[4] end to end: the frames of an Animation (src/Animation.hs generateFrames), frame i on rank
+    i % world, each through the device pipeline of doRender (render -> bloom -> sRGB8, `bs_render_rgb8`), gathered as
+    RGB8 on `gather_to` (6.2 MB per 1080p frame instead of 49.8 MB of f64).  With out_dir, every rank also PNG-encodes the
+    frames it rendered (`<basename>_<zero-padded index>.png`, the naming of app/Animate.hs:55-56 with the padding done
+    right -- SURVEY Appendix F.7).  Returns the ordered list of (h, w, 3) uint8 tensors on the root, None elsewhere."""
+    import os
+
+    import torch
+
+    from .animation import generate_frames, validate_keyframes
+    from .raytracer import render_rgb8, write_png
+
+    validate_keyframes(animation.keyframes)
+    frames = generate_frames(animation)
+    width = len(str(max(len(frames) - 1, 1)))
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+
+    def one(i):
+        rgb8 = render_rgb8(frames[i], tree)
+        if out_dir:
+            write_png(rgb8, os.path.join(out_dir, f"{basename}_{i:0{width}d}.png"))
+        return torch.from_numpy(rgb8)
+
+    return render_sharded(len(frames), one, rank, world, gather_to=gather_to, dist=dist)

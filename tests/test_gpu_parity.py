@@ -461,3 +461,21 @@ def test_star_colours_in_all_three_hsi_sectors(oracle):
         sectors.add(int(h * 3))
     assert sectors == {0, 1, 2}
     t.close()
+
+
+def test_render_animation_single_rank(tree, tmp_path, oracle):
+    """configs[4] in miniature: 5 interpolated cameras of default-ani.yaml through the device pipeline, world = 1."""
+    from blackstar_amd.distributed import render_animation
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
+    anim.nFrames = 5
+    anim.scene.resolution = (96, 54)
+    frames = render_animation(anim, tree, out_dir=str(tmp_path), basename="ani")
+    assert len(frames) == 5 and sorted(os.listdir(tmp_path)) == [f"ani_{i}.png" for i in range(5)]
+    cfgs = bs.generate_frames(anim)
+    for i in (0, 2, 4):
+        img = bs.render(cfgs[i], tree)
+        exp = oracle.srgb8(oracle.bloom(anim.scene.bloomStrength, anim.scene.bloomDivider, img))
+        d = np.abs(frames[i].numpy().astype(int) - exp.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert not np.array_equal(frames[0].numpy(), frames[4].numpy())  # the camera moved
