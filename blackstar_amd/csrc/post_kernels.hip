@@ -114,30 +114,54 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
     for (int k = 0; k < tiles; k++) {
         if (consumer) {
             if (owner) {
-                double *dst = out + c0 + lane;
-                const int x_hi = (k + 1) * kLT < n ? (k + 1) * kLT : n;
-                int x = k * kLT;
-                for (; x + 8 <= x_hi; x += 8) {  // accumulate (:61-64): fetch 8 rows' samples from the ring, then run the chain
-                    double lead[8], trail[8];
+                double *dst = out + (long)(k * kLT) * stride + c0 + lane;
+                const int x_lo = k * kLT, x_hi = (k + 1) * kLT < n ? (k + 1) * kLT : n;
+                const double *rl = ring + lane;
+                if (x_lo - r >= 0 && x_hi - 1 + r < n && x_hi - x_lo == kLT) {
+                    // interior tile: every leading and trailing sample exists -> no bounds selects; the ring reads of
+                    // the NEXT 8 rows are issued before the add/subtract chain of the current 8 runs (accumulate, :61-64)
+                    double la[8], ta[8], lb[8], tb[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        const int xl = x + u + r, xt = x + u - r;
-                        const double a = ring[(xl & (kLR - 1)) * kLC + lane], b = ring[(xt & (kLR - 1)) * kLC + lane];
-                        lead[u] = (xl < n) ? a : 0.0;   // out of bounds -> black
-                        trail[u] = (xt >= 0) ? b : 0.0;
+                        la[u] = rl[((x_lo + u + r) & (kLR - 1)) * kLC];
+                        ta[u] = rl[((x_lo + u - r) & (kLR - 1)) * kLC];
                     }
+#pragma unroll 1
+                    for (int x = x_lo; x < x_hi; x += 16) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        s = (s + lead[u]) - trail[u];
-                        dst[(long)(x + u) * stride] = norm * s;
+                        for (int u = 0; u < 8; u++) {
+                            lb[u] = rl[((x + 8 + u + r) & (kLR - 1)) * kLC];
+                            tb[u] = rl[((x + 8 + u - r) & (kLR - 1)) * kLC];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            s = (s + la[u]) - ta[u];
+                            *dst = norm * s;
+                            dst += stride;
+                        }
+                        if (x + 16 < x_hi) {
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                la[u] = rl[((x + 16 + u + r) & (kLR - 1)) * kLC];
+                                ta[u] = rl[((x + 16 + u - r) & (kLR - 1)) * kLC];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            s = (s + lb[u]) - tb[u];
+                            *dst = norm * s;
+                            dst += stride;
+                        }
                     }
-                }
-                for (; x < x_hi; x++) {
-                    const int xl = x + r, xt = x - r;
-                    const double lead = (xl < n) ? ring[(xl & (kLR - 1)) * kLC + lane] : 0.0;
-                    const double trail = (xt >= 0) ? ring[(xt & (kLR - 1)) * kLC + lane] : 0.0;
-                    s = (s + lead) - trail;
-                    dst[(long)x * stride] = norm * s;
+                } else {  // edge tiles: out-of-range samples read as black (ixh / ixv)
+                    for (int x = x_lo; x < x_hi; x++) {
+                        const int xl = x + r, xt = x - r;
+                        const double lead = (xl < n) ? rl[(xl & (kLR - 1)) * kLC] : 0.0;
+                        const double trail = (xt >= 0) ? rl[(xt & (kLR - 1)) * kLC] : 0.0;
+                        s = (s + lead) - trail;
+                        *dst = norm * s;
+                        dst += stride;
+                    }
                 }
             }
         } else {
