@@ -479,3 +479,42 @@ def test_render_animation_single_rank(tree, tmp_path, oracle):
         d = np.abs(frames[i].numpy().astype(int) - exp.astype(int))
         assert d.max() <= 1 and (d > 0).mean() < 1e-3
     assert not np.array_equal(frames[0].numpy(), frames[4].numpy())  # the camera moved
+
+
+def _random_scene(rng):
+    cam = rng.normal(size=3) * rng.uniform(3, 40)
+    while np.linalg.norm(cam) < 2.5:
+        cam = rng.normal(size=3) * rng.uniform(3, 40)
+    inner = float(rng.uniform(1.1, 6.0))
+    return dict(cam_pos=tuple(float(c) for c in cam), cam_lookat=tuple(float(c) for c in rng.normal(size=3) * 2),
+                cam_up=tuple(float(c) for c in rng.normal(size=3)), fov=float(rng.uniform(0.2, 3.0)),
+                step_size=float(rng.choice([0.15, 0.3, 0.5])), star_intensity=float(rng.uniform(0.1, 1.0)),
+                star_saturation=float(rng.uniform(0.0, 2.0)), disk_hsi=(float(rng.uniform(0, 0.999)), float(rng.uniform(0, 0.5)), float(rng.uniform(0.3, 1.2))),
+                disk_opacity=float(rng.choice([0.0, 0.5, 0.95, 1.0])), disk_inner=inner, disk_outer=inner + float(rng.uniform(0.5, 15.0)),
+                width=int(rng.integers(5, 40)), height=int(rng.integers(5, 30)), supersampling=bool(rng.integers(0, 2)))
+
+
+def test_randomised_scenes_both_modes(tree, oracle, oracle_index):
+    """Seeded fuzz: 40 random cameras / scene parameters / ragged resolutions, both modes, against the oracle."""
+    rng = np.random.default_rng(20260927)
+    worst_fast = 0.0
+    for case in range(40):
+        cfg = _random_scene(rng)
+        ref, ost = oracle.render(cfg, oracle_index, threads=0, max_steps=30000)
+        tree.set_max_steps(30000)
+        try:
+            tree.set_mode(_lib.BS_MODE_STRICT)
+            img = bs.render(cfg, tree); st = tree.stats()
+            assert (st["steps"], st["horizon"], st["escaped"], st["capped"], st["disk_hits"], st["star_hits"]) == \
+                   (ost["steps"], ost["horizon"], ost["escaped"], ost["capped"], ost["disk_hits"], ost["star_hits"]), (case, cfg)
+            assert (np.abs(img - ref) <= ATOL_STRICT + RTOL_STRICT * np.abs(ref)).all(), (case, cfg)
+            tree.set_mode(_lib.BS_MODE_FAST)
+            img = bs.render(cfg, tree); st = tree.stats()
+            assert (st["horizon"], st["escaped"], st["capped"]) == (ost["horizon"], ost["escaped"], ost["capped"]), (case, cfg)
+            err = np.abs(img - ref) - RTOL_FAST * np.abs(ref)
+            assert (err <= ATOL_FAST).all(), (case, cfg, float(err.max()))
+            worst_fast = max(worst_fast, float(np.abs(img - ref).max()))
+        finally:
+            tree.set_mode(_lib.BS_MODE_STRICT)
+            tree.set_max_steps(100000)
+    print(f"worst FAST abs deviation over the fuzz set: {worst_fast:.3e}")
