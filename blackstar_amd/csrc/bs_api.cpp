@@ -277,6 +277,21 @@ int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, 
     return BS_OK;
 }
 
+int bs_supersample(bs_ctx *ctx, const double *in, double *out, int width2, int height2)
+{
+    if (!ctx || !in || !out || width2 < 0 || height2 < 0) return fail(BS_EINVAL, "bad argument");
+    const size_t n_in = (size_t)width2 * height2 * 3, n_out = (size_t)(width2 / 2) * (height2 / 2) * 3;
+    if (n_out == 0) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_post(ctx, n_in);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (bs::launch_supersample(ctx->d_post[2], ctx->d_post[0], width2, height2, ctx->stream)) return fail(BS_EDEVICE, "supersample launch failed");
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_post[0], n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BS_OK;
+}
+
 int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream)
 {
     if (!ctx || (n_values && (!d_in || !d_out_u8))) return fail(BS_EINVAL, "bad argument");

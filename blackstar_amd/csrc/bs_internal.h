@@ -81,6 +81,7 @@ int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, si
 int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, double *d_rgb, int32_t *d_hits, void *stream);
 // post_kernels.hip
 int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, void *stream);
+int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *stream);
 int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, void *stream);
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
 int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);

@@ -203,6 +203,20 @@ __global__ void bloom_combine(const double *img, const double *blurred, double *
     if (i < n) out[i] = img[i] + strength * blurred[i];
 }
 
+// supersample (ImageFilters.hs:88-97) as a standalone op (render fuses it into the trace kernel's epilogue):
+// out(y,x) = 0.25 * (((p(2y,2x) + p(2y+1,2x)) + p(2y,2x+1)) + p(2y+1,2x+1)); output (h2 div 2) x (w2 div 2).
+__global__ void supersample_kernel(const double *in, double *out, int w2, int h, int w)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)h * w * 3) return;
+    int c = (int)(i % 3);
+    size_t px = i / 3;
+    int x = (int)(px % w), y = (int)(px / w);
+    const double *p = in + ((size_t)(2 * y) * w2 + 2 * x) * 3 + c;
+    double a = p[0], b = p[(size_t)w2 * 3], cc = p[3], d = p[(size_t)w2 * 3 + 3];
+    out[i] = 0.25 * (((a + b) + cc) + d);
+}
+
 // writeImg's pixel map: toWord8 . fmap sRGB   (Raytracer.hs:23-32); toWord8 = round-half-even (255 * clamp01 x)
 __global__ void srgb8_kernel(const double *in, unsigned char *out, size_t n)
 {
@@ -243,6 +257,15 @@ int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, in
     }
     // NOTE: pass p+1 transposes B into A while B is still the source -- A and B never alias, so this is safe.
     hipLaunchKernelGGL(bloom_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (const double *)d_b, d_out, n, strength);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *stream)
+{
+    const int w = w2 / 2, h = h2 / 2;
+    const size_t n = (size_t)w * h * 3;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(supersample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, w2, h, w);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

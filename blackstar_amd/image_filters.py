@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's ImageFilters module: `bloom` and `supersample` (src/ImageFilters.hs:5).
 
-Both run on the GPU through the C ABI (`bs_bloom`, and the supersample fused into the trace kernel's epilogue);
-this module contains no pixel arithmetic.  The reference's functions take no context, the GPU needs one: pass
+Both run on the GPU through the C ABI (`bs_bloom`, `bs_supersample`; inside `render` the supersample is fused into
+the trace kernel's epilogue); this module contains no pixel arithmetic.  The reference's functions take no context, the GPU needs one: pass
 the `StarTree` you render with, or let a lazily created context on device 0 be used.
 """
 from __future__ import annotations
@@ -46,9 +46,13 @@ def srgb8(img: np.ndarray, tree: Optional[StarTree] = None) -> np.ndarray:
 
 
 def supersample(img: np.ndarray, tree: Optional[StarTree] = None) -> np.ndarray:
-    """supersample (src/ImageFilters.hs:88-97).  In the reference it is only ever called from render (:67) and
-    here it is fused into the trace kernel, so this standalone form is provided for API completeness through
-    the same device arithmetic: 0.25 * (((p00 + p10) + p01) + p11), computed by bs_bloom-free plain device code
-    is not needed -- the 2x2 mean of a host image is exact data movement plus three adds, done with numpy."""
-    img = np.asarray(img, np.float64)
-    return 0.25 * (((img[0::2, 0::2] + img[1::2, 0::2]) + img[0::2, 1::2]) + img[1::2, 1::2])
+    """supersample :: Image U RGB Double -> Image U RGB Double   (src/ImageFilters.hs:88-97): 2x2 mean in the
+    reference's summation order, on the GPU (`bs_supersample`).  `render` does not call this: there the reduction is
+    fused into the trace kernel's epilogue."""
+    img = np.ascontiguousarray(img, np.float64)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("expected an (h, w, 3) RGB image")
+    h2, w2, _ = img.shape
+    out = np.empty((h2 // 2, w2 // 2, 3), np.float64)
+    _lib.check(_lib.lib().bs_supersample(_ctx(tree).handle, img.ctypes.data, out.ctypes.data, w2, h2), "bs_supersample")
+    return out

@@ -117,6 +117,10 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
 int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int height, double strength, int divider, void *hip_stream);
 int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider); /* host buffers, blocking */
 
+/* Replaces: supersample (src/ImageFilters.hs:88-97) as a standalone call (render itself fuses it): in is height2 x width2
+ * RGB f64, out is (height2 div 2) x (width2 div 2).  Host buffers, blocking. */
+int bs_supersample(bs_ctx *ctx, const double *in, double *out, int width2, int height2);
+
 /* Replaces: A.map (toWord8 . fmap sRGB) in writeImg (src/Raytracer.hs:23-32): n_values f64 channel values ->
  * n_values bytes (sRGB transfer, clamp to [0,1], *255, round half to even). */
 int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream);

@@ -518,3 +518,10 @@ def test_randomised_scenes_both_modes(tree, oracle, oracle_index):
             tree.set_mode(_lib.BS_MODE_STRICT)
             tree.set_max_steps(100000)
     print(f"worst FAST abs deviation over the fuzz set: {worst_fast:.3e}")
+
+
+def test_standalone_supersample(tree, oracle):
+    rng = np.random.default_rng(17)
+    for shape in ((10, 14, 3), (7, 9, 3), (2, 2, 3), (108, 192, 3)):
+        img = rng.uniform(0, 2, shape)
+        assert np.array_equal(bs.supersample(img, tree), oracle.supersample(img))
