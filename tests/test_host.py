@@ -156,3 +156,16 @@ def test_header_is_c99_and_layouts_match_the_shim(tmp_path):
                            "-lblackstar_gpu", "-Wl,-rpath," + os.path.join(ROOT, "blackstar_amd")])
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_missing_native_library_fails_loudly():
+    """No eager / CPU fallback: with the shared object absent every product entry point raises."""
+    import subprocess
+    import sys
+    code = ("import blackstar_amd as bs, numpy as np\n"
+            "for f in (lambda: bs.read_map(bytes(56)), lambda: bs.StarTree(None), lambda: bs.bloom(0.1, 2, np.zeros((4, 4, 3)))):\n"
+            "    try:\n        f()\n        print('NO ERROR')\n    except bs._lib.BlackstarError as e:\n        print('raised', 'is missing' in str(e))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, BLACKSTAR_LIB="/nonexistent/libblackstar_gpu.so"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n")[:3] == ["raised True"] * 3, r.stdout
