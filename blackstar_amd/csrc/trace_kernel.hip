@@ -619,11 +619,15 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 #pragma unroll
     for (int k = 0; k < 6; k++) stat[k * kBlock] = 0u;
     unsigned long long a_iters = 0;  // wave-uniform
+    // The queue pop for tile t+1 is issued BEFORE tile t is traced (the returned index is not needed until the next
+    // trip), so the ~1-2 us round trip of the device-scope atomic never stalls the wavefront.  Over-fetching past
+    // the end is harmless: indices >= n_tiles just end the loop.
+    int next_tile = 0;
+    if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
     for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = (int)atomicAdd(&P.counters[7], 1ull);
-        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile = __builtin_amdgcn_readfirstlane(next_tile);
         if (tile >= n_tiles) break;
+        if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int xi = tx * 8 + lx, yi = ty * 8 + ly;
         const bool inb = xi < P.wt && yi < P.ht;
