@@ -60,45 +60,52 @@ __global__ __launch_bounds__(64) void box_blur_sweep(const double *__restrict__ 
 }
 
 // LDS-staged variant of the same sweep (used whenever the window fits): one workgroup owns kLC adjacent chains.
+// Its INPUT is chain-major -- in[(p * n + row) * 3 + c] for chain (pixel p, channel c) -- and its OUTPUT row-major --
+// out[(row * P + p) * 3 + c]: the horizontal sweep reads the image as it is (p = y, row = x) and writes it transposed,
+// the vertical sweep reads that (p = x, row = y) and writes the image layout back, so no transpose kernels are needed:
+// the loaders fetch a chain-pixel's T x 3 contiguous doubles at a time (1.5 KB coalesced) and scatter them into the
+// ring, the consumer's 33 lanes write 33 contiguous doubles per row.
 // The chain is inherently sequential, so ONE wavefront (lanes 0..kLC-1) walks it -- but it never waits on
 // HBM: the other three wavefronts stream the rows it will need next into an LDS ring (each element is fetched
 // from global memory once, as the leading sample, and re-read from the ring 2r rows later as the trailing one).
 // Per tile of kLT rows: consumer processes rows [kT, kT+T) from the ring while the loaders fill the rows tile
 // k+1 will lead with; one workgroup barrier per tile.  Ring depth kLR rows must cover 2r + 2T.
-constexpr int kLC = 32;    // chains per workgroup (256-B rows)
+constexpr int kLP = 11;    // pixels (chain triples) per workgroup
+constexpr int kLC = 3 * kLP;  // 33 chains per workgroup: whole RGB pixels; odd row stride in the ring
 constexpr int kLT = 64;    // rows per tile
 static_assert(true, "");
-constexpr int kLR = 512;   // ring rows (power of two): 512 * 32 * 8 B = 128 KiB of LDS -> supports r <= (512 - 128) / 2 = 192
+constexpr int kLR = 512;   // ring rows (power of two): 512 * 33 * 8 B = 132 KiB of LDS -> supports r <= (512 - 128) / 2 = 192
 
 __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restrict__ in, double *__restrict__ out, int chains, int n, int r, double norm)
 {
     __shared__ double ring[kLR * kLC];  // [kLR][kLC], 128 KiB static
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * kLC;
-    const long stride = chains;
+    const int c0 = blockIdx.x * kLC;   // first chain of this workgroup
+    const int p0 = blockIdx.x * kLP;   // first chain-pixel
+    const int P = chains / 3;          // chain-pixels in the image
+    const long stride = chains;        // output row stride
     const bool consumer = tid < 64;
-    // loader thread: element e = (tid - 64) + 192 * m of a tile (row = e / kLC, chain = e % kLC), m = 0..kPref-1
-    constexpr int kPref = (kLT * kLC + 191) / 192;
+    // loader thread j = tid - 64 (0..191) handles, for each of the kLP chain-pixels, element j of that pixel's T x 3
+    // contiguous doubles: row = row_lo + j / 3, channel = j % 3
+    constexpr int kPref = kLP;
     double pref[kPref];
+    const int j = tid - 64, jr = j / 3, jc = j - 3 * jr;
     auto fetch = [&](int row_lo) {  // issue the global loads of tile rows [row_lo, row_lo + T) into registers
 #pragma unroll
         for (int m = 0; m < kPref; m++) {
-            const int e = tid - 64 + 192 * m, row = row_lo + e / kLC, c = e % kLC;
-            pref[m] = (e < kLT * kLC && row < n && c0 + c < chains) ? in[(long)row * stride + c0 + c] : 0.0;
+            const int row = row_lo + jr;
+            pref[m] = (row < n && p0 + m < P) ? in[((long)(p0 + m) * n + row) * 3 + jc] : 0.0;
         }
     };
     auto commit = [&](int row_lo) {  // registers -> ring
 #pragma unroll
-        for (int m = 0; m < kPref; m++) {
-            const int e = tid - 64 + 192 * m, row = row_lo + e / kLC, c = e % kLC;
-            if (e < kLT * kLC) ring[(row & (kLR - 1)) * kLC + c] = pref[m];
-        }
+        for (int m = 0; m < kPref; m++) ring[((row_lo + jr) & (kLR - 1)) * kLC + 3 * m + jc] = pref[m];
     };
     // prologue: everything the first tile touches (rows [0, T + r)) straight into the ring, all 256 threads;
     // the loaders also start fetching what tile 1 will lead with.
-    for (int e = tid; e < (kLT + r) * kLC; e += 256) {
-        const int row = e / kLC, c = e % kLC;
-        ring[(row & (kLR - 1)) * kLC + c] = (row < n && c0 + c < chains) ? in[(long)row * stride + c0 + c] : 0.0;
+    for (int e = tid; e < (kLT + r) * 3 * kLP; e += 256) {
+        const int m = e / ((kLT + r) * 3), q = e - m * (kLT + r) * 3, row = q / 3, c = q - 3 * row;
+        ring[(row & (kLR - 1)) * kLC + 3 * m + c] = (row < n && p0 + m < P) ? in[((long)(p0 + m) * n + row) * 3 + c] : 0.0;
     }
     if (!consumer) fetch(kLT + r);
     __syncthreads();
@@ -240,22 +247,21 @@ int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, in
     const dim3 tgrid_wh((unsigned)((h + 31) / 32), (unsigned)((w + 31) / 32));  // transposing a  w x h image
     const double *src = d_in;
     const bool staged = 2 * r + 2 * kLT <= kLR;  // the LDS ring covers the window
-    auto sweep = [&](const double *a, double *b, int chains, int n) {
-        if (staged)
-            hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((chains + kLC - 1) / kLC)), dim3(256), 0, s, a, b, chains, n,
-                               r, norm);
-        else
-            hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, s, a, b, chains, n, r, norm);
-    };
     for (int pass = 0; pass < 3; pass++) {
-        // horizontal sweep = transpose, sweep along the slow axis (coalesced), transpose back.  Same per-chain arithmetic.
-        hipLaunchKernelGGL(transpose_rgb, tgrid_hw, dim3(256), 0, s, src, d_a, h, w);                  // src (h x w) -> A (w x h)
-        sweep(d_a, d_b, h * 3, w);                                                                      // A -> B
-        hipLaunchKernelGGL(transpose_rgb, tgrid_wh, dim3(256), 0, s, (const double *)d_b, d_a, w, h);  // B (w x h) -> A (h x w)
-        sweep(d_a, d_b, w * 3, h);                                                                      // vertical sweep reads the H result (ImageFilters.hs:75-76)
+        if (staged) {
+            // H: image layout (h x w) -> transposed layout (w x h); V: transposed -> image layout.  No transpose kernels.
+            hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((h + kLP - 1) / kLP)), dim3(256), 0, s, src, d_a, h * 3, w, r, norm);
+            hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((w + kLP - 1) / kLP)), dim3(256), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);
+        } else {
+            // window wider than the ring: transpose, sweep along the slow axis with register prefetch, transpose back
+            hipLaunchKernelGGL(transpose_rgb, tgrid_hw, dim3(256), 0, s, src, d_a, h, w);                  // src (h x w) -> A (w x h)
+            hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((h * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, h * 3, w, r, norm);
+            hipLaunchKernelGGL(transpose_rgb, tgrid_wh, dim3(256), 0, s, (const double *)d_b, d_a, w, h);  // B (w x h) -> A (h x w)
+            hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((w * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);
+        }
         src = d_b;
     }
-    // NOTE: pass p+1 transposes B into A while B is still the source -- A and B never alias, so this is safe.
+    // NOTE: pass p+1 reads B while writing A -- A and B never alias, so this is safe.
     hipLaunchKernelGGL(bloom_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (const double *)d_b, d_out, n, strength);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
