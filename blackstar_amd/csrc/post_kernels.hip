@@ -78,7 +78,9 @@ constexpr int kLR = 512;   // ring rows (power of two): 512 * 33 * 8 B = 132 KiB
 
 __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restrict__ in, double *__restrict__ out, int chains, int n, int r, double norm)
 {
-    __shared__ double ring[kLR * kLC];  // [kLR][kLC], 128 KiB static
+    // [kLR + 8][kLC]: rows 0..7 are mirrored at kLR..kLR+7, so a run of 8 consecutive rows never wraps and the
+    // consumer can address it as one base + immediate offsets
+    __shared__ double ring[(kLR + 8) * kLC];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * kLC;   // first chain of this workgroup
     const int p0 = blockIdx.x * kLP;   // first chain-pixel
@@ -98,14 +100,21 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
         }
     };
     auto commit = [&](int row_lo) {  // registers -> ring
+        const int ri = (row_lo + jr) & (kLR - 1);
 #pragma unroll
-        for (int m = 0; m < kPref; m++) ring[((row_lo + jr) & (kLR - 1)) * kLC + 3 * m + jc] = pref[m];
+        for (int m = 0; m < kPref; m++) {
+            ring[ri * kLC + 3 * m + jc] = pref[m];
+            if (ri < 8) ring[(ri + kLR) * kLC + 3 * m + jc] = pref[m];
+        }
     };
     // prologue: everything the first tile touches (rows [0, T + r)) straight into the ring, all 256 threads;
     // the loaders also start fetching what tile 1 will lead with.
     for (int e = tid; e < (kLT + r) * 3 * kLP; e += 256) {
         const int m = e / ((kLT + r) * 3), q = e - m * (kLT + r) * 3, row = q / 3, c = q - 3 * row;
-        ring[(row & (kLR - 1)) * kLC + 3 * m + c] = (row < n && p0 + m < P) ? in[((long)(p0 + m) * n + row) * 3 + c] : 0.0;
+        const double val = (row < n && p0 + m < P) ? in[((long)(p0 + m) * n + row) * 3 + c] : 0.0;
+        const int ri = row & (kLR - 1);
+        ring[ri * kLC + 3 * m + c] = val;
+        if (ri < 8) ring[(ri + kLR) * kLC + 3 * m + c] = val;
     }
     if (!consumer) fetch(kLT + r);
     __syncthreads();
@@ -128,18 +137,14 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
                     // interior tile: every leading and trailing sample exists -> no bounds selects; the ring reads of
                     // the NEXT 8 rows are issued before the add/subtract chain of the current 8 runs (accumulate, :61-64)
                     double la[8], ta[8], lb[8], tb[8];
+                    const double *pl = rl + ((x_lo + r) & (kLR - 1)) * kLC, *pt = rl + ((x_lo - r) & (kLR - 1)) * kLC;
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        la[u] = rl[((x_lo + u + r) & (kLR - 1)) * kLC];
-                        ta[u] = rl[((x_lo + u - r) & (kLR - 1)) * kLC];
-                    }
+                    for (int u = 0; u < 8; u++) { la[u] = pl[u * kLC]; ta[u] = pt[u * kLC]; }
 #pragma unroll 1
                     for (int x = x_lo; x < x_hi; x += 16) {
+                        pl = rl + ((x + 8 + r) & (kLR - 1)) * kLC; pt = rl + ((x + 8 - r) & (kLR - 1)) * kLC;
 #pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            lb[u] = rl[((x + 8 + u + r) & (kLR - 1)) * kLC];
-                            tb[u] = rl[((x + 8 + u - r) & (kLR - 1)) * kLC];
-                        }
+                        for (int u = 0; u < 8; u++) { lb[u] = pl[u * kLC]; tb[u] = pt[u * kLC]; }
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             s = (s + la[u]) - ta[u];
@@ -147,11 +152,9 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
                             dst += stride;
                         }
                         if (x + 16 < x_hi) {
+                            pl = rl + ((x + 16 + r) & (kLR - 1)) * kLC; pt = rl + ((x + 16 - r) & (kLR - 1)) * kLC;
 #pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                la[u] = rl[((x + 16 + u + r) & (kLR - 1)) * kLC];
-                                ta[u] = rl[((x + 16 + u - r) & (kLR - 1)) * kLC];
-                            }
+                            for (int u = 0; u < 8; u++) { la[u] = pl[u * kLC]; ta[u] = pt[u * kLC]; }
                         }
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
