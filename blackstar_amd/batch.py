@@ -1,0 +1,28 @@
+"""Batch mode: a list of scenes rendered with the same star tree (app/Main.hs:68-77), through `bs_render_batch`."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config_file import Config
+from .star_map import StarTree
+
+
+def render_batch(cfgs: Sequence, trees: Sequence[StarTree]) -> List[np.ndarray]:
+    """Render cfgs[i] on trees[i % len(trees)] (one StarTree per GPU); per tree, frame k's device-to-host copy overlaps
+    frame k+1's kernel.  Returns the (h, w, 3) float64 images in order."""
+    if not trees:
+        raise ValueError("need at least one StarTree")
+    cs = [_lib.make_config(c.to_bs_config() if isinstance(c, Config) else c) for c in cfgs]
+    n = len(cs)
+    outs = [np.empty((c.height, c.width, 3), np.float64) for c in cs]
+    if n == 0:
+        return outs
+    arr = (_lib.BsConfig * n)(*cs)
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
+    _lib.check(_lib.lib().bs_render_batch(ctxs, len(trees), arr, n, ptrs), "bs_render_batch")
+    return outs

@@ -105,8 +105,9 @@ int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_dou
 int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t out_doubles, void *hip_stream);
 
 /* Batch mode (app/Main.hs:68-77 renders a directory of scenes sequentially with the same tree):
- * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin); outs[i] is
- * a host buffer of cfgs[i].height*width*3 doubles. */
+ * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin, one host thread per
+ * context); outs[i] is a host buffer of cfgs[i].height*width*3 doubles.  Per context the frames are double-buffered:
+ * frame k's device-to-host copy overlaps frame k+1's kernel. */
 int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs);
 
 /* ---- "next" rows: the two steps after render in app/Main.hs:113-123, kept on the device ---- */

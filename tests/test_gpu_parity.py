@@ -528,3 +528,14 @@ def test_standalone_supersample(tree, oracle):
     for shape in ((10, 14, 3), (7, 9, 3), (2, 2, 3), (108, 192, 3)):
         img = rng.uniform(0, 2, shape)
         assert np.array_equal(bs.supersample(img, tree), oracle.supersample(img))
+
+
+def test_render_batch_pipelined(tree):
+    """bs_render_batch: per context the frames are double-buffered (copy of frame k overlaps kernel k+1); results must equal
+    frame-by-frame renders, including mixed resolutions and an odd number of frames."""
+    cfgs = [scenes.with_res(scenes.ani_frame(i, 600), w, h) for i, (w, h) in zip((0, 150, 300, 450, 599), ((64, 36), (40, 24), (64, 36), (96, 54), (33, 17)))]
+    imgs = bs.render_batch(cfgs, [tree])
+    assert len(imgs) == 5
+    for cfg, img in zip(cfgs, imgs):
+        assert np.array_equal(img, bs.render(cfg, tree))
+    assert bs.render_batch([], [tree]) == []
