@@ -83,27 +83,41 @@ __device__ __forceinline__ double coef_strict(double h2c, double q)
     return div_rn(h2c, n5);
 }
 
-// FAST: -(1.5*h2) * |pos|^-5 from v_rsq_f64 (measured seed error 2^-24.2) + one cubic Newton step
-// (error ~ e^3 -> ~1 ulp); no sqrt, no divide.  BS_NEWTON=2 is the quadratic step (3/8 e^2 ~ 4e-15 relative,
-// one FMA cheaper) kept as an A/B knob; the shipped build uses the cubic one.
+// FAST: |pos|^-5 = q^(-5/2) from v_rsq_f64 (measured seed error 2^-24.2) and the series of the exact correction:
+// with y0 = rsq(q) and e = 1 - q*y0^2,  q^(-5/2) = y0^5 (1-e)^(-5/2) = y0^5 (1 + 5/2 e + 35/8 e^2 + O(e^3)),
+// |e| < 2^-23 so the dropped term is < 1e-20; 7 VALU + the rsq, no sqrt, no divide.  The ray's constant factor
+// -(1.5*h2) is not applied here: it is folded into the per-lane step constants of rk4_planar (PlanarK).
+// BS_NEWTON=2 keeps only the linear term (35/8 e^2 ~ 6e-14 relative, one FMA cheaper) as an A/B knob.
 #ifndef BS_NEWTON
 #define BS_NEWTON 3
 #endif
-__device__ __forceinline__ double coef_fast(double nh2c, double q)
+__device__ __forceinline__ double rm5_fast(double q, double c25, double c4375)
 {
     double y0 = __builtin_amdgcn_rsq(q);
-    double t = q * y0;
-    double e = __builtin_fma(-t, y0, 1.0);
-#if BS_NEWTON == 3
-    double p = __builtin_fma(0.375, e, 0.5);
-    double y1 = __builtin_fma(y0 * e, p, y0);
-#else
-    double y1 = __builtin_fma(y0 * e, 0.5, y0);
-#endif
-    double y2 = y1 * y1;
+    double y2 = y0 * y0;
+    double e = __builtin_fma(-q, y2, 1.0);
     double y4 = y2 * y2;
-    return (nh2c * y1) * y4;
+    double c0 = y4 * y0;
+#if BS_NEWTON == 3
+    double p = __builtin_fma(c4375, e, c25);
+    return __builtin_fma(c0 * e, p, c0);
+#else
+    return __builtin_fma(c0 * e, c25, c0);
+#endif
 }
+
+// Per-ray step constants of the FAST integrator: k = -(1.5*h2) times the step-size factors of the Nystrom form.
+// c25 = 2.5 pinned in a VGPR pair: gfx950's VOP3 takes no literal and only one SGPR operand, so with both series
+// coefficients as immediates the compiler re-materialises 2.5 with two v_mov_b32 in front of every v_fmac (8 VALU slots
+// per step); one opaque register constant makes p a single v_fma_f64 (4.375 from an opaque SGPR pair, so that no literal v_fmac form is chosen).
+struct PlanarK {
+    double hh2, hhh, h2_6, h6, c25, c4375;
+    __device__ __forceinline__ PlanarK(const TraceParams &P, double k) : hh2(k * P.hh2), hhh(k * P.hhh), h2_6(k * P.h2_6), h6(k * P.h6), c25(2.5), c4375(4.375)
+    {
+        asm volatile("" : "+v"(c25));
+        asm volatile("" : "+s"(c4375));
+    }
+};
 
 // STRICT: one classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134), the
 // reference's operation order, one IEEE operation each (this TU is compiled -ffp-contract=off).
@@ -149,25 +163,27 @@ __device__ __forceinline__ void rk4_strict(const TraceParams &P, double h2c, dou
 //   np = (p + h v) + (h^2/6)(a1 + a2 + a3)                nv = v + (h/6)(a1 + 2(a2 + a3) + a4)
 // Rounding differs from the reference's order at the 1e-16 level per operation (tests: <= 1e-10 on the
 // terminal direction, 1e-4 relative on every pixel of the BASELINE frames).
-__device__ __forceinline__ void rk4_planar(const TraceParams &P, double nh2c, double r2, double &x, double &y, double &vx, double &vy, double &r2n)
+// Here a_i = |p_i|^-5 p_i (the acceleration WITHOUT the ray's constant k = -(1.5*h2)); k is pre-multiplied into the
+// four step constants that a_i meets (K), which removes one multiply per stage.
+__device__ __forceinline__ void rk4_planar(const TraceParams &P, const PlanarK &K, double r2, double &x, double &y, double &vx, double &vy, double &r2n)
 {
-    double c = coef_fast(nh2c, r2);
+    double c = rm5_fast(r2, K.c25, K.c4375);
     double a1x = c * x, a1y = c * y;
     double qx = __builtin_fma(P.hh, vx, x), qy = __builtin_fma(P.hh, vy, y);
-    c = coef_fast(nh2c, __builtin_fma(qy, qy, qx * qx));
+    c = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
     double a2x = c * qx, a2y = c * qy;
-    qx = __builtin_fma(P.hh2, a1x, qx); qy = __builtin_fma(P.hh2, a1y, qy);
-    c = coef_fast(nh2c, __builtin_fma(qy, qy, qx * qx));
+    qx = __builtin_fma(K.hh2, a1x, qx); qy = __builtin_fma(K.hh2, a1y, qy);
+    c = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
     double a3x = c * qx, a3y = c * qy;
     double q0x = __builtin_fma(P.h, vx, x), q0y = __builtin_fma(P.h, vy, y);
-    qx = __builtin_fma(P.hhh, a2x, q0x); qy = __builtin_fma(P.hhh, a2y, q0y);
-    c = coef_fast(nh2c, __builtin_fma(qy, qy, qx * qx));
+    qx = __builtin_fma(K.hhh, a2x, q0x); qy = __builtin_fma(K.hhh, a2y, q0y);
+    c = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
     double a4x = c * qx, a4y = c * qy;
     double sx = a2x + a3x, sy = a2y + a3y;
-    x = __builtin_fma(P.h2_6, a1x + sx, q0x);
-    y = __builtin_fma(P.h2_6, a1y + sy, q0y);
-    vx = __builtin_fma(P.h6, __builtin_fma(2.0, sx, a1x) + a4x, vx);
-    vy = __builtin_fma(P.h6, __builtin_fma(2.0, sy, a1y) + a4y, vy);
+    x = __builtin_fma(K.h2_6, a1x + sx, q0x);
+    y = __builtin_fma(K.h2_6, a1y + sy, q0y);
+    vx = __builtin_fma(K.h6, __builtin_fma(2.0, sx, a1x) + a4x, vx);
+    vy = __builtin_fma(K.h6, __builtin_fma(2.0, sy, a1y) + a4y, vy);
     r2n = __builtin_fma(y, y, x * x);
 }
 
@@ -420,7 +436,7 @@ __device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, i
         double ivt = vt > 0 ? 1.0 / vt : 0.0;
         const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
         const double L = P.rcam * vt;
-        const double nh2c = -1.5 * (L * L);
+        const PlanarK K(P, -1.5 * (L * L));
         double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam, Y = p[1];
         while (steps < P.max_steps) {
             steps++;
@@ -428,7 +444,7 @@ __device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, i
             if (r2 > P.safe) { fate = 1; break; }
             double r2n;
             const double r2o = r2;
-            rk4_planar(P, nh2c, r2o, x, y, vx, vy, r2n);
+            rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
             const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
             if (P.disk_opacity != 0 && signum(Yn) != signum(Y)) {
                 double r2ave = (Yn * r2o - Y * r2n) / (Yn - Y);
@@ -506,7 +522,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
         double ivt = vt > 0 ? 1.0 / vt : 0.0;  // purely radial ray: e2 is irrelevant (y stays 0)
         const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
         const double L = P.rcam * vt;  // |pos x vel| in the plane
-        const double nh2c = -1.5 * (L * L);
+        const PlanarK K(P, -1.5 * (L * L));
         double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam;
         double Y = p[1];  // the 3-D y coordinate (disk plane normal), Y = x e1.y + y e2.y
         auto step = [&]() -> bool {
@@ -519,7 +535,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
             if (!wave_any(go)) return false;
             double r2n;
             const double r2o = r2;
-            rk4_planar(P, nh2c, r2o, x, y, vx, vy, r2n);
+            rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
             const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
             if (disk && go && !(Y * Yn > 0.0)) active = record_crossing(P, lds, Y, Yn, r2o, r2n);
             r2 = r2n;
