@@ -31,7 +31,7 @@ __device__ __forceinline__ double quadrance(double x, double y, double z) { retu
 // Wave-level "any": the ballot builtin on a bool (HIP's __any/__ballot take an int, which always costs a
 // v_cndmask + v_cmp round trip; this form is free when the operand is a fresh compare, and costs that same pair
 // only when it is a loop-carried mask).
-__device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+[[maybe_unused]] __device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 
 // libm calls as REAL calls.  ocml's f64 sin / cos / exp carry a large-argument (Payne-Hanek) path that is never taken
 // here but costs ~30 VGPRs wherever it is inlined; the shading code sits outside the stepping loop, so a call is
@@ -369,19 +369,22 @@ struct LaneLds {
 constexpr int kOverflow = 1 << 20;
 
 // findColor's disk guard (:96-98) for the step (y, r2) -> (yn, r2n).  Callers have already established that
-// y*yn is not > 0 (the only way signum y' /= signum y can hold).  Returns false if the queue overflowed.
-__device__ __forceinline__ bool record_crossing(const TraceParams &P, const LaneLds &lds, double y, double yn, double r2, double r2n)
+// y*yn <= 0 (the only way signum y' /= signum y can yield a layer).  A lane whose queue overflows is flagged and
+// keeps stepping (its result is discarded: trace_ray_simple redoes the ray).
+__device__ __forceinline__ void record_crossing(const TraceParams &P, const LaneLds &lds, double y, double yn, double r2, double r2n)
 {
     if (signum(yn) != signum(y)) {
         double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
         if (r2ave > P.in2 && r2ave < P.out2) {           // :97
             int n = lds.count();
-            if (n >= P.disk_slots) { lds.count() = kOverflow; return false; }
-            lds.slot(n) = r2ave;
-            lds.count() = n + 1;
+            if (n >= P.disk_slots) {
+                lds.count() = kOverflow;
+            } else {
+                lds.slot(n) = r2ave;
+                lds.count() = n + 1;
+            }
         }
     }
-    return true;
 }
 
 // The terminal `Bottom` layer of colorize (:84, :93-95) under whatever the disk left transparent.
@@ -478,7 +481,18 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
     const bool disk = P.disk_opacity != 0;
     lds.count() = 0;
     lds.steps() = 0;
-    bool active = live;
+    // The set of lanes still stepping is a wave-uniform 64-bit mask in scalar registers: the guards are two fresh
+    // compares whose ballots are ANDed on the scalar unit, "some lane finished" is a scalar compare, and the lane-level
+    // test (amask >> lane) & 1 is evaluated only inside the rare blocks.  (A per-lane bool costs a v_cndmask + v_cmp
+    // round trip per step to turn the loop-carried mask back into a ballot.)  Lanes that are done free-run: their values
+    // are never read, and a NaN state cannot enter the crossing block (y*yn <= 0 is false for NaN; the reference's
+    // signum test passes NaN on to an r2ave that fails both radius compares, i.e. no layer either way).
+    // "No disk" is folded into the crossing threshold (a product is never <= -inf short of overflow), held in a VGPR
+    // pair: as a scalar flag it was the one value the allocator spilled and re-read (2 v_readlane) in every step.
+    double cross_thr = disk ? 0.0 : -__builtin_inf();
+    asm volatile("" : "+v"(cross_thr));
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned long long amask = __builtin_amdgcn_ballot_w64(live);
     int it = 0;  // iterations of colorize' entered so far (wave-uniform)
     double r2t;  // r^2 fed to the terminating findColor call (read back from LDS)
 
@@ -490,18 +504,24 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
         // one iteration of colorize'; returns false once no lane of the wavefront is stepping
         auto step = [&]() -> bool {
             // findColor guards on the PRE-step position (:93-95); the cap is ours (the reference has none)
-            const bool go = active && it < P.max_steps && !(r2 < 1.0) && !(r2 > P.safe);
-            if (active && !go) {  // guard fired: snapshot the state fed to the terminating findColor call
+            unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
+            if (!(it < P.max_steps)) go = 0;
+            if (go != amask) {  // a guard fired somewhere in the wavefront (rare, wave-uniform branch)
+                if (((amask & ~go) >> lane) & 1) {  // this lane: snapshot the state fed to the terminating findColor call
 #pragma unroll
-                for (int i = 0; i < 3; i++) { lds.snap(i) = v[i]; lds.snap(3 + i) = p[i]; }
-                lds.snap(6) = r2;
-                lds.steps() = it < P.max_steps ? it + 1 : it;
+                    for (int i = 0; i < 3; i++) { lds.snap(i) = v[i]; lds.snap(3 + i) = p[i]; }
+                    lds.snap(6) = r2;
+                    lds.steps() = it < P.max_steps ? it + 1 : it;
+                }
+                amask = go;
+                if (go == 0) return false;
             }
-            active = go;
-            if (!wave_any(go)) return false;
             double nv[3], np[3], r2n;
             rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
-            if (disk && go && !(p[1] * np[1] > 0.0)) active = record_crossing(P, lds, p[1], np[1], r2, r2n);
+            if (p[1] * np[1] <= cross_thr) {
+                asm volatile("" ::: "memory");  // keeps the lane test below in this rare block (else it is folded into the hot branch)
+                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n);
+            }
 #pragma unroll
             for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
             r2 = r2n;
@@ -509,7 +529,8 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
             return true;
         };
         // unrolled by two: the state ping-pongs between two register sets instead of being copied back at the latch
-        while (step() && step()) {}
+        if (amask != 0)  // a wavefront with no ray at all (records kernel tail) must not enter: step() only returns false on a CHANGE of amask
+            while (step() && step()) {}
 #pragma unroll
         for (int i = 0; i < 3; i++) { v[i] = lds.snap(i); p[i] = lds.snap(3 + i); }
         r2t = lds.snap(6);
@@ -526,24 +547,31 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
         double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam;
         double Y = p[1];  // the 3-D y coordinate (disk plane normal), Y = x e1.y + y e2.y
         auto step = [&]() -> bool {
-            const bool go = active && it < P.max_steps && !(r2 < 1.0) && !(r2 > P.safe);
-            if (active && !go) {
-                lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = vx; lds.snap(3) = vy; lds.snap(4) = r2;
-                lds.steps() = it < P.max_steps ? it + 1 : it;
+            unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
+            if (!(it < P.max_steps)) go = 0;
+            if (go != amask) {
+                if (((amask & ~go) >> lane) & 1) {
+                    lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = vx; lds.snap(3) = vy; lds.snap(4) = r2;
+                    lds.steps() = it < P.max_steps ? it + 1 : it;
+                }
+                amask = go;
+                if (go == 0) return false;
             }
-            active = go;
-            if (!wave_any(go)) return false;
             double r2n;
             const double r2o = r2;
             rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
             const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
-            if (disk && go && !(Y * Yn > 0.0)) active = record_crossing(P, lds, Y, Yn, r2o, r2n);
+            if (Y * Yn <= cross_thr) {
+                asm volatile("" ::: "memory");
+                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, Y, Yn, r2o, r2n);
+            }
             r2 = r2n;
             Y = Yn;
             ++it;
             return true;
         };
-        while (step() && step()) {}
+        if (amask != 0)  // a wavefront with no ray at all (records kernel tail) must not enter: step() only returns false on a CHANGE of amask
+            while (step() && step()) {}
         // the snapshot is the PRE-step planar state of the terminating iteration (guards precede rk4)
         x = lds.snap(0); y = lds.snap(1); vx = lds.snap(2); vy = lds.snap(3); r2t = lds.snap(4);
 #pragma unroll

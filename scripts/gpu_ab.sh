@@ -3,18 +3,18 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -15) > gpurun_out/pytest_gpu.log 2>&1
+(timeout ${TEST_TIMEOUT:-300} python -m pytest tests -q -m gpu -x 2>&1 | tail -15) > gpurun_out/pytest_gpu.log 2>&1
 rm -f gpurun_out/ab.txt
 for round in 1 2 3; do
   for lib in ${LIBS:-blackstar_amd/libblackstar_gpu.so variants_prev.so}; do
     for m in fast strict; do
       echo -n "$round $lib $m " >> gpurun_out/ab.txt
-      BLACKSTAR_LIB=$PWD/$lib python scripts/prof_frame.py --mode $m --frames 8 | grep -o "'kernel_ms': [0-9.]*" >> gpurun_out/ab.txt
+      BLACKSTAR_LIB=$PWD/$lib timeout 120 python scripts/prof_frame.py --mode $m --frames 8 | grep -o "'kernel_ms': [0-9.]*" >> gpurun_out/ab.txt
     done
   done
 done
-python bench.py --steps 20 --warmup 3 --mode strict --cpu-seconds 0 > gpurun_out/bench_strict.json 2> gpurun_out/bench_strict.err
-python bench.py --steps 20 --warmup 3 --mode fast --cpu-seconds 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err
+timeout 300 python bench.py --steps 20 --warmup 3 --mode strict --cpu-seconds 0 > gpurun_out/bench_strict.json 2> gpurun_out/bench_strict.err
+timeout 300 python bench.py --steps 20 --warmup 3 --mode fast --cpu-seconds 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err
 cat gpurun_out/pytest_gpu.log; cat gpurun_out/ab.txt
 python - <<'PY'
 import json
