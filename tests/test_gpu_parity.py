@@ -539,3 +539,21 @@ def test_render_batch_pipelined(tree):
     for cfg, img in zip(cfgs, imgs):
         assert np.array_equal(img, bs.render(cfg, tree))
     assert bs.render_batch([], [tree]) == []
+
+
+@pytest.mark.parametrize("mode", [_lib.BS_MODE_STRICT, _lib.BS_MODE_FAST])
+@pytest.mark.parametrize("n", [1, 63, 65, 129, 257])
+def test_trace_rays_counts_that_leave_wavefronts_empty(n, mode, tree, oracle, oracle_index):
+    """The records kernel runs 256-lane workgroups: n = 1, 65, ... leaves wavefronts with no ray at all, which must fall
+    straight through the stepping loop (a build whose loop only ended on a CHANGE of the active mask spun forever here)."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 96, 54)
+    rng = np.random.default_rng(n)
+    ys, xs = rng.integers(0, 108, n), rng.integers(0, 192, n)
+    tree.set_mode(mode)
+    try:
+        rec = bs.trace_rays(cfg, tree, ys, xs)
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    orc = oracle.trace_rays(cfg, oracle_index, ys, xs)
+    assert np.array_equal(rec["steps"], orc["steps"]) and np.array_equal(rec["fate"], orc["fate"])
+    assert np.array_equal(rec["disk_hits"], orc["disk_hits"])
