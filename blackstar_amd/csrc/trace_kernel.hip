@@ -155,6 +155,50 @@ __device__ __forceinline__ void rk4_strict(const TraceParams &P, double h2c, dou
     r2n = quadrance(np[0], np[1], np[2]);
 }
 
+// Orbital-plane frame of a ray (FAST).  With e1 = pos/|pos| (the camera direction, wave-uniform, from the host) and
+// e2 = the unit vector along the part of vel orthogonal to e1, the 3-D y coordinate (the disk plane's normal) of a point
+// x e1 + y e2 is Y = n1 x + n2 y, (n1, n2) = (e1.y, e2.y).  The frame used for stepping is (e1, e2) ROTATED in the plane
+// so that its first axis lies along the line in which the disk plane cuts the orbital plane:
+//   f1 = cs e1 - sn e2,  f2 = sn e1 + cs e2,  (cs, sn) = (n2, n1)/m,  m = |(n1, n2)|     =>     Y = m * y'  with m > 0.
+// The sign of Y is then the sign of the planar coordinate y' itself: the stepping loop needs no dot product to watch for
+// disk crossings, and r2ave = (Yn r2 - Y r2n)/(Yn - Y) is unchanged by the common factor m.  A camera in the disk plane
+// has n1 = 0 exactly, hence sn = 0 and y' = 0 exactly, like Y.  If the orbital plane IS the disk plane (m = 0, Y = 0 along
+// the whole ray) there is never a crossing (signum 0 == signum 0, :96): `in_disk_plane`.
+struct PlanarFrame {
+    double f1[3], f2[3];
+    double x, y, vx, vy;  // initial planar state
+    double k;             // -(1.5 * h2), h2 = |pos x vel|^2
+    bool in_disk_plane;
+    __device__ __forceinline__ PlanarFrame(const TraceParams &P, const double v[3])
+    {
+        const double vr = __builtin_fma(v[2], P.e1[2], __builtin_fma(v[1], P.e1[1], v[0] * P.e1[0]));
+        const double w[3] = {__builtin_fma(-vr, P.e1[0], v[0]), __builtin_fma(-vr, P.e1[1], v[1]), __builtin_fma(-vr, P.e1[2], v[2])};
+        const double vt = __builtin_sqrt(quadrance(w[0], w[1], w[2]));
+        const double ivt = vt > 0 ? 1.0 / vt : 0.0;  // purely radial ray: e2 = 0, the motion stays on the e1 axis
+        const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
+        const double n1 = P.e1[1], n2 = e2[1];
+        const double m = __builtin_sqrt(__builtin_fma(n2, n2, n1 * n1));
+        in_disk_plane = !(m > 0);
+        const double im = in_disk_plane ? 0.0 : 1.0 / m;
+        const double cs = in_disk_plane ? 1.0 : n2 * im, sn = n1 * im;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            f1[i] = __builtin_fma(cs, P.e1[i], -(sn * e2[i]));
+            f2[i] = __builtin_fma(sn, P.e1[i], cs * e2[i]);
+        }
+        x = cs * P.rcam; y = sn * P.rcam;                  // pos = rcam e1
+        vx = __builtin_fma(cs, vr, -(sn * vt));            // vel = vr e1 + vt e2
+        vy = __builtin_fma(sn, vr, cs * vt);
+        const double L = P.rcam * vt;                      // |pos x vel| in the plane
+        k = -1.5 * (L * L);
+    }
+    __device__ __forceinline__ void to_space(double px, double py, double out[3]) const
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++) out[i] = __builtin_fma(px, f1[i], py * f2[i]);
+    }
+};
+
 // FAST: the same RK4 map evaluated in the ray's orbital plane.  f(pos) = c(|pos|) pos is rotation-covariant,
 // so every RK4 stage stays in span{pos, vel}: with an orthonormal basis (e1, e2) of that plane the 6-vector
 // map reduces EXACTLY (in real arithmetic) to a 4-vector one -- 2/3 of the vector work.  The stages are also
@@ -163,27 +207,29 @@ __device__ __forceinline__ void rk4_strict(const TraceParams &P, double h2c, dou
 //   np = (p + h v) + (h^2/6)(a1 + a2 + a3)                nv = v + (h/6)(a1 + 2(a2 + a3) + a4)
 // Rounding differs from the reference's order at the 1e-16 level per operation (tests: <= 1e-10 on the
 // terminal direction, 1e-4 relative on every pixel of the BASELINE frames).
-// Here a_i = |p_i|^-5 p_i (the acceleration WITHOUT the ray's constant k = -(1.5*h2)); k is pre-multiplied into the
-// four step constants that a_i meets (K), which removes one multiply per stage.
+// With c_i = |p_i|^-5 (the ray's constant k = -(1.5*h2) is pre-multiplied into the four step constants K), the
+// accelerations a_i = k c_i p_i are never formed: the two weighted sums the update needs are accumulated with FMAs,
+//   R = c2 p2 + c3 p3,   S = c1 p + R  (= (a1+a2+a3)/k),   T = S + R + c4 p4  (= (a1+2a2+2a3+a4)/k),
+// p3 = p2 + (K.hh2 c1) p and p4 = (p + h v) + K.hhh (c2 p2): 23 VALU for the linear algebra of a step (29 with a_i formed).
 __device__ __forceinline__ void rk4_planar(const TraceParams &P, const PlanarK &K, double r2, double &x, double &y, double &vx, double &vy, double &r2n)
 {
-    double c = rm5_fast(r2, K.c25, K.c4375);
-    double a1x = c * x, a1y = c * y;
-    double qx = __builtin_fma(P.hh, vx, x), qy = __builtin_fma(P.hh, vy, y);
-    c = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
-    double a2x = c * qx, a2y = c * qy;
-    qx = __builtin_fma(K.hh2, a1x, qx); qy = __builtin_fma(K.hh2, a1y, qy);
-    c = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
-    double a3x = c * qx, a3y = c * qy;
-    double q0x = __builtin_fma(P.h, vx, x), q0y = __builtin_fma(P.h, vy, y);
-    qx = __builtin_fma(K.hhh, a2x, q0x); qy = __builtin_fma(K.hhh, a2y, q0y);
-    c = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
-    double a4x = c * qx, a4y = c * qy;
-    double sx = a2x + a3x, sy = a2y + a3y;
-    x = __builtin_fma(K.h2_6, a1x + sx, q0x);
-    y = __builtin_fma(K.h2_6, a1y + sy, q0y);
-    vx = __builtin_fma(K.h6, __builtin_fma(2.0, sx, a1x) + a4x, vx);
-    vy = __builtin_fma(K.h6, __builtin_fma(2.0, sy, a1y) + a4y, vy);
+    const double c1 = rm5_fast(r2, K.c25, K.c4375);
+    double qx = __builtin_fma(P.hh, vx, x), qy = __builtin_fma(P.hh, vy, y);  // p2
+    const double c2 = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
+    double Rx = c2 * qx, Ry = c2 * qy;
+    const double kc1 = K.hh2 * c1;
+    qx = __builtin_fma(kc1, x, qx); qy = __builtin_fma(kc1, y, qy);          // p3
+    const double c3 = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
+    const double q0x = __builtin_fma(P.h, vx, x), q0y = __builtin_fma(P.h, vy, y);
+    const double ux = __builtin_fma(K.hhh, Rx, q0x), uy = __builtin_fma(K.hhh, Ry, q0y);  // p4
+    Rx = __builtin_fma(c3, qx, Rx); Ry = __builtin_fma(c3, qy, Ry);
+    const double c4 = rm5_fast(__builtin_fma(uy, uy, ux * ux), K.c25, K.c4375);
+    const double Sx = __builtin_fma(c1, x, Rx), Sy = __builtin_fma(c1, y, Ry);
+    const double Tx = __builtin_fma(c4, ux, Sx + Rx), Ty = __builtin_fma(c4, uy, Sy + Ry);
+    x = __builtin_fma(K.h2_6, Sx, q0x);
+    y = __builtin_fma(K.h2_6, Sy, q0y);
+    vx = __builtin_fma(K.h6, Tx, vx);
+    vy = __builtin_fma(K.h6, Ty, vy);
     r2n = __builtin_fma(y, y, x * x);
 }
 
@@ -433,33 +479,24 @@ __device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, i
             r2 = r2n;
         }
     } else {
-        double vr = __builtin_fma(v[2], P.e1[2], __builtin_fma(v[1], P.e1[1], v[0] * P.e1[0]));
-        double w[3] = {__builtin_fma(-vr, P.e1[0], v[0]), __builtin_fma(-vr, P.e1[1], v[1]), __builtin_fma(-vr, P.e1[2], v[2])};
-        double vt = __builtin_sqrt(quadrance(w[0], w[1], w[2]));
-        double ivt = vt > 0 ? 1.0 / vt : 0.0;
-        const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
-        const double L = P.rcam * vt;
-        const PlanarK K(P, -1.5 * (L * L));
-        double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam, Y = p[1];
+        const PlanarFrame F(P, v);
+        const PlanarK K(P, F.k);
+        double x = F.x, y = F.y, vx = F.vx, vy = F.vy, r2 = __builtin_fma(y, y, x * x);
         while (steps < P.max_steps) {
             steps++;
             if (r2 < 1.0) { fate = 0; break; }
             if (r2 > P.safe) { fate = 1; break; }
             double r2n;
-            const double r2o = r2;
+            const double r2o = r2, yo = y;
             rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
-            const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
-            if (P.disk_opacity != 0 && signum(Yn) != signum(Y)) {
-                double r2ave = (Yn * r2o - Y * r2n) / (Yn - Y);
+            if (P.disk_opacity != 0 && !F.in_disk_plane && signum(y) != signum(yo)) {
+                double r2ave = (y * r2o - yo * r2n) / (y - yo);
                 if (r2ave > P.in2 && r2ave < P.out2) { shade_disk(P, r2ave, rgba); ncross++; }
             }
             r2 = r2n;
-            Y = Yn;
         }
-        for (int i = 0; i < 3; i++) {
-            v[i] = __builtin_fma(vx, P.e1[i], vy * e2[i]);
-            p[i] = __builtin_fma(x, P.e1[i], y * e2[i]);
-        }
+        F.to_space(vx, vy, v);
+        F.to_space(x, y, p);
     }
     for (int i = 0; i < 3; i++) { out[i] = v[i]; out[3 + i] = p[i]; }
     for (int i = 0; i < 4; i++) out[6 + i] = rgba[i];
@@ -535,17 +572,10 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
         for (int i = 0; i < 3; i++) { v[i] = lds.snap(i); p[i] = lds.snap(3 + i); }
         r2t = lds.snap(6);
     } else {
-        // Orbital-plane frame: e1 = pos/|pos| (the camera direction, wave-uniform, from the host),
-        // e2 = the unit vector along the part of vel orthogonal to e1 (per lane).
-        double vr = __builtin_fma(v[2], P.e1[2], __builtin_fma(v[1], P.e1[1], v[0] * P.e1[0]));
-        double w[3] = {__builtin_fma(-vr, P.e1[0], v[0]), __builtin_fma(-vr, P.e1[1], v[1]), __builtin_fma(-vr, P.e1[2], v[2])};
-        double vt = __builtin_sqrt(quadrance(w[0], w[1], w[2]));
-        double ivt = vt > 0 ? 1.0 / vt : 0.0;  // purely radial ray: e2 is irrelevant (y stays 0)
-        const double e2[3] = {w[0] * ivt, w[1] * ivt, w[2] * ivt};
-        const double L = P.rcam * vt;  // |pos x vel| in the plane
-        const PlanarK K(P, -1.5 * (L * L));
-        double x = P.rcam, y = 0.0, vx = vr, vy = vt, r2 = P.rcam * P.rcam;
-        double Y = p[1];  // the 3-D y coordinate (disk plane normal), Y = x e1.y + y e2.y
+        const PlanarFrame F(P, v);
+        const PlanarK K(P, F.k);
+        if (F.in_disk_plane) cross_thr = -__builtin_inf();
+        double x = F.x, y = F.y, vx = F.vx, vy = F.vy, r2 = __builtin_fma(y, y, x * x);
         auto step = [&]() -> bool {
             unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
             if (!(it < P.max_steps)) go = 0;
@@ -558,15 +588,13 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
                 if (go == 0) return false;
             }
             double r2n;
-            const double r2o = r2;
+            const double r2o = r2, yo = y;
             rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
-            const double Yn = __builtin_fma(x, P.e1[1], y * e2[1]);
-            if (Y * Yn <= cross_thr) {
+            if (yo * y <= cross_thr) {  // the planar y IS the disk-normal coordinate up to a positive factor (PlanarFrame)
                 asm volatile("" ::: "memory");
-                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, Y, Yn, r2o, r2n);
+                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, yo, y, r2o, r2n);
             }
             r2 = r2n;
-            Y = Yn;
             ++it;
             return true;
         };
@@ -574,11 +602,8 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
             while (step() && step()) {}
         // the snapshot is the PRE-step planar state of the terminating iteration (guards precede rk4)
         x = lds.snap(0); y = lds.snap(1); vx = lds.snap(2); vy = lds.snap(3); r2t = lds.snap(4);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            v[i] = __builtin_fma(vx, P.e1[i], vy * e2[i]);
-            p[i] = __builtin_fma(x, P.e1[i], y * e2[i]);
-        }
+        F.to_space(vx, vy, v);
+        F.to_space(x, y, p);
     }
     int steps = lds.steps();
     int ncross = lds.count();
