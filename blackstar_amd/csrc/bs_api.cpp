@@ -45,7 +45,8 @@ struct bs_ctx {
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;
     bs::StarColor *d_colors = nullptr;
-    double *d_splits = nullptr;
+    uint32_t *d_cell_start = nullptr;
+    size_t n_entries = 0;  // stars + border duplicates in the direction grid
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;  // pinned
     double *d_img = nullptr;                   // scratch image for bs_render (host-output variant)
@@ -82,11 +83,10 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
         p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
         p.stagger_cycles = tiles >= 8 * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs many tiles
     }
-    p.n_stars = (int32_t)ctx->n_stars;
-    p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
+    p.n_entries = (int32_t)ctx->n_entries;
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
-    p.splits = ctx->d_splits;
+    p.cell_start = ctx->d_cell_start;
     p.counters = ctx->d_counters;
     return BS_OK;
 }
@@ -168,8 +168,9 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     }
     std::vector<bs::StarNode> nodes;
     std::vector<bs::StarColor> colors;
-    std::vector<double> splits;
-    bs::build_star_index(stars, n_stars, nodes, colors, splits);
+    std::vector<uint32_t> cell_start;
+    bs::build_star_index(stars, n_stars, nodes, colors, cell_start);
+    ctx->n_entries = nodes.size();
     auto ok = [&](hipError_t r, const char *what) {
         if (r == hipSuccess) return true;
         fail(BS_EDEVICE, std::string(what) + ": " + hipGetErrorString(r));
@@ -183,10 +184,10 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
                 ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
                 ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev1), "hipEventCreate") &&
                 ok(hipEventCreate(&ctx->ev2), "hipEventCreate") &&
-                ok(hipMalloc((void **)&ctx->d_nodes, nodes.size() * sizeof(bs::StarNode)), "hipMalloc nodes") &&
-                ok(hipMalloc((void **)&ctx->d_colors, colors.size() * sizeof(bs::StarColor)), "hipMalloc colors") &&
-                ok(hipMalloc((void **)&ctx->d_splits, splits.size() * sizeof(double)), "hipMalloc splits") &&
-                ok(hipMemcpy(ctx->d_splits, splits.data(), splits.size() * sizeof(double), hipMemcpyHostToDevice), "upload splits") &&
+                ok(hipMalloc((void **)&ctx->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(bs::StarNode)), "hipMalloc nodes") &&
+                ok(hipMalloc((void **)&ctx->d_colors, std::max<size_t>(1, colors.size()) * sizeof(bs::StarColor)), "hipMalloc colors") &&
+                ok(hipMalloc((void **)&ctx->d_cell_start, cell_start.size() * sizeof(uint32_t)), "hipMalloc cell_start") &&
+                ok(hipMemcpy(ctx->d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "upload cell_start") &&
                 ok(hipMalloc((void **)&ctx->d_counters, bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
                 ok(hipHostMalloc((void **)&ctx->h_counters, bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
                 ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
@@ -207,7 +208,7 @@ void bs_destroy(bs_ctx *ctx)
         (void)hipDeviceSynchronize();
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
-        if (ctx->d_splits) (void)hipFree(ctx->d_splits);
+        if (ctx->d_cell_start) (void)hipFree(ctx->d_cell_start);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_img) (void)hipFree(ctx->d_img);
         if (ctx->d_img2) (void)hipFree(ctx->d_img2);
@@ -507,11 +508,10 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
     p.star_intensity = intensity;
     p.star_saturation = saturation;
     p.star_a = std::log(2.0) / 50;
-    p.n_stars = (int32_t)ctx->n_stars;
-    p.lds_nodes = (int32_t)std::min<size_t>(ctx->n_stars, bs::kLdsNodes);
+    p.n_entries = (int32_t)ctx->n_entries;
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
-    p.splits = ctx->d_splits;
+    p.cell_start = ctx->d_cell_start;
     HIP_TRY(hipSetDevice(ctx->device));
     double *d = nullptr;
     int32_t *dh = nullptr;

@@ -11,29 +11,42 @@
 
 namespace bs {
 
-// One node of the flat k-d array: 32 B, loaded as two dwordx4 (or one ds_read_b128 pair from LDS).
-// Layout: 1-based Eytzinger order of a left-balanced k-d tree (children of i are 2i, 2i+1; the split
-// axis of a node at depth d is d % 3, mirroring kdt's `cycle (pointAsList q)`), so the top L levels are
-// the first 2^L - 1 entries and can be staged in LDS as one contiguous block.
+// One entry of the star grid: 32 B, loaded as two dwordx4.
 struct alignas(32) StarNode {
     double x, y, z;
     int32_t mag;  // magnitude * 100 (StarMap.hs:57)
     int32_t id;   // index into the caller's star array (for tests / canonical ordering)
 };
 
-struct alignas(16) StarColor {
-    double hue, sat;  // starColor' (StarMap.hs:61-72), indexed like StarNode
+// What a HIT needs besides d^2 and mag, indexed like StarNode: the hue enters toPixelRGB (PixelHSI h s i) only through
+// cos a / cos b of its sector (massiv-io), which do not depend on the ray -- the host evaluates the two
+// cosines once per star (libm, like the reference) and the kernel keeps the reference's i + is*ca/cb arithmetic.
+struct alignas(32) StarColor {
+    double ca, cb;   // cos a, cos b of the hue's sector
+    double sat;      // starColor' saturation (StarMap.hs:61-72), before the scene's starSaturation factor
+    int32_t sector;  // 0, 1, 2: which of (r,g,b) is `first`
+    int32_t pad_;
 };
 
-// The traversal only ever needs a node's SPLIT coordinate (8 B); they live in their own Eytzinger-ordered f64
-// array (3.8 MB for 470 k stars -> resident in each XCD's 4 MB L2, where the 15 MB node array is not), and the
-// top kLdsLevels levels of it are staged in LDS.  The full 32-B node is read only when the query ball reaches
-// the node's splitting plane.
-#ifndef BS_LDS_LEVELS
-#define BS_LDS_LEVELS 10
-#endif
-constexpr int kLdsLevels = BS_LDS_LEVELS;                      // top levels of the split array staged in LDS
-constexpr int kLdsNodes = (1 << kLdsLevels) - 1;    // 1023 splits * 8 B = 8184 B per workgroup (4 workgroups/CU with the per-lane scratch)
+// ---- star index: a cube-map grid of directions -------------------------------------------------------------------
+// The reference queries kdt's `inRadius tree (3*w) nvel` (StarMap.hs:104): all stars p with |p - nvel|^2 <= r^2,
+// r = 0.0015.  Only the SET matters, so the index is free to be anything that returns that set.  A star within chord
+// distance r of a unit vector q lies within the angle asin(r) of q's direction, whatever the star's own length, so
+// the index bins DIRECTIONS: the cube face of the largest |component| (face = 2*axis + (component < 0)) and the
+// gnomonic coordinates u = a/|m|, v = b/|m| of the other two components (cyclic order), cut into kGridG x kGridG cells
+// per face, cell rows contiguous in u.  On a face (|u|,|v| <= 1 + kGridDelta) the coordinate u moves by at most
+// sqrt(1+u^2)*sqrt(1+u^2+v^2) <= 2.47 per radian, so everything within asin(r) of q projects into the box
+// [u-D, u+D] x [v-D, v+D], D = kGridDelta = 0.0039 (2.6 r: 4 % slack for curvature and the kernel's approximate
+// reciprocal).  Stars whose box neighbourhood reaches over a face edge are ALSO listed in that neighbouring face (in
+// its clamped border cells), so a query only ever reads its own face: at most 2 x 2 cells (2 D <= cell width), two
+// contiguous runs of entries.  6 * 256^2 cell offsets = 1.5 MB stay in every XCD's L2; a lookup is ~40 VALU of
+// addressing plus ~12 per candidate star (about 5), against ~25 dependent node visits in a k-d descent.
+constexpr double kStarW = 0.0005;                 // StarMap.hs:103
+constexpr double kStarRadius = 3 * kStarW;        // StarMap.hs:104
+constexpr int kGridG = 256;                       // cells per face edge: width 2/256 = 0.0078125 >= 2 * kGridDelta
+constexpr double kGridDelta = 0.0039;
+constexpr int kGridCells = 6 * kGridG * kGridG;
+constexpr double kOriginReach = 0.0016;           // > kStarRadius + 1e-6: stars a non-normalised (|v|^2 <= 1e-12) query can reach
 constexpr int kCounters = 8;                        // steps, capped, horizon, escaped, disk_hits, star_hits, wave_iters, tile queue head
 
 // Everything the trace kernel needs, passed by value as the kernel argument (lands in SGPRs / kernarg).
@@ -54,15 +67,14 @@ struct TraceParams {
     int32_t ss;                  // supersampling
     int32_t out_w, out_h;
     int32_t max_steps;
-    int32_t n_stars;
-    int32_t lds_nodes;           // min(n_stars, kLdsNodes)
+    int32_t n_entries;           // entries in nodes/colors (stars + border duplicates)
     int32_t grid_blocks;         // persistent workgroups launched (<= 4 per CU)
     int32_t stagger_cycles;      // first-tile phase offset per SIMD slot, in shader cycles (0 = off)
     int32_t blocks_per_slot;     // workgroups per residency slot (= CUs): workgroup b sits in slot b / blocks_per_slot
     int32_t disk_slots;          // LDS crossing-queue depth in use (<= 4; tests shrink it to force the overflow path)
-    const StarNode *nodes;       // device, n_stars + 1 entries (entry 0 unused)
-    const double *splits;        // device, n_stars + 1 entries: the coordinate of node i along axis depth(i) % 3
-    const StarColor *colors;     // device, n_stars + 1 entries
+    const StarNode *nodes;       // device, n_entries, sorted by cell
+    const StarColor *colors;     // device, n_entries
+    const uint32_t *cell_start;  // device, kGridCells + 2: entries of cell c are [cell_start[c], cell_start[c+1]); cell kGridCells = origin list
     double *out;                 // device, out_h * out_w * 3
     unsigned long long *counters;  // device, kCounters
 };
@@ -72,8 +84,16 @@ void host_hsi_to_rgb(double hue, double s, double i, double rgb[3], bool *ok);
 // Fills every derived field of TraceParams except the device pointers.  Returns false + message on bad input.
 bool derive_params(const bs_config &cfg, TraceParams &p, std::string &err);
 
-// star_index.cpp: build the 1-based Eytzinger left-balanced k-d array from the caller's stars.
-void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors, std::vector<double> &splits);
+// star_index.cpp: bin the caller's stars into the cube-map grid (entries sorted by cell, border duplicates included).
+void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors, std::vector<uint32_t> &cell_start);
+// The cell coordinate of a gnomonic coordinate t (shared by the builder and, with the same operations, the kernel).
+inline int grid_cell(double t)
+{
+    double c = (t + 1.0) * (0.5 * kGridG);
+    if (!(c > 0.0)) return 0;
+    if (c >= (double)kGridG) return kGridG - 1;
+    return (int)c;
+}
 
 // trace_kernel.hip launchers (enqueue on `stream`, no sync).
 int launch_trace(const TraceParams &p, int mode, void *stream);

@@ -1,15 +1,14 @@
-// star_index.cpp -- flatten the star set into a pointer-free k-d array for the GPU.
+// star_index.cpp -- bin the star set into the cube-map direction grid the kernel queries (bs_internal.h).
 //
-// The reference keeps stars in kdt's `KdMap` (src/StarMap.hs:26,91: build toList), a balanced static k-d
-// tree of boxed nodes whose split axis cycles x,y,z with depth, and queries it with `inRadius`
-// (src/StarMap.hs:104).  Only the SET of stars within the radius affects the result, so the GPU index is
-// free to choose its own node order: a left-balanced (complete) tree stored in 1-based Eytzinger order.
-//   * children of node i are 2i and 2i+1, no pointers, no per-node axis (axis = depth % 3);
-//   * nodes 1..2^L-1 are exactly the top L levels -> one contiguous block the kernel stages in LDS;
-//   * a complete tree makes "index <= n" the only existence test.
+// The reference keeps stars in kdt's `KdMap` (src/StarMap.hs:26,91: build toList) and queries it with
+// `inRadius tree (3*w) nvel` (src/StarMap.hs:104).  Only the SET of stars within the radius affects the result, so
+// the GPU index is free to choose its own structure: here a counting sort of the stars by (face, v cell, u cell) of
+// their direction, plus a copy of every star into each neighbouring face whose border cells its neighbourhood can
+// reach.  Entries of one cell are ordered by the caller's star index, so the result does not depend on input order
+// beyond that.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
-#include <numeric>
 
 #include "bs_internal.h"
 
@@ -17,69 +16,56 @@ namespace bs {
 
 namespace {
 
-// Size of the left subtree of a complete binary tree with n nodes.
-size_t left_subtree_size(size_t n)
+// cos a, cos b and the sector of toPixelRGB (PixelHSI h' s i) for hue h' in [0,1)  (massiv-io):
+// the same expressions as host_hsi_to_rgb (host_math.cpp), evaluated once per star.
+StarColor star_color(double hue, double sat)
 {
-    if (n <= 1) return 0;
-    size_t h = 0;  // floor(log2(n))
-    while ((size_t(2) << h) <= n) h++;
-    size_t full = (size_t(1) << h) - 1;       // nodes above the last level
-    size_t last = n - full;                   // nodes on the last level
-    size_t half = size_t(1) << (h - 1);       // capacity of the left half of the last level
-    return (half - 1) + std::min(last, half);
+    const double pi = 3.141592653589793;
+    const double h = hue * 2 * pi;
+    const int k = (h < 2 * pi / 3) ? 0 : ((h < 4 * pi / 3) ? 1 : 2);
+    const double a = k == 0 ? h : (k == 1 ? h - 2 * pi / 3 : h - 4 * pi / 3);
+    const double b = k == 0 ? pi / 3 - h : (k == 1 ? h + pi : 2 * pi - pi / 3 - h);
+    return StarColor{std::cos(a), std::cos(b), sat, k, 0};
 }
 
-struct Builder {
-    const bs_star *stars;
-    std::vector<uint32_t> order;
-    std::vector<StarNode> *nodes;
-    std::vector<StarColor> *colors;
-
-    double coord(uint32_t id, int axis) const { return axis == 0 ? stars[id].x : (axis == 1 ? stars[id].y : stars[id].z); }
-
-    void build(size_t node, size_t lo, size_t hi, int axis)
-    {
-        // iterative on the right child to bound recursion depth to log2(n)
-        while (lo < hi) {
-            size_t n = hi - lo;
-            size_t mid = lo + left_subtree_size(n);
-            std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](uint32_t a, uint32_t b) {
-                double ca = coord(a, axis), cb = coord(b, axis);
-                return ca < cb || (ca == cb && a < b);  // deterministic under ties
-            });
-            uint32_t id = order[mid];
-            StarNode &nd = (*nodes)[node];
-            nd.x = stars[id].x; nd.y = stars[id].y; nd.z = stars[id].z;
-            nd.mag = stars[id].mag;
-            nd.id = (int32_t)id;
-            (*colors)[node] = StarColor{stars[id].hue, stars[id].sat};
-            int next = axis == 2 ? 0 : axis + 1;
-            build(2 * node, lo, mid, next);
-            node = 2 * node + 1;
-            lo = mid + 1;
-            axis = next;
-        }
-    }
+struct Placement {
+    uint32_t cell, star;
 };
 
 }  // namespace
 
-void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors, std::vector<double> &splits)
+void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nodes, std::vector<StarColor> &colors, std::vector<uint32_t> &cell_start)
 {
-    nodes.assign(n + 1, StarNode{0, 0, 0, 0, -1});
-    colors.assign(n + 1, StarColor{0, 0});
-    splits.assign(n + 1, 0.0);
-    if (n == 0) return;
-    Builder b{stars, {}, &nodes, &colors};
-    b.order.resize(n);
-    std::iota(b.order.begin(), b.order.end(), 0u);
-    b.build(1, 0, n, 0);
-    // split coordinate of node i = its point's coordinate along axis depth(i) % 3, depth(i) = floor(log2 i)
-    for (size_t i = 1; i <= n; i++) {
-        int depth = 0;
-        for (size_t t = i; t > 1; t >>= 1) depth++;
-        const StarNode &nd = nodes[i];
-        splits[i] = depth % 3 == 0 ? nd.x : (depth % 3 == 1 ? nd.y : nd.z);
+    std::vector<Placement> placed;
+    placed.reserve(n + n / 16);
+    const double lim = 1.0 + kGridDelta;
+    for (size_t i = 0; i < n; i++) {
+        const double d[3] = {stars[i].x, stars[i].y, stars[i].z};
+        if (!(std::isfinite(d[0]) && std::isfinite(d[1]) && std::isfinite(d[2]))) continue;  // can never be within the radius
+        // linear's normalize leaves a vector with |v|^2 <= 1e-12 as it is, so such a (degenerate) query is NOT a unit
+        // vector: it can only reach stars within the radius of the origin.  Those go to one extra list after the cells.
+        if ((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] <= kOriginReach * kOriginReach) placed.push_back(Placement{(uint32_t)kGridCells, (uint32_t)i});
+        for (int f = 0; f < 6; f++) {
+            const int a = f >> 1;
+            const double m = (f & 1) ? -d[a] : d[a];
+            if (!(m > 0.0)) continue;  // the zero vector has no direction (a unit query is 1 > radius away from it)
+            const double u = d[(a + 1) % 3] / m, v = d[(a + 2) % 3] / m;
+            if (!(std::fabs(u) <= lim && std::fabs(v) <= lim)) continue;
+            placed.push_back(Placement{(uint32_t)((f * kGridG + grid_cell(v)) * kGridG + grid_cell(u)), (uint32_t)i});
+        }
+    }
+    // counting sort by cell; `placed` is in star order, so entries of a cell come out in star order
+    cell_start.assign((size_t)kGridCells + 2, 0u);  // cells, the origin list, end
+    for (const Placement &p : placed) cell_start[p.cell + 1]++;
+    for (size_t c = 0; c <= (size_t)kGridCells; c++) cell_start[c + 1] += cell_start[c];
+    nodes.assign(placed.size(), StarNode{0, 0, 0, 0, -1});
+    colors.assign(placed.size(), StarColor{0, 0, 0, 0, 0});
+    std::vector<uint32_t> fill(cell_start.begin(), cell_start.end() - 1);
+    for (const Placement &p : placed) {
+        const uint32_t k = fill[p.cell]++;
+        const bs_star &s = stars[p.star];
+        nodes[k] = StarNode{s.x, s.y, s.z, s.mag, (int32_t)p.star};
+        colors[k] = star_color(s.hue, s.sat);
     }
 }
 

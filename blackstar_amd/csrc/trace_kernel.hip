@@ -36,7 +36,6 @@ __device__ __forceinline__ double quadrance(double x, double y, double z) { retu
 // libm calls as REAL calls.  ocml's f64 sin / cos / exp carry a large-argument (Payne-Hanek) path that is never taken
 // here but costs ~30 VGPRs wherever it is inlined; the shading code sits outside the stepping loop, so a call is
 // free and keeps the kernel at <= 111 VGPRs with no scratch.
-__device__ __noinline__ double cos_call(double x) { return cos(x); }
 __device__ __noinline__ double sin_call(double x) { return sin(x); }
 __device__ __noinline__ double exp_call(double x) { return exp(x); }
 
@@ -233,64 +232,50 @@ __device__ __forceinline__ void rk4_planar(const TraceParams &P, const PlanarK &
     r2n = __builtin_fma(y, y, x * x);
 }
 
-// massiv-io Graphics.ColorSpace toPixelRGB (PixelHSI h' s i), h' in [0,1)  (recalled)
-__device__ __forceinline__ void hsi_to_rgb(double hp, double s, double i, double &r, double &g, double &b)
+// Per-star colour of starLookup's renderPixel (StarMap.hs:105-114), added to the running sum.  toPixelRGB (PixelHSI h s i)
+// (massiv-io) with the hue's two cosines taken from the star's StarColor record (host libm, once per star):
+// first = i + is*cos a / cos b, second = i - is, third = i + 2*is + second - first, (r,g,b) a rotation of (first, third, second).
+__device__ __forceinline__ void add_star(const TraceParams &P, unsigned k, double d2, double &accR, double &accG, double &accB)
 {
-    const double pi = 3.141592653589793;
-    double h = hp * 2 * pi;
-    double is = i * s;
-    double second = i - is;
-    // Sector k: first = i + is*cos a / cos b, third = i + 2*is + second - first; (r,g,b) is a rotation of
-    // (first, third, second).  Written with selects so the three channels stay in registers.
-    const int k = (h < 2 * pi / 3) ? 0 : ((h < 4 * pi / 3) ? 1 : 2);
-    double a = k == 0 ? h : (k == 1 ? h - 2 * pi / 3 : h - 4 * pi / 3);
-    double bb = k == 0 ? pi / 3 - h : (k == 1 ? h + pi : 2 * pi - pi / 3 - h);
-    double first = i + is * cos_call(a) / cos_call(bb);
-    double third = i + 2 * is + second - first;
-    r = k == 0 ? first : (k == 1 ? second : third);
-    g = k == 0 ? third : (k == 1 ? first : second);
-    b = k == 0 ? second : (k == 1 ? third : first);
-}
-
-// Per-star colour of starLookup's renderPixel (StarMap.hs:105-114), added to the running sum.
-__device__ __forceinline__ void add_star(const TraceParams &P, unsigned i, double d2, double &accR, double &accG, double &accB)
-{
-    const double w = 0.0005;
-    const double two_w2 = 2 * (w * w);
-    const int mag = P.nodes[i].mag;
-    const StarColor sc = P.colors[i];
+    const double two_w2 = 2 * (kStarW * kStarW);
+    const int mag = P.nodes[k].mag;
+    const StarColor sc = P.colors[k];
     double e = exp_call(P.star_a * (950.0 - (double)mag) - d2 / two_w2);
     double m = (1.0 <= e) ? 1.0 : e;  // min 1
-    double val = m * P.star_intensity;
-    double cr, cg, cb;
-    hsi_to_rgb(sc.hue, P.star_saturation * sc.sat, val, cr, cg, cb);
-    accR = accR + cr; accG = accG + cg; accB = accB + cb;
+    const double i = m * P.star_intensity;
+    const double is = i * (P.star_saturation * sc.sat);
+    const double second = i - is;
+    const double first = i + is * sc.ca / sc.cb;
+    const double third = i + 2 * is + second - first;
+    const int sec = sc.sector;
+    accR = accR + (sec == 0 ? first : (sec == 1 ? second : third));
+    accG = accG + (sec == 0 ? third : (sec == 1 ? first : second));
+    accB = accB + (sec == 0 ? second : (sec == 1 ? third : first));
 }
 
-// starLookup (StarMap.hs:93-115) over the flat k-d array.  Stackless depth-first traversal: `pending`
-// holds one bit per depth whose far child is still to be visited; the path itself is the node index.
-// Returns the number of stars within the radius; rgb = min 1 (sum of per-star colours).
-//
-// What makes it cheap (it was 10 % of the frame, all of it VALU issue, none of it memory latency):
-//   * a visit reads only the node's SPLIT coordinate (8 B, from LDS for the top kLdsLevels levels, else from the
-//     L2-resident split array); the point itself can only be within the radius if it is within the radius
-//     along that axis, so the full 32-B node and the distance test are touched only when
-//     |q_axis - split| <= radius -- the same condition that makes the far child worth visiting;
-//   * hits (0.25 per lookup) are only RECORDED during the traversal (node index + d^2 into the lane's LDS
-//     column, in traversal order) and shaded afterwards -- exp, two cos, a divide, ~300 instructions that the
-//     wavefront would otherwise execute at every iteration in which any lane happens to hit.
+// bs_internal.h grid_cell, same operations (the builder bins with it, so binning and query agree by monotonicity).
+__device__ __forceinline__ int grid_cell_dev(double t)
+{
+    double c = (t + 1.0) * (0.5 * kGridG);
+    if (!(c > 0.0)) return 0;  // also NaN
+    if (c >= (double)kGridG) return kGridG - 1;
+    return (int)c;
+}
+
+// starLookup (StarMap.hs:93-115) over the cube-map direction grid (bs_internal.h): the stars within the radius of nvel
+// are all listed in nvel's own face, in the <= 2 x 2 cells its D-box touches; each touched row of cells is ONE contiguous
+// run of entries.  Returns the number of stars within the radius; rgb = min 1 (sum of per-star colours).
+// Hits (0.25 per lookup) are only RECORDED while scanning (entry index + d^2 into the lane's LDS column) and shaded
+// afterwards -- exp and a divide, ~100 instructions that the wavefront would otherwise execute at every candidate at
+// which any lane happens to hit.
 #ifndef BS_HIT_SLOTS
 #define BS_HIT_SLOTS 5
 #endif
 constexpr int kHitSlots = BS_HIT_SLOTS;  // per lane, in the snapshot/queue columns (free by the time the lookup runs)
 
-__device__ __forceinline__ int star_lookup(const TraceParams &P, const double *lds_splits, double *lane_col, double vx, double vy, double vz,
-                                           double &R, double &G, double &B)
+__device__ __forceinline__ int star_lookup(const TraceParams &P, double *lane_col, double vx, double vy, double vz, double &R, double &G, double &B)
 {
-    const double w = 0.0005;
-    const double radius = 3 * w;            // StarMap.hs:104  inRadius starmap (3 * w) nvel
-    const double r2 = radius * radius;      // kdt: distSqr p q <= radius * radius
-    const double rpad = radius * (1.0 + 0x1p-40);  // gate for the exact test: d2 <= r2 implies |d_axis| <= rpad in FP too
+    const double r2 = kStarRadius * kStarRadius;  // kdt: distSqr p q <= radius * radius
     // linear.normalize: unchanged when |l| or |1-l| <= 1e-12
     double l = quadrance(vx, vy, vz);
     double nx = vx, ny = vy, nz = vz;
@@ -298,45 +283,54 @@ __device__ __forceinline__ int star_lookup(const TraceParams &P, const double *l
         double s = __builtin_sqrt(l);
         nx = vx / s; ny = vy / s; nz = vz / s;
     }
+    // face of the largest |component|, gnomonic coordinates of the other two in cyclic order.  A NaN or zero vector
+    // lands in some cell of face 4 and matches nothing (every d^2 compare fails).
+    const double ax = fabs(nx), ay = fabs(ny), az = fabs(nz);
+    const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const double m = axis == 0 ? nx : (axis == 1 ? ny : nz);
+    const double a = axis == 0 ? ny : (axis == 1 ? nz : nx);
+    const double b = axis == 0 ? nz : (axis == 1 ? nx : ny);
+    const int face = 2 * axis + (m < 0 ? 1 : 0);
+    const double im = __builtin_amdgcn_rcp(fabs(m));  // ~2^-24 relative; kGridDelta carries 4 % of slack
+    const double u = a * im, v = b * im;
+    const int iu0 = grid_cell_dev(u - kGridDelta), iu1 = grid_cell_dev(u + kGridDelta);
+    int iv = grid_cell_dev(v - kGridDelta);
+    const int iv1 = grid_cell_dev(v + kGridDelta);
+    unsigned row = (unsigned)((face * kGridG + iv) * kGridG);
+    unsigned k = P.cell_start[row + iu0], e = P.cell_start[row + iu1 + 1];
+    if (fabs(l) <= 1e-12) {  // not normalised above, so not a unit vector: only the stars around the origin are in reach
+        k = P.cell_start[kGridCells];
+        e = P.cell_start[kGridCells + 1];
+        iv = iv1;
+    }
     double accR = 0, accG = 0, accB = 0;
     int hits = 0;
-    const unsigned n = (unsigned)P.n_stars;
-    const unsigned nl = (unsigned)P.lds_nodes;
-    unsigned i = 1, pending = 0;
-    int depth = 0, axis = 0;
-    for (;;) {
-        while (i <= n) {
-            const double sa = (i <= nl) ? lds_splits[i - 1] : P.splits[i];
-            const double qa = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            const double diff = qa - sa;
-            if (fabs(diff) <= rpad) {
-                pending |= 1u << (depth + 1);  // the far child intersects the ball
-                const StarNode nd = P.nodes[i];
-                double dx = nd.x - nx, dy = nd.y - ny, dz = nd.z - nz;  // qd pos nvel = quadrance (pos - nvel)
-                double d2 = quadrance(dx, dy, dz);
-                if (d2 <= r2) {
-                    if (hits < kHitSlots) {
-                        lane_col[hits * kBlock] = d2;
-                        lane_col[(kHitSlots + hits) * kBlock] = (double)i;
-                    } else {
-                        add_star(P, i, d2, accR, accG, accB);  // more hits than slots: shade in place
-                    }
-                    hits++;
+    for (bool more = true; more;) {
+        if (k < e) {
+            const StarNode nd = P.nodes[k];
+            double dx = nd.x - nx, dy = nd.y - ny, dz = nd.z - nz;  // qd pos nvel = quadrance (pos - nvel)
+            double d2 = quadrance(dx, dy, dz);
+            if (d2 <= r2) {
+                if (hits < kHitSlots) {
+                    lane_col[hits * kBlock] = d2;
+                    lane_col[(kHitSlots + hits) * kBlock] = (double)k;
+                } else {
+                    add_star(P, k, d2, accR, accG, accB);  // more hits than slots: shade in place
                 }
+                hits++;
             }
-            i = 2 * i + (diff <= 0 ? 0u : 1u);  // near child
-            depth++;
-            axis = (axis == 2) ? 0 : axis + 1;
+            k++;
+        } else if (iv < iv1) {  // next row of cells
+            iv++;
+            row += kGridG;
+            k = P.cell_start[row + iu0];
+            e = P.cell_start[row + iu1 + 1];
+        } else {
+            more = false;
         }
-        if (pending == 0) break;
-        int dd = 31 - __clz((int)pending);
-        pending &= ~(1u << dd);
-        i = (i >> (depth - dd)) ^ 1u;  // sibling of the near child taken at depth dd
-        depth = dd;
-        axis = dd % 3;
     }
     const int queued = hits < kHitSlots ? hits : kHitSlots;
-    for (int k = 0; k < queued; k++) add_star(P, (unsigned)lane_col[(kHitSlots + k) * kBlock], lane_col[k * kBlock], accR, accG, accB);
+    for (int q = 0; q < queued; q++) add_star(P, (unsigned)lane_col[(kHitSlots + q) * kBlock], lane_col[q * kBlock], accR, accG, accB);
     R = (1.0 <= accR) ? 1.0 : accR;  // fmap (min 1)
     G = (1.0 <= accG) ? 1.0 : accG;
     B = (1.0 <= accB) ? 1.0 : accB;
@@ -434,7 +428,7 @@ __device__ __forceinline__ void record_crossing(const TraceParams &P, const Lane
 }
 
 // The terminal `Bottom` layer of colorize (:84, :93-95) under whatever the disk left transparent.
-__device__ __forceinline__ int finish_ray(const TraceParams &P, const double *lds_splits, double *lane_col, int fate, const double v[3], double rgba[4])
+__device__ __forceinline__ int finish_ray(const TraceParams &P, double *lane_col, int fate, const double v[3], double rgba[4])
 {
     int star_hits = 0;
     if (fate == 0) {  // Bottom (PixelRGBA 0 0 0 1)
@@ -443,7 +437,7 @@ __device__ __forceinline__ int finish_ray(const TraceParams &P, const double *ld
         rgba[3] = rgba[3] + 1.0 * om;
     } else if (fate == 1) {  // Bottom . addAlpha 1 $ starLookup ... vel   (the PRE-step vel, :94-95)
         double sr, sg, sb;
-        star_hits = star_lookup(P, lds_splits, lane_col, v[0], v[1], v[2], sr, sg, sb);
+        star_hits = star_lookup(P, lane_col, v[0], v[1], v[2], sr, sg, sb);
         double om = 1 - rgba[3];
         rgba[0] = rgba[0] + sr * om; rgba[1] = rgba[1] + sg * om; rgba[2] = rgba[2] + sb * om;
         rgba[3] = rgba[3] + 1.0 * om;
@@ -509,7 +503,7 @@ __device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, i
 // register and a lane's step count (iterations of colorize', :80-86) is simply its value when the lane's
 // guard fires.  See "per-lane LDS scratch" above for why the loop looks the way it does.
 template <bool FAST>
-__device__ __forceinline__ void trace_ray(const TraceParams &P, const double *lds_splits, const LaneLds &lds, bool live, int yi, int xi,
+__device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &lds, bool live, int yi, int xi,
                                           RayResult &res, unsigned &wave_iters)
 {
     double v[3], p[3];
@@ -619,19 +613,13 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const double *ld
         for (int i = 0; i < 4; i++) rgba[i] = out[6 + i];
         steps = iout[0]; fate = iout[1]; ncross = iout[2];
     }
-    int star_hits = finish_ray(P, lds_splits, lds.col, fate, v, rgba);
+    int star_hits = finish_ray(P, lds.col, fate, v, rgba);
 #pragma unroll
     for (int i = 0; i < 3; i++) { res.vel[i] = v[i]; res.pos[i] = p[i]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) res.rgba[i] = rgba[i];
     res.steps = steps; res.fate = fate; res.disk_hits = ncross; res.star_hits = star_hits;
     wave_iters = (unsigned)it + 1u;  // iterations entered, including the one in which the last guards fired
-}
-
-__device__ __forceinline__ void stage_tree(const TraceParams &P, double *s_splits)
-{
-    for (int k = threadIdx.x; k < P.lds_nodes; k += kBlock) s_splits[k] = P.splits[k + 1];
-    __syncthreads();
 }
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v)
@@ -657,11 +645,9 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 template <bool FAST>
 __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const TraceParams P)
 {
-    __shared__ double s_nodes[kLdsNodes];
     __shared__ double s_lane[kLaneLdsDoubles];
     __shared__ int s_ints[2 * kBlock];
     __shared__ unsigned s_stats[6 * kBlock];
-    stage_tree(P, s_nodes);
     const LaneLds lds(s_lane, s_ints);
 
     const int lane = threadIdx.x & 63;
@@ -703,7 +689,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 
         RayResult res;
         unsigned w_iters;
-        trace_ray<FAST>(P, s_nodes, lds, inb, yi, xi, res, w_iters);
+        trace_ray<FAST>(P, lds, inb, yi, xi, res, w_iters);
 
         if (P.ss) {
             const int base = lane & ~3;
@@ -749,16 +735,14 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 template <bool FAST>
 __global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams P, const int32_t *yx, size_t n_rays, bs_ray_record *out)
 {
-    __shared__ double s_nodes[kLdsNodes];
     __shared__ double s_lane[kLaneLdsDoubles];
     __shared__ int s_ints[2 * kBlock];
-    stage_tree(P, s_nodes);
     const LaneLds lds(s_lane, s_ints);
     size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = k < n_rays;
     RayResult res;
     unsigned w_iters;
-    trace_ray<FAST>(P, s_nodes, lds, live, live ? yx[2 * k] : 0, live ? yx[2 * k + 1] : 0, res, w_iters);
+    trace_ray<FAST>(P, lds, live, live ? yx[2 * k] : 0, live ? yx[2 * k + 1] : 0, res, w_iters);
     if (!live) return;
     bs_ray_record r;
     for (int i = 0; i < 3; i++) { r.vel[i] = res.vel[i]; r.pos[i] = res.pos[i]; }
@@ -770,13 +754,11 @@ __global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams
 // starLookup over a batch of directions (same device function as the trace kernel's escape branch).
 __global__ __launch_bounds__(kBlock) void star_lookup_kernel(const TraceParams P, const double *dirs, size_t n, double *rgb, int32_t *hits)
 {
-    __shared__ double s_nodes[kLdsNodes];
     __shared__ double s_lane[2 * kHitSlots * kBlock];
-    stage_tree(P, s_nodes);
     size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
     double r, g, b;
-    int h = star_lookup(P, s_nodes, s_lane + threadIdx.x, dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2], r, g, b);
+    int h = star_lookup(P, s_lane + threadIdx.x, dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2], r, g, b);
     rgb[3 * k] = r; rgb[3 * k + 1] = g; rgb[3 * k + 2] = b;
     if (hits) hits[k] = h;
 }

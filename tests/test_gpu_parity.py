@@ -557,3 +557,94 @@ def test_trace_rays_counts_that_leave_wavefronts_empty(n, mode, tree, oracle, or
     orc = oracle.trace_rays(cfg, oracle_index, ys, xs)
     assert np.array_equal(rec["steps"], orc["steps"]) and np.array_equal(rec["fate"], orc["fate"])
     assert np.array_equal(rec["disk_hits"], orc["disk_hits"])
+
+
+def _brute_hits(stars_xyz, dirs):
+    """Hit counts of starLookup by definition: normalise (linear's shortcut), then |p - n|^2 <= (3w)^2 for every star."""
+    l = (dirs[:, 0] * dirs[:, 0] + dirs[:, 1] * dirs[:, 1]) + dirs[:, 2] * dirs[:, 2]
+    keep = (np.abs(l) <= 1e-12) | (np.abs(1 - l) <= 1e-12)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        nv = np.where(keep[:, None], dirs, dirs / np.sqrt(l)[:, None])
+    out = np.zeros(len(dirs), np.int64)
+    r2 = 0.0015 * 0.0015
+    for k in range(len(dirs)):
+        d = stars_xyz - nv[k]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        with np.errstate(invalid="ignore"):
+            out[k] = int((d2 <= r2).sum())
+    return out
+
+
+def test_star_grid_adversarial_geometry():
+    """The direction grid must return exactly the in-radius SET wherever the query sits on the cube map: stars on face
+    edges and corners (listed in several faces, never counted twice), on cell boundaries, queries at the radius itself,
+    stars off the unit sphere (|p| in 0.9985..1.0015 can still be within 0.0015 of a unit vector), zero / NaN stars and
+    degenerate query vectors."""
+    rng = np.random.default_rng(21)
+    pts = []
+    s = 1 / np.sqrt(3.0)
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                pts.append([sx * s, sy * s, sz * s])                      # the 8 corners
+    e = 1 / np.sqrt(2.0)
+    for a, b in ((0, 1), (1, 2), (2, 0)):
+        for sa in (-1, 1):
+            for sb in (-1, 1):
+                for t in np.linspace(-0.57, 0.57, 7):
+                    p = np.zeros(3); p[a] = sa * e; p[b] = sb * e; p[3 - a - b] = t
+                    pts.append(p / np.linalg.norm(p))                      # along the 12 edges
+    g = np.arange(-128, 129) / 128.0                                       # cell boundaries of a face, as directions
+    for u in g[::16]:
+        for v in g[::16]:
+            p = np.array([u, v, 1.0]); pts.append(p / np.linalg.norm(p))
+            p = np.array([1.0, u, v]); pts.append(-p / np.linalg.norm(p))
+    pts = np.array(pts)
+    pts = np.concatenate([pts, pts[:60] * rng.uniform(0.9986, 1.0014, (60, 1)),   # off-sphere but reachable
+                          pts[60:90] * 1.01, np.zeros((2, 3)), [[np.nan, 0, 1.0]], [[np.inf, 0, 0]],
+                          [[0.001, 0, 0], [0, -0.0015, 0], [0, 0, 0.00150001]]])  # around the origin: in reach of |v|^2 <= 1e-12 queries only
+    pts = np.concatenate([pts, pts[:200] + rng.normal(scale=4e-4, size=(200, 3))])  # close pairs -> multi-hit queries
+    stars = np.zeros(len(pts), _lib.STAR_DTYPE)
+    stars["x"], stars["y"], stars["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    stars["hue"], stars["sat"], stars["mag"] = rng.uniform(0, 0.999, len(pts)), rng.uniform(0, 1, len(pts)), rng.integers(-100, 900, len(pts))
+    t = bs.StarTree(stars)
+    try:
+        base = pts[np.isfinite(pts).all(axis=1) & (np.abs(pts).sum(axis=1) > 0)]
+        q = [base]
+        for scale in (0.0014, 0.0014999, 0.0015001, 0.0016, 0.0030):      # offsets just inside / outside the radius
+            d = rng.normal(size=base.shape); d /= np.linalg.norm(d, axis=1)[:, None]
+            q.append(base / np.linalg.norm(base, axis=1)[:, None] + scale * d)
+        q.append(base * rng.uniform(0.1, 50, (len(base), 1)))              # un-normalised queries
+        q.append(np.array([[0.0, 0, 0], [np.nan, 1, 0], [np.inf, 1, 0], [1, 1, 1], [-1, 1, 1], [1e-300, 0, 0], [0, -2, 0],
+                           [5e-7, 0, 0], [0, -9e-7, 0], [0, 0, 9.9e-7], [1.1e-6, 0, 0]]))
+        dirs = np.concatenate(q)
+        rgb, hits = bs.star_lookup(t, 0.4, 1.5, dirs, return_hits=True)
+        ref = _brute_hits(pts, dirs)
+        bad = np.nonzero(hits != ref)[0]
+        assert len(bad) == 0, f"{len(bad)} queries with a wrong hit set, first {dirs[bad[0]]} got {hits[bad[0]]} want {ref[bad[0]]}"
+        assert ref.max() >= 2 and (ref == 0).any() and np.isfinite(rgb[ref == 0]).all()
+    finally:
+        t.close()
+
+
+def test_star_grid_full_catalogue_queries_at_the_stars():
+    """Every 5th star of the 470k catalogue queried at its own direction plus a random offset around the radius: brute-force
+    hit counts (numpy) must match."""
+    stars = bs.read_map(synthetic.ppm_catalogue_bytes())
+    xyz = np.stack([stars["x"], stars["y"], stars["z"]], axis=1)
+    t = bs.StarTree(stars)
+    try:
+        rng = np.random.default_rng(33)
+        sel = rng.choice(len(xyz), 3000, replace=False)
+        # bias the sample to the cube-map seams: largest and second-largest |component| nearly equal
+        a = np.sort(np.abs(xyz), axis=1)
+        seam = np.argsort(a[:, 2] - a[:, 1])[:1500]
+        sel = np.concatenate([sel, seam])
+        d = rng.normal(size=(len(sel), 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+        dirs = xyz[sel] + rng.uniform(0, 0.003, (len(sel), 1)) * d
+        _, hits = bs.star_lookup(t, 0.4, 1.5, dirs, return_hits=True)
+        ref = _brute_hits(xyz, dirs)
+        assert np.array_equal(hits, ref), f"{(hits != ref).sum()} of {len(sel)} hit sets differ"
+        assert ref.sum() > 1500
+    finally:
+        t.close()
