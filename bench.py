@@ -49,7 +49,7 @@ def cpu_baseline(cfg, star_bytes, budget_s):
 def pmc_traffic(mode):
     """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950 -- an upper
-    bound here, since that calibration is for wide coalesced reads and this kernel's reads are 32-byte k-d nodes)."""
+    bound here, since that calibration is for wide coalesced reads and this kernel's reads are 32-byte star-grid entries)."""
     import glob
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
         try:
@@ -177,7 +177,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("scenes/default-aa.yaml 1920x1080, 4x supersample (8,294,400 rays/frame), 470k-star synthetic "
-                                    "PPM-layout catalogue k-d lookup (BASELINE configs[2])") if frames_cfg is None else
+                                    "PPM-layout catalogue, direction-grid star lookup (BASELINE configs[2])") if frames_cfg is None else
                                    ("animations/default-ani.yaml, nFrames=600, 1920x1080, 4x supersample, 470k-star synthetic catalogue, "
                                     "frame i on rank i % N (BASELINE configs[4]); roofline figures refer to the LAST frame rendered"),
                        "mode": args.mode, "frames_per_step_per_gpu": 1, "parallelism": f"frame-sharded x{world}",

@@ -639,7 +639,7 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 //
 // Why stagger: every tile costs nearly the same (lane efficiency 0.9987; step counts vary by a few percent
 // across the frame), so wavefronts that start together stay in phase and all four waves of a SIMD reach
-// their latency-bound tail (k-d lookup, shading, image write, next tile's setup) at the same time, leaving the
+// their latency-bound tail (star lookup, shading, image write, next tile's setup) at the same time, leaving the
 // f64 pipe idle (PMC: VALU busy 91 % with stars vs 96 % without).  Delaying the first tile of the wave in
 // SIMD slot k by k/4 of a tile time keeps the four phases apart for the rest of the frame.
 template <bool FAST>

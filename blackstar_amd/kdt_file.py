@@ -8,7 +8,7 @@ a real file -- treat a decode failure on a real `stars.kdt` as a bug in this mod
     KdMap    = u8 0 (pointAsList dummy) . u8 0 (distSqr dummy) . TreeNode . i64be size          -- record field order
     TreeNode = u8 0 . TreeNode(left) . V3 (3 x f64be) . i64be mag . utf8 spectral-char . f64be axisValue . TreeNode(right)
              | u8 1                                                                              -- Empty
-Only the (position, (mag, spectral)) pairs matter downstream: the GPU builds its own flat k-d array from them
+Only the (position, (mag, spectral)) pairs matter downstream: the GPU builds its own direction grid from them
 (bs_create), so the tree shape in the file is not used.
 """
 from __future__ import annotations

@@ -2,7 +2,7 @@
 
 Reference -> here:
   readMapFromFile  (:77-80)   -> read_map_from_file   (catalogue parse runs in the C library: bs_read_ppm)
-  buildStarTree    (:90-91)   -> build_star_tree      (flat k-d array built + uploaded by bs_create)
+  buildStarTree    (:90-91)   -> build_star_tree      (direction grid built + uploaded by bs_create)
   treeToByteString (:87-88)   -> tree_to_byte_string  (own flat format; the `.kdt` cereal layout is out of scope)
   readTreeFromFile (:82-85)   -> read_tree_from_file
   starLookup       (:93-115)  -> star_lookup          (device function, batched through bs_star_lookup)
@@ -41,7 +41,7 @@ def read_map_from_file(path: str) -> np.ndarray:
 
 
 class StarTree:
-    """The `StarTree` argument of render: the star set resident on one GPU as a flat k-d array."""
+    """The `StarTree` argument of render: the star set resident on one GPU as a cube-map direction grid (csrc/star_index.cpp)."""
 
     def __init__(self, stars: Optional[np.ndarray], device: int = 0):
         stars = np.zeros(0, STAR_DTYPE) if stars is None else np.ascontiguousarray(stars, dtype=STAR_DTYPE)

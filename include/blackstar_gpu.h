@@ -88,7 +88,7 @@ typedef struct bs_ray_record {
 typedef struct bs_ctx bs_ctx;
 
 /* Replaces: readTreeFromFile's result being handed to doStart once (app/Main.hs:46-49) -- the star set is
- * uploaded once and reused for every frame.  Copies `stars`, builds the flat k-d array, uploads.
+ * uploaded once and reused for every frame.  Copies `stars`, builds the star direction grid, uploads.
  * n_stars == 0 is the "no starmap" case: inRadius yields [] and escaped rays are black (src/StarMap.hs:104,115).
  * device: HIP device ordinal (>= 0).  Returns NULL on error. */
 bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars);

@@ -173,7 +173,7 @@ void orc_rk4(double h, double h2, const double vel[3], const double pos[3], doub
     }
 }
 
-/* ---------------------------------------------------------------- star index (independent of the product's k-d array) */
+/* ---------------------------------------------------------------- star index (independent of the product's cube-map direction grid) */
 
 #define GRID 256
 struct orc_index {

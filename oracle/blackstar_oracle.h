@@ -61,7 +61,7 @@ typedef struct {
 
 typedef struct orc_index orc_index;
 
-/* Uniform-grid in-radius index over the star list (independent of the product's k-d array). */
+/* Uniform-grid in-radius index over the star list (a 3-D cell grid; independent of the product's cube-map direction grid). */
 orc_index *orc_index_create(const orc_star *stars, size_t n);
 void orc_index_destroy(orc_index *);
 

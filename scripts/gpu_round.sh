@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 nproc > gpurun_out/nproc.txt; rocminfo | grep -E "Marketing|gfx9" | head -4 >> gpurun_out/nproc.txt; cat /sys/fs/cgroup/cpu.max >> gpurun_out/nproc.txt 2>&1
 (time python -c "import __graft_entry__ as g; g.smoke()") > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$?" >> gpurun_out/smoke.log
-(time timeout 1500 python -m pytest tests -q -m gpu) > gpurun_out/pytest_gpu.log 2>&1
+(time timeout 400 python -m pytest tests -q -m gpu) > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 python scripts/ubench.py > gpurun_out/ubench.json 2> gpurun_out/ubench.err
 python bench.py --steps 20 --warmup 3 --mode strict --cpu-seconds 0 > gpurun_out/bench_strict.json 2> gpurun_out/bench_strict.err
