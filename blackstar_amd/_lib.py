@@ -39,7 +39,7 @@ RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4
 SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
            "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
            "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots",
-           "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample")
+           "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid")
 
 _lib = None
 
@@ -100,6 +100,9 @@ def lib() -> C.CDLL:
     L.bs_set_max_steps.argtypes = [vp, C.c_int]
     L.bs_stats.argtypes = [vp, C.POINTER(BsStats)]
     L.bs_last_error.restype = C.c_char_p
+    if hasattr(L, "bs_debug_star_grid"):
+        L.bs_debug_star_grid.restype = C.c_long
+        L.bs_debug_star_grid.argtypes = [vp, sz, vp, vp, sz]
     L.bs_read_ppm.restype = C.c_long
     L.bs_read_ppm.argtypes = [vp, sz, vp, sz]
     L.bs_hsi_to_rgb.argtypes = [dp, dp, dp, vp]

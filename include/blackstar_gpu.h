@@ -167,6 +167,13 @@ int bs_abi_version(void);
  * holds; writes at most `cap` of them.  Host-only; returns BS_EINVAL if nbytes < 28. */
 long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size_t cap);
 
+/* Test hook, host-only (no device is touched): the star index bs_create builds for buildStarTree (src/StarMap.hs:90-91),
+ * a cube-map grid of star directions ("Star lookup").  Writes the 6*256*256 + 2 cell offsets to
+ * cell_start (entries of cell c are [cell_start[c], cell_start[c+1]); the last cell lists the stars around the origin)
+ * and, for each entry, the index of its star in `stars` to entry_star (at most `cap`).  Returns the number of entries
+ * (stars + copies in neighbouring faces), or BS_EINVAL. */
+long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_start, int32_t *entry_star, size_t cap);
+
 /* Replaces: toPixelRGB on PixelHSI (massiv-io Graphics.ColorSpace; call sites src/Raytracer.hs:65,
  * src/StarMap.hs:114).  Host-only; returns BS_EINVAL if the hue is outside [0,1). */
 int bs_hsi_to_rgb(double hue, double sat, double intensity, double rgb[3]);

@@ -169,3 +169,93 @@ def test_missing_native_library_fails_loudly():
                        env=dict(os.environ, BLACKSTAR_LIB="/nonexistent/libblackstar_gpu.so"))
     assert r.returncode == 0, r.stderr
     assert r.stdout.split("\n")[:3] == ["raised True"] * 3, r.stdout
+
+
+# ---- star direction grid (csrc/star_index.cpp), host side ---------------------------------------------------------------
+
+G, DELTA, RADIUS = 256, 0.0039, 0.0015  # kGridG, kGridDelta, kStarRadius of csrc/bs_internal.h
+
+
+def _star_grid(stars):
+    L = _lib.lib()
+    cs = np.zeros(6 * G * G + 2, np.uint32)
+    cap = 4 * len(stars) + 8
+    ent = np.zeros(cap, np.int32)
+    n = L.bs_debug_star_grid(stars.ctypes.data if len(stars) else None, len(stars), cs.ctypes.data, ent.ctypes.data, cap)
+    assert 0 <= n <= cap
+    return cs, ent[:n]
+
+
+def _cell(t):
+    c = (t + 1.0) * (0.5 * G)
+    return int(min(max(np.floor(c), 0), G - 1)) if c > 0 else 0
+
+
+def _grid_query(cs, ent, q):
+    """The kernel's addressing (star_lookup, csrc/trace_kernel.hip) replayed with numpy: candidate star indices of unit q."""
+    axis = 0 if (abs(q[0]) >= abs(q[1]) and abs(q[0]) >= abs(q[2])) else (1 if abs(q[1]) >= abs(q[2]) else 2)
+    m, a, b = q[axis], q[(axis + 1) % 3], q[(axis + 2) % 3]
+    face = 2 * axis + (1 if m < 0 else 0)
+    u, v = a / abs(m), b / abs(m)
+    iu0, iu1, iv0, iv1 = _cell(u - DELTA), _cell(u + DELTA), _cell(v - DELTA), _cell(v + DELTA)
+    assert iu1 - iu0 <= 1 and iv1 - iv0 <= 1  # at most 2 x 2 cells: 2 * DELTA <= cell width
+    out = []
+    for iv in range(iv0, iv1 + 1):
+        row = (face * G + iv) * G
+        out.extend(ent[cs[row + iu0]:cs[row + iu1 + 1]])
+    return out
+
+
+def test_star_grid_builder_and_query_geometry_on_cpu():
+    """Every star within the radius of a unit query must be among the candidates of the query's own face, exactly once
+    -- including at face edges/corners (border copies), for off-sphere stars, and with the margin kGridDelta."""
+    rng = np.random.default_rng(3)
+    stars = bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_SMALL))
+    extra = np.zeros(64, _lib.STAR_DTYPE)
+    s3, s2 = 1 / np.sqrt(3), 1 / np.sqrt(2)
+    pts = [[sx * s3, sy * s3, sz * s3] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+    pts += [[s2, s2, 0], [s2, 0, -s2], [0, -s2, s2], [-s2, s2, 1e-9], [0.9986 * s2, 0.9986 * s2, 0], [0, 0, 0], [1e-4, 0, 0], [np.nan, 0, 0]]
+    extra["x"][:len(pts)], extra["y"][:len(pts)], extra["z"][:len(pts)] = np.array(pts).T
+    extra["x"][len(pts):] = 1.0  # the rest: copies of (1,0,0)
+    stars = np.concatenate([stars, extra])
+    cs, ent = _star_grid(stars)
+    assert np.all(np.diff(cs.astype(np.int64)) >= 0) and cs[-1] == len(ent)
+    xyz = np.stack([stars["x"], stars["y"], stars["z"]], axis=1)
+    fin = np.isfinite(xyz).all(axis=1)
+    nz = fin & (np.abs(xyz).sum(axis=1) > 0)
+    counts = np.bincount(ent[:cs[6 * G * G]], minlength=len(stars))
+    assert np.all(counts[nz] >= 1) and np.all(counts <= 3) and np.all(counts[~fin] == 0)  # own face (+ up to 2 neighbours)
+    origin = set(ent[cs[6 * G * G]:cs[6 * G * G + 1]])
+    r2all = (xyz * xyz).sum(axis=1)
+    with np.errstate(invalid="ignore"):
+        assert origin == set(np.nonzero(fin & (r2all <= 0.0016 ** 2))[0])
+    # queries: at every star, offset by up to 2 radii in a random direction, then normalised
+    base = xyz[nz]
+    d = rng.normal(size=base.shape); d /= np.linalg.norm(d, axis=1)[:, None]
+    qs = base / np.linalg.norm(base, axis=1)[:, None] + rng.uniform(0, 2 * RADIUS, (len(base), 1)) * d
+    qs /= np.linalg.norm(qs, axis=1)[:, None]
+    hits = 0
+    for q in qs:
+        cand = _grid_query(cs, ent, q)
+        assert len(cand) == len(set(cand)), "a star is listed twice within one face"
+        with np.errstate(invalid="ignore"):
+            inside = set(np.nonzero(((xyz - q) ** 2).sum(axis=1) <= RADIUS * RADIUS)[0])
+        assert inside <= set(cand), f"query {q}: in-radius stars {inside - set(cand)} are not candidates"
+        hits += len(inside)
+    assert hits > len(qs) // 3
+
+
+def test_star_grid_margin_bound():
+    """The bound behind kGridDelta: on a face (|u|,|v| <= 1 + D) a direction change of asin(r) moves u by less than D."""
+    rng = np.random.default_rng(4)
+    n = 200000
+    uv = rng.uniform(-1.0, 1.0, (n, 2))
+    uv[: n // 4] = np.sign(uv[: n // 4]) * rng.uniform(0.99, 1.0, (n // 4, 2))  # corners
+    p = np.concatenate([uv, np.ones((n, 1))], axis=1)
+    p /= np.linalg.norm(p, axis=1)[:, None]
+    t = rng.normal(size=(n, 3)); t -= (t * p).sum(axis=1)[:, None] * p; t /= np.linalg.norm(t, axis=1)[:, None]
+    th = np.arcsin(RADIUS)
+    s = np.cos(th) * p + np.sin(th) * t  # directions exactly asin(r) away
+    du = np.abs(s[:, 0] / s[:, 2] - uv[:, 0]); dv = np.abs(s[:, 1] / s[:, 2] - uv[:, 1])
+    assert max(du.max(), dv.max()) < DELTA * 0.97, (du.max(), dv.max())
+    assert 2 * DELTA <= 2.0 / G
