@@ -69,15 +69,20 @@ struct bs_ctx {
 
 namespace {
 
-int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
+// row0/row1: the band of OUTPUT rows to render ([0, height) = the frame).
+int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 = 0, int row1 = -1)
 {
     std::string err;
     std::memset(&p, 0, sizeof p);
     if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
+    if (row1 < 0) row1 = cfg->height;
+    if (row0 < 0 || row1 > cfg->height || row0 >= row1) return fail(BS_EINVAL, "row band must satisfy 0 <= row0 < row1 <= height");
+    p.band_t0 = p.ss ? 2 * row0 : row0;
+    p.band_t1 = p.ss ? 2 * row1 : row1;
     p.max_steps = ctx->max_steps;
     p.disk_slots = ctx->disk_slots;
     {
-        const long tiles = (long)((p.wt + 7) / 8) * ((p.ht + 7) / 8);
+        const long tiles = (long)((p.wt + 7) / 8) * ((p.band_t1 - p.band_t0 + 7) / 8);
         const long waves = (long)ctx->n_cu * 4 * ctx->blocks_per_cu;  // resident wavefronts: blocks_per_cu workgroups of 4 per CU
         p.blocks_per_slot = ctx->n_cu;
         p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
@@ -91,13 +96,14 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p)
     return BS_OK;
 }
 
-int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_doubles, hipStream_t s)
+int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_doubles, hipStream_t s, int row0 = 0, int row1 = -1)
 {
     if (!ctx || !cfg || !d_out) return fail(BS_EINVAL, "null argument");
     bs::TraceParams p;
-    int rc = fill_params(ctx, cfg, p);
+    int rc = fill_params(ctx, cfg, p, row0, row1);
     if (rc) return rc;
-    if (out_doubles < (size_t)cfg->width * cfg->height * 3) return fail(BS_EINVAL, "output buffer too small");
+    if (row1 < 0) row1 = cfg->height;
+    if (out_doubles < (size_t)cfg->width * (size_t)(row1 - row0) * 3) return fail(BS_EINVAL, "output buffer too small");
     p.out = d_out;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, bs::kCounters * sizeof(unsigned long long), s));
@@ -107,7 +113,7 @@ int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_
     HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, bs::kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(ctx->ev2, s));
     ctx->pending = true;
-    ctx->last_rays = (uint64_t)p.wt * (uint64_t)p.ht;
+    ctx->last_rays = (uint64_t)p.wt * (uint64_t)(p.band_t1 - p.band_t0);
     return BS_OK;
 }
 
@@ -375,12 +381,25 @@ int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t 
     return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream));
 }
 
+int bs_render_rows_device(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, void *d_out_rgb, size_t out_doubles, void *hip_stream)
+{
+    if (row1 < 0) return fail(BS_EINVAL, "row band must satisfy 0 <= row0 < row1 <= height");
+    return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream), row0, row1);
+}
+
 int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
+{
+    if (!cfg) return fail(BS_EINVAL, "null argument");
+    return bs_render_rows(ctx, cfg, 0, cfg->height, out_rgb, out_doubles);
+}
+
+int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double *out_rgb, size_t out_doubles)
 {
     if (!ctx || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
     if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
+    if (row0 < 0 || row1 > cfg->height || row0 >= row1) return fail(BS_EINVAL, "row band must satisfy 0 <= row0 < row1 <= height");
     auto t0 = std::chrono::steady_clock::now();
-    size_t need = (size_t)cfg->width * cfg->height * 3;
+    size_t need = (size_t)cfg->width * (size_t)(row1 - row0) * 3;
     if (out_doubles < need) return fail(BS_EINVAL, "output buffer too small");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->img_cap < need) {
@@ -390,7 +409,7 @@ int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_dou
         if (hipMalloc((void **)&ctx->d_img, need * sizeof(double)) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc image failed");
         ctx->img_cap = need;
     }
-    int rc = enqueue_render(ctx, cfg, ctx->d_img, need, ctx->stream);
+    int rc = enqueue_render(ctx, cfg, ctx->d_img, need, ctx->stream, row0, row1);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgb, ctx->d_img, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -64,6 +64,7 @@ struct TraceParams {
     double star_intensity, star_saturation;
     double star_a;               // log 2 / 50 (StarMap.hs:108)
     int32_t wt, ht;              // traced resolution
+    int32_t band_t0, band_t1;    // traced rows [band_t0, band_t1) this launch renders (0, ht for a whole frame); `out` is the band's first row
     int32_t ss;                  // supersampling
     int32_t out_w, out_h;
     int32_t max_steps;

@@ -661,7 +661,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         ly = lane >> 3;
     }
     const int tiles_x = (P.wt + 7) >> 3;
-    const int n_tiles = tiles_x * ((P.ht + 7) >> 3);
+    const int n_tiles = tiles_x * ((P.band_t1 - P.band_t0 + 7) >> 3);  // the band's tiles (a whole frame: band = [0, ht))
 
     // phase stagger (performance only): workgroups b, b+#CU, b+2#CU, ... are the ones observed to share a CU
     if (P.stagger_cycles > 0) {
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         if (tile >= n_tiles) break;
         if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const int xi = tx * 8 + lx, yi = ty * 8 + ly;
-        const bool inb = xi < P.wt && yi < P.ht;
+        const int xi = tx * 8 + lx, yb = ty * 8 + ly, yi = P.band_t0 + yb;  // yb: traced row within the band (band_t0 is even with supersampling)
+        const bool inb = xi < P.wt && yi < P.band_t1;
 
         RayResult res;
         unsigned w_iters;
@@ -703,11 +703,11 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
                 o[c] = 0.25 * (((a + b) + cc) + dd);
             }
             if (inb && (lane & 3) == 0) {
-                double *dst = P.out + ((size_t)(yi >> 1) * P.out_w + (xi >> 1)) * 3;
+                double *dst = P.out + ((size_t)(yb >> 1) * P.out_w + (xi >> 1)) * 3;
                 dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
             }
         } else if (inb) {
-            double *dst = P.out + ((size_t)yi * P.out_w + xi) * 3;
+            double *dst = P.out + ((size_t)yb * P.out_w + xi) * 3;
             dst[0] = res.rgba[0]; dst[1] = res.rgba[1]; dst[2] = res.rgba[2];  // dropAlpha
         }
         stat[0 * kBlock] += (unsigned)res.steps;

@@ -2,8 +2,9 @@
 
 The reference renders a directory of frames sequentially in one process (app/Main.hs:68-77).  Frames are
 independent, so the multi-GPU path has NO data-path collective: every rank renders its own frames with its
-own bs_ctx; the only communication is the final gather of finished frames to rank 0 (RCCL over xGMI when the
-tensors live in HBM, gloo on CPU in tests).  torch.distributed is plumbing here, nothing more.
+own bs_ctx; the only communication is the optional gather of finished frames to rank 0 (RCCL over xGMI when the
+tensors live in HBM, gloo on CPU in tests).  A single huge frame can instead be split into row bands, one per GPU
+(shard_rows / render_frame_by_rows over bs_render_rows).  torch.distributed is plumbing here, nothing more.
 """
 from __future__ import annotations
 
@@ -19,6 +20,46 @@ def shard_frames(n_frames: int, rank: int, world: int) -> List[int]:
 
 def owner_of(frame: int, world: int) -> int:
     return frame % world
+
+
+def shard_rows(height: int, rank: int, world: int) -> "tuple[int, int]":
+    """The band of output rows rank `rank` renders when ONE frame is split over `world` GPUs: contiguous, sizes differ by at
+    most one row, empty (row0 == row1) only if there are more ranks than rows.  Every ray is independent and a supersampled
+    output row only needs its own two traced rows, so bands need no halo (the fallback for single huge frames)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, extra = divmod(max(height, 0), world)
+    row0 = rank * base + min(rank, extra)
+    return row0, row0 + base + (1 if rank < extra else 0)
+
+
+def render_frame_by_rows(height: int, width: int, render_band: Callable[[int, int], "object"], rank: int, world: int,
+                         gather_to: Optional[int] = 0, dist=None):
+    """One frame, row-sharded: this rank renders `render_band(row0, row1) -> (row1-row0, width, 3) tensor`; the bands are
+    gathered on `gather_to` (padded to a common height for the collective, trimmed after) and returned there as the
+    (height, width, 3) frame; other ranks get None.  With gather_to=None the local band is returned as it is."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLC0415
+    if world > height:  # checked identically on every rank, before anything is rendered or any collective is entered
+        raise ValueError(f"{world} ranks for a frame of {height} rows: use world <= height")
+    row0, row1 = shard_rows(height, rank, world)
+    band = render_band(row0, row1)
+    if gather_to is None or world == 1:
+        return band
+    rows_max = -(-height // world)
+    padded = torch.zeros((rows_max, width, 3), dtype=band.dtype, device=band.device)
+    padded[: row1 - row0] = band
+    if rank == gather_to:
+        bufs = [torch.empty_like(padded) for _ in range(world)]
+        dist.gather(padded, bufs, dst=gather_to)
+        parts = []
+        for k in range(world):
+            a, b = shard_rows(height, k, world)
+            parts.append(bufs[k][: b - a])
+        return torch.cat(parts, dim=0)
+    dist.gather(padded, None, dst=gather_to)
+    return None
 
 
 def render_sharded(n_frames: int, render_frame: Callable[[int], "object"], rank: int, world: int, gather_to: Optional[int] = 0,

@@ -30,6 +30,24 @@ def render(cfg, startree: StarTree) -> np.ndarray:
     return out
 
 
+def render_rows(cfg, startree: StarTree, row0: int, row1: int) -> np.ndarray:
+    """Output rows [row0, row1) of the frame `cfg` describes, (row1-row0, width, 3): one band of a frame sharded by rows
+    over several GPUs.  Bands concatenated are bit-identical to render(cfg)."""
+    c = _bs_config(cfg)
+    if not (0 <= row0 < row1 <= c.height):
+        raise ValueError(f"row band [{row0}, {row1}) outside the frame's {c.height} rows")
+    out = np.empty((row1 - row0, c.width, 3), np.float64)
+    _lib.check(_lib.lib().bs_render_rows(startree.handle, C.byref(c), row0, row1, out.ctypes.data, out.size), "bs_render_rows")
+    return out
+
+
+def render_rows_device(cfg, startree: StarTree, row0: int, row1: int, d_out_ptr: int, out_doubles: int, stream_ptr: int = 0) -> None:
+    """render_rows with the band left in HBM at d_out_ptr ((row1-row0)*width*3 doubles)."""
+    c = _bs_config(cfg)
+    _lib.check(_lib.lib().bs_render_rows_device(startree.handle, C.byref(c), row0, row1, d_out_ptr, out_doubles, stream_ptr or None),
+               "bs_render_rows_device")
+
+
 def render_device(cfg, startree: StarTree, d_out_ptr: int, out_doubles: int, stream_ptr: int = 0) -> None:
     """Enqueue a render whose image stays in HBM (d_out_ptr = device pointer, e.g. torch tensor.data_ptr())."""
     c = _bs_config(cfg)

@@ -104,6 +104,13 @@ int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_dou
  * synchronising.  Used by bench.py (inputs/outputs resident) and by on-device post-processing. */
 int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t out_doubles, void *hip_stream);
 
+/* One frame split into horizontal bands (a single huge frame sharded by rows over several GPUs, no halo:
+ * rays are independent and the 2x2 supersample never straddles an output row).  Renders output rows [row0, row1) of the
+ * frame `cfg` describes into a buffer of (row1-row0)*width*3 doubles; the bands of a frame concatenated are bit-identical
+ * to bs_render of the whole frame.  bs_render(ctx, cfg, ...) == bs_render_rows(ctx, cfg, 0, cfg->height, ...). */
+int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double *out_rgb, size_t out_doubles);
+int bs_render_rows_device(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, void *d_out_rgb, size_t out_doubles, void *hip_stream);
+
 /* Batch mode (app/Main.hs:68-77 renders a directory of scenes sequentially with the same tree):
  * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin, one host thread per
  * context); outs[i] is a host buffer of cfgs[i].height*width*3 doubles.  Per context the frames are double-buffered:

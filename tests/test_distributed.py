@@ -58,3 +58,63 @@ def test_two_process_frame_sharding_and_gather(n_frames):
     assert res[0][0] == list(range(0, n_frames, 2)) and res[1][0] == list(range(1, n_frames, 2))
     assert res[1][1] is None
     assert res[0][1] == [i + 0.001 * (i % 2) for i in range(n_frames)]  # frame order restored on the root, each from its owner
+
+
+def test_row_shard_map():
+    from blackstar_amd.distributed import shard_rows
+    assert [shard_rows(1080, r, 8) for r in range(8)] == [(135 * r, 135 * (r + 1)) for r in range(8)]
+    bands = [shard_rows(2161, r, 8) for r in range(8)]  # ragged: sizes differ by at most one, contiguous, cover everything
+    assert bands[0][0] == 0 and bands[-1][1] == 2161 and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+    assert {b - a for a, b in bands} == {270, 271}
+    assert shard_rows(3, 2, 4) == (2, 3) and shard_rows(3, 3, 4) == (3, 3)
+    with pytest.raises(ValueError):
+        shard_rows(10, 4, 4)
+
+
+def _row_worker(rank, world, port, height, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blackstar_amd.distributed import render_frame_by_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bands = []
+
+    def fake_band(row0, row1):  # stands in for bs.render_rows_device: every row carries its own index, every band its rank
+        bands.append((row0, row1))
+        t = torch.arange(row0, row1, dtype=torch.float64).reshape(-1, 1, 1).expand(row1 - row0, 5, 3).clone()
+        t[:, 0, 0] += 0.001 * rank
+        return t
+
+    frame = render_frame_by_rows(height, 5, fake_band, rank, world, gather_to=0)
+    dist.barrier()
+    q.put((rank, bands, None if frame is None else (tuple(frame.shape), [float(v) for v in frame[:, 1, 2]], [float(v) for v in frame[:, 0, 0]])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [8, 9])
+def test_two_process_row_sharding_of_one_frame(height):
+    import torch.multiprocessing as mp
+    from blackstar_amd.distributed import shard_rows
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_row_worker, args=(r, 2, port, height, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, bands, frame = q.get(timeout=120)
+        res[r] = (bands, frame)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == [shard_rows(height, 0, 2)] and res[1][0] == [shard_rows(height, 1, 2)]
+    assert res[1][1] is None
+    shape, rows, tagged = res[0][1]
+    assert shape == (height, 5, 3) and rows == [float(y) for y in range(height)]  # bands re-assembled in row order, padding trimmed
+    split = shard_rows(height, 0, 2)[1]
+    assert tagged == [y + (0.001 if y >= split else 0.0) for y in range(height)]  # each row from the rank that owns it
