@@ -120,6 +120,42 @@ inline Image render(const Config &cfg, const StarTree &tree)
     return img;
 }
 
+// Output rows [row0, row1) of render(cfg): one band of a frame split by rows over several StarTrees / GPUs (bs_render_rows).
+inline Image renderRows(const Config &cfg, const StarTree &tree, int row0, int row1)
+{
+    bs_config c = cfg.to_bs_config();
+    if (c.width <= 0 || row0 < 0 || row1 > c.height || row0 >= row1) throw std::runtime_error("bs_render_rows: bad row band");
+    Image img;
+    img.width = c.width;
+    img.height = row1 - row0;
+    img.rgb.resize((size_t)c.width * img.height * 3);
+    if (bs_render_rows(tree.handle(), &c, row0, row1, img.rgb.data(), img.rgb.size()))
+        throw std::runtime_error(std::string("bs_render_rows: ") + bs_last_error());
+    return img;
+}
+
+// The directory batch mode (app/Main.hs:68-77): scene i on trees[i % trees.size()] (one StarTree per GPU), bs_render_batch.
+inline std::vector<Image> renderBatch(const std::vector<Config> &cfgs, const std::vector<const StarTree *> &trees)
+{
+    if (trees.empty()) throw std::runtime_error("bs_render_batch: no StarTree");
+    std::vector<bs_config> cs;
+    std::vector<Image> imgs(cfgs.size());
+    std::vector<double *> outs;
+    std::vector<bs_ctx *> ctxs;
+    for (const StarTree *t : trees) ctxs.push_back(t->handle());
+    for (size_t i = 0; i < cfgs.size(); i++) {
+        cs.push_back(cfgs[i].to_bs_config());
+        if (cs[i].width <= 0 || cs[i].height <= 0) throw std::runtime_error("bs_render_batch: resolution must be positive");
+        imgs[i].width = cs[i].width;
+        imgs[i].height = cs[i].height;
+        imgs[i].rgb.resize((size_t)cs[i].width * cs[i].height * 3);
+        outs.push_back(imgs[i].rgb.data());
+    }
+    if (!cfgs.empty() && bs_render_batch(ctxs.data(), (int)ctxs.size(), cs.data(), (int)cs.size(), outs.data()))
+        throw std::runtime_error(std::string("bs_render_batch: ") + bs_last_error());
+    return imgs;
+}
+
 // bloom :: Double -> Int -> Image U RGB Double -> IO (Image U RGB Double)
 inline Image bloom(double strength, int divider, const Image &img, const StarTree &tree)
 {

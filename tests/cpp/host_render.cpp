@@ -25,6 +25,14 @@ int main(int argc, char **argv)
         StarTree tree = buildStarTree(readMapFromFile(argv[1]), 0);
         bs_set_mode(tree.handle(), BS_MODE_STRICT);
         Image img = render(cfg, tree);
+        {   // row bands and the batch entry reproduce the frame bit for bit
+            Image top = renderRows(cfg, tree, 0, 19), bottom = renderRows(cfg, tree, 19, 54);
+            std::vector<double> cat = top.rgb;
+            cat.insert(cat.end(), bottom.rgb.begin(), bottom.rgb.end());
+            if (cat != img.rgb) return 6;
+            std::vector<Image> two = renderBatch({cfg, cfg}, {&tree});
+            if (two.size() != 2 || two[0].rgb != img.rgb || two[1].rgb != img.rgb) return 7;
+        }
         if (argc > 3 && !std::strcmp(argv[3], "bloom")) img = bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img, tree);
         FILE *f = std::fopen(argv[2], "wb");
         if (!f) return 3;
