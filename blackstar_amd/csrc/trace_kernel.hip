@@ -537,7 +537,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             // findColor guards on the PRE-step position (:93-95); the cap is ours (the reference has none)
             unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
             if (!(it < P.max_steps)) go = 0;
-            if (go != amask) {  // a guard fired somewhere in the wavefront (rare, wave-uniform branch)
+            if (__builtin_expect(go != amask, 0)) {  // a guard fired somewhere in the wavefront (rare, wave-uniform branch)
                 if (((amask & ~go) >> lane) & 1) {  // this lane: snapshot the state fed to the terminating findColor call
 #pragma unroll
                     for (int i = 0; i < 3; i++) { lds.snap(i) = v[i]; lds.snap(3 + i) = p[i]; }
@@ -549,7 +549,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             }
             double nv[3], np[3], r2n;
             rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
-            if (p[1] * np[1] <= cross_thr) {
+            if (__builtin_expect(p[1] * np[1] <= cross_thr, 0)) {
                 asm volatile("" ::: "memory");  // keeps the lane test below in this rare block (else it is folded into the hot branch)
                 if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n);
             }
@@ -573,7 +573,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         auto step = [&]() -> bool {
             unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
             if (!(it < P.max_steps)) go = 0;
-            if (go != amask) {
+            if (__builtin_expect(go != amask, 0)) {
                 if (((amask & ~go) >> lane) & 1) {
                     lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = vx; lds.snap(3) = vy; lds.snap(4) = r2;
                     lds.steps() = it < P.max_steps ? it + 1 : it;
@@ -584,7 +584,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             double r2n;
             const double r2o = r2, yo = y;
             rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
-            if (yo * y <= cross_thr) {  // the planar y IS the disk-normal coordinate up to a positive factor (PlanarFrame)
+            if (__builtin_expect(yo * y <= cross_thr, 0)) {  // the planar y IS the disk-normal coordinate up to a positive factor (PlanarFrame)
                 asm volatile("" ::: "memory");
                 if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, yo, y, r2o, r2n);
             }
