@@ -26,3 +26,15 @@ def render_batch(cfgs: Sequence, trees: Sequence[StarTree]) -> List[np.ndarray]:
     ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
     _lib.check(_lib.lib().bs_render_batch(ctxs, len(trees), arr, n, ptrs), "bs_render_batch")
     return outs
+
+
+def render_split(cfg, trees: Sequence[StarTree]) -> np.ndarray:
+    """ONE frame over several StarTrees (one per GPU): tree k renders the k-th contiguous band of rows (`bs_render_split`).
+    Bit-identical to render(cfg, trees[0])."""
+    if not trees:
+        raise ValueError("need at least one StarTree")
+    c = _lib.make_config(cfg.to_bs_config() if isinstance(cfg, Config) else cfg)
+    out = np.empty((c.height, c.width, 3), np.float64)
+    ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
+    _lib.check(_lib.lib().bs_render_split(ctxs, len(trees), C.byref(c), out.ctypes.data, out.size), "bs_render_split")
+    return out

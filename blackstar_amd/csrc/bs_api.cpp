@@ -483,6 +483,33 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
     return BS_OK;
 }
 
+int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
+{
+    if (!ctxs || n_ctx <= 0 || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
+    for (int c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
+    if (out_doubles < (size_t)cfg->width * cfg->height * 3) return fail(BS_EINVAL, "output buffer too small");
+    // Context c renders the c-th of n contiguous row bands (sizes differ by at most one row; contexts beyond the number
+    // of rows stay idle), one host thread per context, each copying its band straight into its place in out_rgb.
+    const int n = std::min(n_ctx, cfg->height);
+    const int base = cfg->height / n, extra = cfg->height % n;
+    std::vector<int> rcs(n, BS_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n; c++) {
+        const int row0 = c * base + std::min(c, extra), row1 = row0 + base + (c < extra ? 1 : 0);
+        th.emplace_back([&, c, row0, row1]() {
+            rcs[c] = bs_render_rows(ctxs[c], cfg, row0, row1, out_rgb + (size_t)row0 * cfg->width * 3, (size_t)(row1 - row0) * cfg->width * 3);
+            if (rcs[c]) errs[c] = g_err;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n; c++)
+        if (rcs[c]) return fail(rcs[c], errs[c]);
+    return BS_OK;
+}
+
 int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out)
 {
     if (!ctx || !cfg || (n_rays && (!yx || !out))) return fail(BS_EINVAL, "null argument");

@@ -110,6 +110,10 @@ int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t 
  * to bs_render of the whole frame.  bs_render(ctx, cfg, ...) == bs_render_rows(ctx, cfg, 0, cfg->height, ...). */
 int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double *out_rgb, size_t out_doubles);
 int bs_render_rows_device(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, void *d_out_rgb, size_t out_doubles, void *hip_stream);
+/* The same from one process that holds several contexts (one per GPU): context c renders the c-th of n_ctx contiguous row
+ * bands of the frame (one host thread per context) straight into its place in out_rgb (height*width*3 doubles).  The
+ * result is bit-identical to bs_render on any one of the contexts. */
+int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles);
 
 /* Batch mode (app/Main.hs:68-77 renders a directory of scenes sequentially with the same tree):
  * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin, one host thread per

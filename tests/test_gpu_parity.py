@@ -679,3 +679,20 @@ def test_row_bands_concatenate_to_the_frame(scene, cuts, mode, tree):
         assert L.bs_render_rows(tree.handle, C.byref(c), 0, 3, buf.ctypes.data, buf.size) == -1  # BS_EINVAL: buffer too small
     finally:
         tree.set_mode(_lib.BS_MODE_STRICT)
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2, 3, 7])
+def test_render_split_over_several_contexts(n_ctx, tree, catalogue_bytes):
+    """bs_render_split: one frame over n contexts (here all on device 0; one per GPU in production), each rendering its band
+    of rows from its own host thread straight into the caller's buffer -- bit-identical to the one-context frame."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 80, 45)
+    extra = [bs.StarTree(bs.read_map(catalogue_bytes), device=0) for _ in range(n_ctx - 1)]
+    try:
+        tree.set_mode(_lib.BS_MODE_FAST)
+        for t in extra:
+            t.set_mode(_lib.BS_MODE_FAST)
+        assert np.array_equal(bs.render_split(cfg, [tree] + extra), bs.render(cfg, tree))
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+        for t in extra:
+            t.close()
