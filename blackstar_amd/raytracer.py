@@ -23,9 +23,28 @@ def _bs_config(cfg) -> _lib.BsConfig:
     return _lib.make_config(cfg.to_bs_config() if isinstance(cfg, Config) else cfg)
 
 
-def render(cfg, startree: StarTree) -> np.ndarray:
+def alloc_image(startree: StarTree, height: int, width: int, channels: int = 3, dtype=np.float64) -> np.ndarray:
+    """An image buffer in page-locked host memory (`bs_host_alloc`): the GPU's copy engine writes it directly, so
+    render(cfg, tree, out=buf) delivers a frame without the runtime's staging copies.  Freed when the array (and every view
+    of it) is garbage."""
+    import weakref
+    n = int(height) * int(width) * int(channels) * np.dtype(dtype).itemsize
+    L = _lib.lib()
+    p = L.bs_host_alloc(startree.handle, n)
+    if not p:
+        raise _lib.BlackstarError(f"bs_host_alloc failed: {_lib.last_error()}")
+    raw = (C.c_ubyte * n).from_address(p)
+    weakref.finalize(raw, L.bs_host_free, p)
+    return np.frombuffer(raw, dtype=dtype).reshape(height, width, channels)
+
+
+def render(cfg, startree: StarTree, out: np.ndarray = None) -> np.ndarray:
+    """render cfg tree (src/Raytracer.hs:53).  `out`: an (h, w, 3) C-contiguous float64 array to fill (e.g. from alloc_image)."""
     c = _bs_config(cfg)
-    out = np.empty((c.height, c.width, 3), np.float64)
+    if out is None:
+        out = np.empty((c.height, c.width, 3), np.float64)
+    elif out.shape != (c.height, c.width, 3) or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous float64 array of shape {(c.height, c.width, 3)}")
     _lib.check(_lib.lib().bs_render(startree.handle, C.byref(c), out.ctypes.data, out.size), "bs_render")
     return out
 

@@ -696,3 +696,39 @@ def test_render_split_over_several_contexts(n_ctx, tree, catalogue_bytes):
         tree.set_mode(_lib.BS_MODE_STRICT)
         for t in extra:
             t.close()
+
+
+def test_host_delivery_in_sub_bands_is_invisible(catalogue_bytes, monkeypatch):
+    """bs_render hands a big frame to the host as several consecutive launches whose copies overlap the next launch's
+    kernel (BLACKSTAR_HOST_BANDS, read at bs_create).  Pixels and the frame's statistics must not depend on the split."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 1280, 719)  # 22 MB of f64: above the 8 MiB threshold, odd height
+    frames, stats = [], []
+    for bands in ("1", "4", "7"):
+        monkeypatch.setenv("BLACKSTAR_HOST_BANDS", bands)
+        t = bs.StarTree(bs.read_map(catalogue_bytes), device=0)
+        try:
+            frames.append(bs.render(cfg, t))
+            st = t.stats()
+            stats.append({k: st[k] for k in ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")})
+        finally:
+            t.close()
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    assert stats[0] == stats[1] == stats[2] and stats[0]["rays"] == 4 * 1280 * 719
+
+
+def test_pinned_host_image_buffers(tree):
+    """bs_host_alloc: render into page-locked host memory (the copy engine writes it directly); same pixels, the buffer can be
+    reused across frames and outlives views of it."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 96, 54)
+    buf = bs.alloc_image(tree, 54, 96)
+    img = bs.render(cfg, tree, out=buf)
+    assert img is buf and np.array_equal(buf, bs.render(cfg, tree))
+    view = buf[10:20]
+    del buf, img
+    cfg2 = scenes.with_res(scenes.LENSING_DISK, 96, 54)
+    assert np.isfinite(view).all() and view.shape == (10, 96, 3)
+    big = bs.alloc_image(tree, 719, 1280)  # above the sub-band threshold: asynchronous copies from the copy stream
+    ref = bs.render(scenes.with_res(cfg2, 1280, 719), tree)
+    assert np.array_equal(bs.render(scenes.with_res(cfg2, 1280, 719), tree, out=big), ref)
+    with pytest.raises(ValueError):
+        bs.render(cfg, tree, out=big)
