@@ -38,6 +38,7 @@ __device__ __forceinline__ double quadrance(double x, double y, double z) { retu
 // free and keeps the kernel at <= 111 VGPRs with no scratch.
 __device__ __noinline__ double sin_call(double x) { return sin(x); }
 __device__ __noinline__ double exp_call(double x) { return exp(x); }
+__device__ __noinline__ double pow_call(double x, double y) { return pow(x, y); }
 
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
 __device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
@@ -105,16 +106,27 @@ __device__ __forceinline__ double rm5_fast(double q, double c25, double c4375)
 #endif
 }
 
-// Per-ray step constants of the FAST integrator: k = -(1.5*h2) times the step-size factors of the Nystrom form.
-// c25 = 2.5 pinned in a VGPR pair: gfx950's VOP3 takes no literal and only one SGPR operand, so with both series
-// coefficients as immediates the compiler re-materialises 2.5 with two v_mov_b32 in front of every v_fmac (8 VALU slots
-// per step); one opaque register constant makes p a single v_fma_f64 (4.375 from an opaque SGPR pair, so that no literal v_fmac form is chosen).
-struct PlanarK {
-    double hh2, hhh, h2_6, h6, c25, c4375;
-    __device__ __forceinline__ PlanarK(const TraceParams &P, double k) : hh2(k * P.hh2), hhh(k * P.hhh), h2_6(k * P.h2_6), h6(k * P.h6), c25(2.5), c4375(4.375)
+// Per-ray units of the FAST integrator.  x'' = k x/|x|^5 (k = -(1.5*h2) < 0) integrated with step h is the same discrete
+// map, up to rounding, as X'' = kappa X/|X|^5 with unit step in the variables X = x/s, W = h*vel/s (displacement per
+// step), kappa = k h^2/s^5: RK4 commutes with the rescaling of length and time.  With s = (|k| h^2/4)^(1/5), kappa = -4 and
+// every step constant of the Nystrom form is a literal: p3 = p2 - c1 p, p4 = (p + W) - 2 R, new p = (p + W) - 2/3 S,
+// new W = W - 2/3 T -- no per-lane constants in registers and no multiply to scale c1.  The guards compare the scaled
+// |X|^2 with the per-lane thresholds lo = 1/s^2 (horizon) and hi = safeDistance/s^2.  A ray aimed at the centre has
+// k = 0: s is floored, the force term is then ~1e-150 of the position and the path a straight line, as it should be.
+// c25 / c4375 / m23: 2.5 pinned in a VGPR pair, 4.375 and -2/3 in SGPR pairs (gfx950's VOP3 takes no literal and one
+// SGPR operand; with immediates the compiler re-materialises 2.5 with two v_mov_b32 in front of every v_fmac).
+struct PlanarUnits {
+    double s, inv_s, lo, hi, c25, c4375, m23;
+    __device__ __forceinline__ PlanarUnits(const TraceParams &P, double k) : c25(2.5), c4375(4.375), m23(-2.0 / 3.0)
     {
+        const double a = fabs(k) * P.hh2;  // |k| h^2/4
+        s = a > 1e-150 ? pow_call(a, 0.2) : 1e-30;
+        inv_s = 1.0 / s;
+        lo = inv_s * inv_s;
+        hi = P.safe * lo;
         asm volatile("" : "+v"(c25));
         asm volatile("" : "+s"(c4375));
+        asm volatile("" : "+s"(m23));
     }
 };
 
@@ -206,29 +218,29 @@ struct PlanarFrame {
 //   np = (p + h v) + (h^2/6)(a1 + a2 + a3)                nv = v + (h/6)(a1 + 2(a2 + a3) + a4)
 // Rounding differs from the reference's order at the 1e-16 level per operation (tests: <= 1e-10 on the
 // terminal direction, 1e-4 relative on every pixel of the BASELINE frames).
-// With c_i = |p_i|^-5 (the ray's constant k = -(1.5*h2) is pre-multiplied into the four step constants K), the
-// accelerations a_i = k c_i p_i are never formed: the two weighted sums the update needs are accumulated with FMAs,
-//   R = c2 p2 + c3 p3,   S = c1 p + R  (= (a1+a2+a3)/k),   T = S + R + c4 p4  (= (a1+2a2+2a3+a4)/k),
-// p3 = p2 + (K.hh2 c1) p and p4 = (p + h v) + K.hhh (c2 p2): 23 VALU for the linear algebra of a step (29 with a_i formed).
-__device__ __forceinline__ void rk4_planar(const TraceParams &P, const PlanarK &K, double r2, double &x, double &y, double &vx, double &vy, double &r2n)
+// With c_i = |p_i|^-5 the accelerations a_i = kappa c_i p_i are never formed: the two weighted sums the update needs are
+// accumulated with FMAs,  R = c2 p2 + c3 p3,   S = c1 p + R  (= (a1+a2+a3)/kappa),   T = S + R + c4 p4
+// (= (a1+2a2+2a3+a4)/kappa); in the ray's own units (PlanarUnits: kappa = -4, unit step, w = displacement per step)
+//   p2 = p + w/2     p3 = p2 - c1 p     p4 = (p + w) - 2 c2 p2     np = (p + w) - 2/3 S     nw = w - 2/3 T
+// 22 VALU for the linear algebra of a step (29 with the a_i formed and per-lane constants).
+__device__ __forceinline__ void rk4_planar(const PlanarUnits &U, double r2, double &x, double &y, double &wx, double &wy, double &r2n)
 {
-    const double c1 = rm5_fast(r2, K.c25, K.c4375);
-    double qx = __builtin_fma(P.hh, vx, x), qy = __builtin_fma(P.hh, vy, y);  // p2
-    const double c2 = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
+    const double c1 = rm5_fast(r2, U.c25, U.c4375);
+    double qx = __builtin_fma(0.5, wx, x), qy = __builtin_fma(0.5, wy, y);   // p2
+    const double c2 = rm5_fast(__builtin_fma(qy, qy, qx * qx), U.c25, U.c4375);
     double Rx = c2 * qx, Ry = c2 * qy;
-    const double kc1 = K.hh2 * c1;
-    qx = __builtin_fma(kc1, x, qx); qy = __builtin_fma(kc1, y, qy);          // p3
-    const double c3 = rm5_fast(__builtin_fma(qy, qy, qx * qx), K.c25, K.c4375);
-    const double q0x = __builtin_fma(P.h, vx, x), q0y = __builtin_fma(P.h, vy, y);
-    const double ux = __builtin_fma(K.hhh, Rx, q0x), uy = __builtin_fma(K.hhh, Ry, q0y);  // p4
+    qx = __builtin_fma(-c1, x, qx); qy = __builtin_fma(-c1, y, qy);          // p3
+    const double c3 = rm5_fast(__builtin_fma(qy, qy, qx * qx), U.c25, U.c4375);
+    const double q0x = x + wx, q0y = y + wy;
+    const double ux = __builtin_fma(-2.0, Rx, q0x), uy = __builtin_fma(-2.0, Ry, q0y);  // p4
     Rx = __builtin_fma(c3, qx, Rx); Ry = __builtin_fma(c3, qy, Ry);
-    const double c4 = rm5_fast(__builtin_fma(uy, uy, ux * ux), K.c25, K.c4375);
+    const double c4 = rm5_fast(__builtin_fma(uy, uy, ux * ux), U.c25, U.c4375);
     const double Sx = __builtin_fma(c1, x, Rx), Sy = __builtin_fma(c1, y, Ry);
     const double Tx = __builtin_fma(c4, ux, Sx + Rx), Ty = __builtin_fma(c4, uy, Sy + Ry);
-    x = __builtin_fma(K.h2_6, Sx, q0x);
-    y = __builtin_fma(K.h2_6, Sy, q0y);
-    vx = __builtin_fma(K.h6, Tx, vx);
-    vy = __builtin_fma(K.h6, Ty, vy);
+    x = __builtin_fma(U.m23, Sx, q0x);
+    y = __builtin_fma(U.m23, Sy, q0y);
+    wx = __builtin_fma(U.m23, Tx, wx);
+    wy = __builtin_fma(U.m23, Ty, wy);
     r2n = __builtin_fma(y, y, x * x);
 }
 
@@ -393,12 +405,13 @@ static_assert(kSnapDoubles + kDiskSlots >= 2 * kHitSlots, "the star-hit queue re
 
 struct LaneLds {
     double *col;  // this lane's column: col[word * kBlock]
-    int *ints;    // this lane's ints: ints[0] crossing count (or kOverflow), ints[kBlock] steps
+    int *ints;    // this lane's ints: ints[0] crossing count (or kOverflow), ints[kBlock] steps, ints[2*kBlock] fate
     __device__ __forceinline__ LaneLds(double *area, int *iarea) : col(area + threadIdx.x), ints(iarea + threadIdx.x) {}
     __device__ __forceinline__ double &snap(int k) const { return col[k * kBlock]; }
     __device__ __forceinline__ double &slot(int k) const { return col[(kSnapDoubles + k) * kBlock]; }
     __device__ __forceinline__ int &count() const { return ints[0]; }
     __device__ __forceinline__ int &steps() const { return ints[kBlock]; }
+    __device__ __forceinline__ int &fate() const { return ints[2 * kBlock]; }  // FAST: which guard fired (0 horizon, 1 escape, 2 neither = step cap)
 };
 
 // Disk crossings are rare (~0.2 per ray) but their shading (sqrt, divide, sin) is ~150 instructions that the
@@ -411,10 +424,11 @@ constexpr int kOverflow = 1 << 20;
 // findColor's disk guard (:96-98) for the step (y, r2) -> (yn, r2n).  Callers have already established that
 // y*yn <= 0 (the only way signum y' /= signum y can yield a layer).  A lane whose queue overflows is flagged and
 // keeps stepping (its result is discarded: trace_ray_simple redoes the ray).
-__device__ __forceinline__ void record_crossing(const TraceParams &P, const LaneLds &lds, double y, double yn, double r2, double r2n)
+// r2, r2n may be in the ray's own units of length (FAST): unit2 = s^2 brings r2ave back (1.0, exact, in STRICT).
+__device__ __forceinline__ void record_crossing(const TraceParams &P, const LaneLds &lds, double y, double yn, double r2, double r2n, double unit2)
 {
     if (signum(yn) != signum(y)) {
-        double r2ave = (yn * r2 - y * r2n) / (yn - y);  // :102
+        double r2ave = ((yn * r2 - y * r2n) / (yn - y)) * unit2;  // :102
         if (r2ave > P.in2 && r2ave < P.out2) {           // :97
             int n = lds.count();
             if (n >= P.disk_slots) {
@@ -474,23 +488,25 @@ __device__ __forceinline__ void trace_ray_simple(const TraceParams &P, int yi, i
         }
     } else {
         const PlanarFrame F(P, v);
-        const PlanarK K(P, F.k);
-        double x = F.x, y = F.y, vx = F.vx, vy = F.vy, r2 = __builtin_fma(y, y, x * x);
+        const PlanarUnits U(P, F.k);
+        const double wscale = P.h * U.inv_s;
+        double x = F.x * U.inv_s, y = F.y * U.inv_s, wx = F.vx * wscale, wy = F.vy * wscale, r2 = __builtin_fma(y, y, x * x);
         while (steps < P.max_steps) {
             steps++;
-            if (r2 < 1.0) { fate = 0; break; }
-            if (r2 > P.safe) { fate = 1; break; }
+            if (r2 < U.lo) { fate = 0; break; }
+            if (r2 > U.hi) { fate = 1; break; }
             double r2n;
             const double r2o = r2, yo = y;
-            rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
+            rk4_planar(U, r2o, x, y, wx, wy, r2n);
             if (P.disk_opacity != 0 && !F.in_disk_plane && signum(y) != signum(yo)) {
-                double r2ave = (y * r2o - yo * r2n) / (y - yo);
+                double r2ave = ((y * r2o - yo * r2n) / (y - yo)) * (U.s * U.s);
                 if (r2ave > P.in2 && r2ave < P.out2) { shade_disk(P, r2ave, rgba); ncross++; }
             }
             r2 = r2n;
         }
-        F.to_space(vx, vy, v);
-        F.to_space(x, y, p);
+        const double vscale = U.s / P.h;
+        F.to_space(wx * vscale, wy * vscale, v);
+        F.to_space(x * U.s, y * U.s, p);
     }
     for (int i = 0; i < 3; i++) { out[i] = v[i]; out[3 + i] = p[i]; }
     for (int i = 0; i < 4; i++) out[6 + i] = rgba[i];
@@ -525,7 +541,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
     const unsigned lane = threadIdx.x & 63u;
     unsigned long long amask = __builtin_amdgcn_ballot_w64(live);
     int it = 0;  // iterations of colorize' entered so far (wave-uniform)
-    double r2t;  // r^2 fed to the terminating findColor call (read back from LDS)
+    int fate_code;  // which guard ended the ray: 0 horizon, 1 escape, 2 neither (step cap)
 
     if constexpr (!FAST) {
         // h2 = quadrance (pos `cross` vel)   (:73)
@@ -551,7 +567,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
             if (__builtin_expect(p[1] * np[1] <= cross_thr, 0)) {
                 asm volatile("" ::: "memory");  // keeps the lane test below in this rare block (else it is folded into the hot branch)
-                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n);
+                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n, 1.0);
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
@@ -564,18 +580,22 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             while (step() && step()) {}
 #pragma unroll
         for (int i = 0; i < 3; i++) { v[i] = lds.snap(i); p[i] = lds.snap(3 + i); }
-        r2t = lds.snap(6);
+        const double r2t = lds.snap(6);  // r^2 fed to the terminating findColor call
+        fate_code = r2t < 1.0 ? 0 : (r2t > P.safe ? 1 : 2);
     } else {
         const PlanarFrame F(P, v);
-        const PlanarK K(P, F.k);
+        const PlanarUnits U(P, F.k);
         if (F.in_disk_plane) cross_thr = -__builtin_inf();
-        double x = F.x, y = F.y, vx = F.vx, vy = F.vy, r2 = __builtin_fma(y, y, x * x);
+        const double wscale = P.h * U.inv_s;
+        double x = F.x * U.inv_s, y = F.y * U.inv_s, wx = F.vx * wscale, wy = F.vy * wscale, r2 = __builtin_fma(y, y, x * x);
+        lds.snap(5) = U.s;  // the unit of length is needed again only after the loop (and in the rare crossing block)
         auto step = [&]() -> bool {
-            unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
+            unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < U.lo)) & __builtin_amdgcn_ballot_w64(!(r2 > U.hi));
             if (!(it < P.max_steps)) go = 0;
             if (__builtin_expect(go != amask, 0)) {
                 if (((amask & ~go) >> lane) & 1) {
-                    lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = vx; lds.snap(3) = vy; lds.snap(4) = r2;
+                    lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = wx; lds.snap(3) = wy;
+                    lds.fate() = r2 < U.lo ? 0 : (r2 > U.hi ? 1 : 2);  // which guard fired, decided on the very values the guards compared
                     lds.steps() = it < P.max_steps ? it + 1 : it;
                 }
                 amask = go;
@@ -583,10 +603,13 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             }
             double r2n;
             const double r2o = r2, yo = y;
-            rk4_planar(P, K, r2o, x, y, vx, vy, r2n);
+            rk4_planar(U, r2o, x, y, wx, wy, r2n);
             if (__builtin_expect(yo * y <= cross_thr, 0)) {  // the planar y IS the disk-normal coordinate up to a positive factor (PlanarFrame)
                 asm volatile("" ::: "memory");
-                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, yo, y, r2o, r2n);
+                if (disk && ((amask >> lane) & 1)) {
+                    const double unit = lds.snap(5);
+                    record_crossing(P, lds, yo, y, r2o, r2n, unit * unit);
+                }
             }
             r2 = r2n;
             ++it;
@@ -594,14 +617,15 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         };
         if (amask != 0)  // a wavefront with no ray at all (records kernel tail) must not enter: step() only returns false on a CHANGE of amask
             while (step() && step()) {}
-        // the snapshot is the PRE-step planar state of the terminating iteration (guards precede rk4)
-        x = lds.snap(0); y = lds.snap(1); vx = lds.snap(2); vy = lds.snap(3); r2t = lds.snap(4);
-        F.to_space(vx, vy, v);
-        F.to_space(x, y, p);
+        // the snapshot is the PRE-step planar state of the terminating iteration (guards precede rk4), in the ray's units
+        const double unit = lds.snap(5), vscale = unit / P.h;
+        F.to_space(lds.snap(2) * vscale, lds.snap(3) * vscale, v);
+        F.to_space(lds.snap(0) * unit, lds.snap(1) * unit, p);
+        fate_code = lds.fate();
     }
     int steps = lds.steps();
     int ncross = lds.count();
-    int fate = !live ? -1 : (r2t < 1.0 ? 0 : (r2t > P.safe ? 1 : 2));
+    int fate = !live ? -1 : fate_code;
     double rgba[4] = {0, 0, 0, 0};  // colorize' starts from PixelRGBA 0 0 0 0 (:86)
     if (ncross < kOverflow) {
         for (int k = 0; k < ncross; k++) shade_disk(P, lds.slot(k), rgba);  // blend the recorded layers, oldest first
@@ -646,7 +670,7 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const TraceParams P)
 {
     __shared__ double s_lane[kLaneLdsDoubles];
-    __shared__ int s_ints[2 * kBlock];
+    __shared__ int s_ints[3 * kBlock];
     __shared__ unsigned s_stats[6 * kBlock];
     const LaneLds lds(s_lane, s_ints);
 
@@ -736,7 +760,7 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void trace_records_kernel(const TraceParams P, const int32_t *yx, size_t n_rays, bs_ray_record *out)
 {
     __shared__ double s_lane[kLaneLdsDoubles];
-    __shared__ int s_ints[2 * kBlock];
+    __shared__ int s_ints[3 * kBlock];
     const LaneLds lds(s_lane, s_ints);
     size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = k < n_rays;
