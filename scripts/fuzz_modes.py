@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Stress of FAST against STRICT on the GPU (no oracle: STRICT is the one pinned to it by the test suite): N random scenes,
+including the degenerate geometries the orbital-plane reduction and the per-ray units have to survive -- cameras on the
+axes and in the disk plane, the centre of the hole dead ahead (a purely radial ray: k = 0), very near and very far
+cameras, coarse and fine steps, disks inside the photon sphere.  Prints one JSON summary."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import blackstar_amd as bs
+from blackstar_amd import _lib, synthetic
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rng = np.random.default_rng(424242)
+tree = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_SMALL)))
+tree.set_max_steps(20000)
+RT, AT = 1e-4, 1e-7
+
+
+def scene(i):
+    kind = i % 8
+    r = float(np.exp(rng.uniform(np.log(1.6), np.log(400.0))))
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    if kind == 1: d = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1, 1])          # on an axis
+    if kind == 2: d[1] = 0.0; d /= np.linalg.norm(d)                                 # in the disk plane
+    cam = d * r
+    look = rng.normal(size=3) * rng.uniform(0, 3)
+    if kind in (1, 3): look = np.zeros(3)                                             # the hole dead ahead
+    up = rng.normal(size=3)
+    if kind == 1: up = np.eye(3)[(int(np.argmax(np.abs(d))) + 1) % 3]
+    inner = float(rng.uniform(1.05, 8.0))
+    w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
+    if kind in (1, 3): w |= 1; h |= 1
+    return dict(cam_pos=tuple(map(float, cam)), cam_lookat=tuple(map(float, look)), cam_up=tuple(map(float, up)),
+                fov=float(rng.uniform(0.05, 3.0)), step_size=float(rng.choice([0.05, 0.15, 0.3, 0.5, 1.0])),
+                star_intensity=float(rng.uniform(0.1, 1.0)), star_saturation=float(rng.uniform(0.0, 2.0)),
+                disk_hsi=(float(rng.uniform(0, 0.999)), float(rng.uniform(0, 0.5)), float(rng.uniform(0.3, 1.2))),
+                disk_opacity=float(rng.choice([0.0, 0.5, 0.95, 1.0])), disk_inner=inner, disk_outer=inner + float(rng.uniform(0.5, 30.0)),
+                width=w, height=h, supersampling=bool(rng.integers(0, 2)))
+
+
+out = dict(scenes=0, values=0, outside_tolerance=0, fate_mismatch_scenes=0, step_mismatch_scenes=0, disk_hit_mismatch_scenes=0,
+           worst_abs=0.0, worst_rel=0.0, nonfinite_scenes=0, bad=[])
+for i in range(N):
+    cfg = scene(i)
+    tree.set_mode(_lib.BS_MODE_STRICT); a = bs.render(cfg, tree); sa = tree.stats()
+    tree.set_mode(_lib.BS_MODE_FAST); b = bs.render(cfg, tree); sb = tree.stats()
+    out["scenes"] += 1; out["values"] += a.size
+    if not (np.isfinite(a).all() and np.isfinite(b).all()):
+        out["nonfinite_scenes"] += 1
+    d = np.abs(a - b)
+    bad = int((d > AT + RT * np.abs(a)).sum())
+    out["outside_tolerance"] += bad
+    out["worst_abs"] = max(out["worst_abs"], float(np.nanmax(d)))
+    m = np.abs(a) > 1e-3
+    if m.any(): out["worst_rel"] = max(out["worst_rel"], float(np.nanmax(d[m] / np.abs(a[m]))))
+    f = (sa["horizon"], sa["escaped"], sa["capped"]) != (sb["horizon"], sb["escaped"], sb["capped"])
+    out["fate_mismatch_scenes"] += int(f)
+    out["step_mismatch_scenes"] += int(sa["steps"] != sb["steps"])
+    out["disk_hit_mismatch_scenes"] += int(sa["disk_hits"] != sb["disk_hits"])
+    if (bad or f) and len(out["bad"]) < 5:
+        out["bad"].append(dict(index=i, cfg=cfg, outside=bad, strict=(sa["horizon"], sa["escaped"], sa["capped"], sa["steps"]),
+                               fast=(sb["horizon"], sb["escaped"], sb["capped"], sb["steps"])))
+print(json.dumps(out))
