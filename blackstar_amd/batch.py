@@ -11,14 +11,20 @@ from .config_file import Config
 from .star_map import StarTree
 
 
-def render_batch(cfgs: Sequence, trees: Sequence[StarTree]) -> List[np.ndarray]:
-    """Render cfgs[i] on trees[i % len(trees)] (one StarTree per GPU); per tree, frame k's device-to-host copy overlaps
-    frame k+1's kernel.  Returns the (h, w, 3) float64 images in order."""
+def render_batch(cfgs: Sequence, trees: Sequence[StarTree], outs: Sequence[np.ndarray] = None) -> List[np.ndarray]:
+    """Render cfgs[i] on trees[i % len(trees)] (one StarTree per GPU); per tree two frames are in flight: frame k's
+    device-to-host copy and its end-of-frame tail overlap frame k+1's kernel.  Returns the (h, w, 3) float64 images in order;
+    `outs` supplies the buffers to fill (reused or page-locked ones from alloc_image avoid first-touch page faults)."""
     if not trees:
         raise ValueError("need at least one StarTree")
     cs = [_lib.make_config(c.to_bs_config() if isinstance(c, Config) else c) for c in cfgs]
     n = len(cs)
-    outs = [np.empty((c.height, c.width, 3), np.float64) for c in cs]
+    if outs is None:
+        outs = [np.empty((c.height, c.width, 3), np.float64) for c in cs]
+    else:
+        outs = list(outs)
+        if len(outs) != n or any(o.shape != (c.height, c.width, 3) or o.dtype != np.float64 or not o.flags["C_CONTIGUOUS"] for o, c in zip(outs, cs)):
+            raise ValueError("outs must hold one C-contiguous float64 (h, w, 3) array per frame")
     if n == 0:
         return outs
     arr = (_lib.BsConfig * n)(*cs)

@@ -55,6 +55,8 @@ struct bs_ctx {
     size_t img2_cap = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr;                  // bs_render_batch: odd frames run on a second compute stream with their own counters,
+    unsigned long long *d_counters2 = nullptr;      // so that a frame's first wavefronts fill the slots the previous frame's last tiles leave idle
     double *d_post[3] = {nullptr, nullptr, nullptr};  // bloom ping-pong buffers + host-variant staging
     size_t post_cap = 0;
     unsigned char *d_u8 = nullptr;
@@ -73,7 +75,7 @@ struct bs_ctx {
 namespace {
 
 // row0/row1: the band of OUTPUT rows to render ([0, height) = the frame).
-int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 = 0, int row1 = -1)
+int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 = 0, int row1 = -1, unsigned long long *counters = nullptr)
 {
     std::string err;
     std::memset(&p, 0, sizeof p);
@@ -95,20 +97,31 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
     p.cell_start = ctx->d_cell_start;
-    p.counters = ctx->d_counters;
+    p.counters = counters ? counters : ctx->d_counters;
     return BS_OK;
 }
 
 // first/last: a frame (or band) delivered as several consecutive launches accumulates ONE set of statistics: the counters
 // are cleared and the start event recorded by the first launch only (later ones reset just the tile queue head), the end
 // event and the counter read-back belong to the last.
+// alt_counters: a private counter block (tile queue + statistics nobody reads) for a frame that may run concurrently with
+// another frame of the same context (bs_render_batch); such a launch records no events and leaves bs_stats alone.
 int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_doubles, hipStream_t s, int row0 = 0, int row1 = -1,
-                   bool first = true, bool last = true)
+                   bool first = true, bool last = true, unsigned long long *alt_counters = nullptr)
 {
     if (!ctx || !cfg || !d_out) return fail(BS_EINVAL, "null argument");
     bs::TraceParams p;
-    int rc = fill_params(ctx, cfg, p, row0, row1);
+    int rc = fill_params(ctx, cfg, p, row0, row1, alt_counters);
     if (rc) return rc;
+    if (alt_counters) {
+        if (row1 < 0) row1 = cfg->height;
+        if (out_doubles < (size_t)cfg->width * (size_t)(row1 - row0) * 3) return fail(BS_EINVAL, "output buffer too small");
+        p.out = d_out;
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMemsetAsync(alt_counters, 0, bs::kCounters * sizeof(unsigned long long), s));
+        if (bs::launch_trace(p, ctx->mode, s)) return fail(BS_EDEVICE, "kernel launch failed");
+        return BS_OK;
+    }
     if (row1 < 0) row1 = cfg->height;
     if (out_doubles < (size_t)cfg->width * (size_t)(row1 - row0) * 3) return fail(BS_EINVAL, "output buffer too small");
     p.out = d_out;
@@ -234,6 +247,8 @@ void bs_destroy(bs_ctx *ctx)
         if (ctx->d_img) (void)hipFree(ctx->d_img);
         if (ctx->d_img2) (void)hipFree(ctx->d_img2);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ctx->d_counters2) (void)hipFree(ctx->d_counters2);
         for (hipEvent_t e : ctx->ev_frame)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->ev_band)
@@ -500,19 +515,27 @@ static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *c
     };
     if (!grow(ctx->d_img, ctx->img_cap) || !grow(ctx->d_img2, ctx->img2_cap)) return fail(BS_ENOMEM, "hipMalloc image failed");
     if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->d_counters2) HIP_TRY(hipMalloc((void **)&ctx->d_counters2, 2 * bs::kCounters * sizeof(unsigned long long)));
     for (hipEvent_t &e : ctx->ev_frame)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // Frame k: image buf[k&1], compute stream cs[k&1], counter block k&1 -- two frames can be in flight, and the persistent
+    // wavefronts of frame k+1 take over the slots frame k's wavefronts leave as its tile queue runs dry (the end-of-frame
+    // tail and the copy both disappear behind the neighbouring frame).
     double *buf[2] = {ctx->d_img, ctx->d_img2};
+    hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+    unsigned long long *ctr[2] = {ctx->d_counters2, ctx->d_counters2 + bs::kCounters};
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // a pending bs_render_device of this context owns d_counters; let it finish
     int k = 0;
-    int rc = enqueue_render(ctx, &cfgs[first], buf[0], need, ctx->stream);
+    int rc = enqueue_render(ctx, &cfgs[first], buf[0], need, cs[0], 0, -1, true, true, ctr[0]);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev_frame[0], ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_frame[0], cs[0]));
     for (int i = first; i < n_frames; i += step, k++) {
         const int nxt = i + step;
         if (nxt < n_frames) {  // buf[(k+1)&1] is free: its previous copy was waited for before this point
-            rc = enqueue_render(ctx, &cfgs[nxt], buf[(k + 1) & 1], need, ctx->stream);
+            rc = enqueue_render(ctx, &cfgs[nxt], buf[(k + 1) & 1], need, cs[(k + 1) & 1], 0, -1, true, true, ctr[(k + 1) & 1]);
             if (rc) return rc;
-            HIP_TRY(hipEventRecord(ctx->ev_frame[(k + 1) & 1], ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->ev_frame[(k + 1) & 1], cs[(k + 1) & 1]));
         }
         HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_frame[k & 1], 0));
         HIP_TRY(hipMemcpyAsync(outs[i], buf[k & 1], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
