@@ -133,37 +133,57 @@ struct PlanarUnits {
 // STRICT: one classical RK4 step of y' = f(y), f(vel,pos) = (-(c*pos), vel)   (Raytracer.hs:113-134), the
 // reference's operation order, one IEEE operation each (this TU is compiled -ffp-contract=off).
 // r2 = quadrance pos on entry (carried from the previous step's findColor), r2n = quadrance newPos on exit.
-__device__ __forceinline__ void rk4_strict(const TraceParams &P, double h2c, double r2, const double v[3], const double p[3], double nv[3],
-                                           double np[3], double &r2n)
+// In two halves so that the stepping loop can take its ballots in between: the new POSITION needs only k1..k3
+// (its k4 term is vel + a3*h), the new velocity needs the fourth force evaluation.
+struct StrictMid {
+    double a1[3], a2[3], a3[3], q4[3];  // the three accelerations so far and the stage-4 position
+};
+
+__device__ __forceinline__ void rk4_strict_position(const TraceParams &P, double h2c, double r2, const double v[3], const double p[3], double np[3],
+                                                    double &r2n, StrictMid &M)
 {
     const double h = P.h, hh = P.hh, h6 = P.h6;
-    double a1[3], a2[3], a3[3], a4[3], v2[3], v3[3], v4[3], q[3];
+    double v2[3], v3[3], v4[3], q[3];
     double c = coef_strict(h2c, r2);
 #pragma unroll
-    for (int i = 0; i < 3; i++) a1[i] = -(c * p[i]);
+    for (int i = 0; i < 3; i++) M.a1[i] = -(c * p[i]);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { v2[i] = v[i] + a1[i] * hh; q[i] = p[i] + v[i] * hh; }
+    for (int i = 0; i < 3; i++) { v2[i] = v[i] + M.a1[i] * hh; q[i] = p[i] + v[i] * hh; }
     c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
-    for (int i = 0; i < 3; i++) a2[i] = -(c * q[i]);
+    for (int i = 0; i < 3; i++) M.a2[i] = -(c * q[i]);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { v3[i] = v[i] + a2[i] * hh; q[i] = p[i] + v2[i] * hh; }
+    for (int i = 0; i < 3; i++) { v3[i] = v[i] + M.a2[i] * hh; q[i] = p[i] + v2[i] * hh; }
     c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
 #pragma unroll
-    for (int i = 0; i < 3; i++) a3[i] = -(c * q[i]);
+    for (int i = 0; i < 3; i++) M.a3[i] = -(c * q[i]);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { v4[i] = v[i] + a3[i] * h; q[i] = p[i] + v3[i] * h; }
-    c = coef_strict(h2c, quadrance(q[0], q[1], q[2]));
-#pragma unroll
-    for (int i = 0; i < 3; i++) a4[i] = -(c * q[i]);
+    for (int i = 0; i < 3; i++) { v4[i] = v[i] + M.a3[i] * h; M.q4[i] = p[i] + v3[i] * h; }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double sv = ((a1[i] + a2[i] * 2) + a3[i] * 2) + a4[i];  // sumK = ((k1 + 2 k2) + 2 k3) + k4
-        double sp = ((v[i] + v2[i] * 2) + v3[i] * 2) + v4[i];
-        nv[i] = v[i] + sv * h6;
+        double sp = ((v[i] + v2[i] * 2) + v3[i] * 2) + v4[i];  // sumK = ((k1 + 2 k2) + 2 k3) + k4, position rows
         np[i] = p[i] + sp * h6;
     }
     r2n = quadrance(np[0], np[1], np[2]);
+}
+
+__device__ __forceinline__ void rk4_strict_velocity(const TraceParams &P, double h2c, const StrictMid &M, const double v[3], double nv[3])
+{
+    const double c = coef_strict(h2c, quadrance(M.q4[0], M.q4[1], M.q4[2]));
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double a4 = -(c * M.q4[i]);
+        double sv = ((M.a1[i] + M.a2[i] * 2) + M.a3[i] * 2) + a4;  // velocity rows of sumK
+        nv[i] = v[i] + sv * P.h6;
+    }
+}
+
+__device__ __forceinline__ void rk4_strict(const TraceParams &P, double h2c, double r2, const double v[3], const double p[3], double nv[3],
+                                           double np[3], double &r2n)
+{
+    StrictMid M;
+    rk4_strict_position(P, h2c, r2, v, p, np, r2n, M);
+    rk4_strict_velocity(P, h2c, M, v, nv);
 }
 
 // Orbital-plane frame of a ray (FAST).  With e1 = pos/|pos| (the camera direction, wave-uniform, from the host) and
@@ -223,7 +243,13 @@ struct PlanarFrame {
 // (= (a1+2a2+2a3+a4)/kappa); in the ray's own units (PlanarUnits: kappa = -4, unit step, w = displacement per step)
 //   p2 = p + w/2     p3 = p2 - c1 p     p4 = (p + w) - 2 c2 p2     np = (p + w) - 2/3 S     nw = w - 2/3 T
 // 22 VALU for the linear algebra of a step (29 with the a_i formed and per-lane constants).
-__device__ __forceinline__ void rk4_planar(const PlanarUnits &U, double r2, double &x, double &y, double &wx, double &wy, double &r2n)
+// Split in two so that the stepping loop can take its ballots between the halves: the new POSITION needs only stages 1-3.
+struct PlanarMid {
+    double ux, uy, Rx, Ry, Sx, Sy;  // p4 and the partial sums stage 4 completes
+};
+
+// stages 1-3 and the position update: x, y become the new position, r2n its square
+__device__ __forceinline__ void rk4_planar_position(const PlanarUnits &U, double r2, double &x, double &y, double wx, double wy, double &r2n, PlanarMid &M)
 {
     const double c1 = rm5_fast(r2, U.c25, U.c4375);
     double qx = __builtin_fma(0.5, wx, x), qy = __builtin_fma(0.5, wy, y);   // p2
@@ -232,16 +258,28 @@ __device__ __forceinline__ void rk4_planar(const PlanarUnits &U, double r2, doub
     qx = __builtin_fma(-c1, x, qx); qy = __builtin_fma(-c1, y, qy);          // p3
     const double c3 = rm5_fast(__builtin_fma(qy, qy, qx * qx), U.c25, U.c4375);
     const double q0x = x + wx, q0y = y + wy;
-    const double ux = __builtin_fma(-2.0, Rx, q0x), uy = __builtin_fma(-2.0, Ry, q0y);  // p4
-    Rx = __builtin_fma(c3, qx, Rx); Ry = __builtin_fma(c3, qy, Ry);
-    const double c4 = rm5_fast(__builtin_fma(uy, uy, ux * ux), U.c25, U.c4375);
-    const double Sx = __builtin_fma(c1, x, Rx), Sy = __builtin_fma(c1, y, Ry);
-    const double Tx = __builtin_fma(c4, ux, Sx + Rx), Ty = __builtin_fma(c4, uy, Sy + Ry);
-    x = __builtin_fma(U.m23, Sx, q0x);
-    y = __builtin_fma(U.m23, Sy, q0y);
+    M.ux = __builtin_fma(-2.0, Rx, q0x); M.uy = __builtin_fma(-2.0, Ry, q0y);  // p4
+    M.Rx = __builtin_fma(c3, qx, Rx); M.Ry = __builtin_fma(c3, qy, Ry);
+    M.Sx = __builtin_fma(c1, x, M.Rx); M.Sy = __builtin_fma(c1, y, M.Ry);
+    x = __builtin_fma(U.m23, M.Sx, q0x);
+    y = __builtin_fma(U.m23, M.Sy, q0y);
+    r2n = __builtin_fma(y, y, x * x);
+}
+
+// stage 4 and the velocity update
+__device__ __forceinline__ void rk4_planar_velocity(const PlanarUnits &U, const PlanarMid &M, double &wx, double &wy)
+{
+    const double c4 = rm5_fast(__builtin_fma(M.uy, M.uy, M.ux * M.ux), U.c25, U.c4375);
+    const double Tx = __builtin_fma(c4, M.ux, M.Sx + M.Rx), Ty = __builtin_fma(c4, M.uy, M.Sy + M.Ry);
     wx = __builtin_fma(U.m23, Tx, wx);
     wy = __builtin_fma(U.m23, Ty, wy);
-    r2n = __builtin_fma(y, y, x * x);
+}
+
+__device__ __forceinline__ void rk4_planar(const PlanarUnits &U, double r2, double &x, double &y, double &wx, double &wy, double &r2n)
+{
+    PlanarMid M;
+    rk4_planar_position(U, r2, x, y, wx, wy, r2n, M);
+    rk4_planar_velocity(U, M, wx, wy);
 }
 
 // Per-star colour of starLookup's renderPixel (StarMap.hs:105-114), added to the running sum.  toPixelRGB (PixelHSI h s i)
@@ -549,9 +587,12 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         const double h2c = 1.5 * quadrance(cx, cy, cz);
         double r2 = quadrance(p[0], p[1], p[2]);
         // one iteration of colorize'; returns false once no lane of the wavefront is stepping
+        // `ok`, `crossed`: see the FAST branch below -- the guards of the next state and the crossing test are ballots taken as
+        // soon as their operands exist and consumed by scalar branches, so a step is one basic block.
+        unsigned long long ok = __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
         auto step = [&]() -> bool {
             // findColor guards on the PRE-step position (:93-95); the cap is ours (the reference has none)
-            unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2 > P.safe));
+            unsigned long long go = amask & ok;
             if (!(it < P.max_steps)) go = 0;
             if (__builtin_expect(go != amask, 0)) {  // a guard fired somewhere in the wavefront (rare, wave-uniform branch)
                 if (((amask & ~go) >> lane) & 1) {  // this lane: snapshot the state fed to the terminating findColor call
@@ -564,10 +605,15 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
                 if (go == 0) return false;
             }
             double nv[3], np[3], r2n;
-            rk4_strict(P, h2c, r2, v, p, nv, np, r2n);
-            if (__builtin_expect(p[1] * np[1] <= cross_thr, 0)) {
-                asm volatile("" ::: "memory");  // keeps the lane test below in this rare block (else it is folded into the hot branch)
-                if (disk && ((amask >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n, 1.0);
+            StrictMid M;
+            rk4_strict_position(P, h2c, r2, v, p, np, r2n, M);
+            ok = __builtin_amdgcn_ballot_w64(!(r2n < 1.0)) & __builtin_amdgcn_ballot_w64(!(r2n > P.safe));
+            const unsigned long long crossed = __builtin_amdgcn_ballot_w64(p[1] * np[1] <= cross_thr);
+            __builtin_amdgcn_sched_barrier(0);  // the compares issue here, a quarter of a step ahead of the scalar code that reads them
+            rk4_strict_velocity(P, h2c, M, v, nv);
+            if (__builtin_expect(crossed != 0, 0)) {
+                asm volatile("" ::"v"(nv[0]), "v"(nv[1]), "v"(nv[2]) : "memory");  // lane test stays here, the whole step stays in front of the branch
+                if (disk && (((amask & crossed) >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n, 1.0);
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
@@ -589,8 +635,14 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         const double wscale = P.h * U.inv_s;
         double x = F.x * U.inv_s, y = F.y * U.inv_s, wx = F.vx * wscale, wy = F.vy * wscale, r2 = __builtin_fma(y, y, x * x);
         lds.snap(5) = U.s;  // the unit of length is needed again only after the loop (and in the rare crossing block)
+        // `ok`: the guards of the state about to be stepped, as a wave-uniform mask.  It is computed at the END of the step that
+        // produced that state (and before the loop for the first one), so the two v_cmp are long retired when the scalar
+        // unit combines them at the top of the next step; likewise the crossing compare is a ballot taken as soon as the new
+        // y exists and tested with a scalar branch at the end.  A step is one basic block with two (rare) scalar exits --
+        // no VALU -> SALU -> branch round trip sits on the wavefront's critical path.
+        unsigned long long ok = __builtin_amdgcn_ballot_w64(!(r2 < U.lo)) & __builtin_amdgcn_ballot_w64(!(r2 > U.hi));
         auto step = [&]() -> bool {
-            unsigned long long go = amask & __builtin_amdgcn_ballot_w64(!(r2 < U.lo)) & __builtin_amdgcn_ballot_w64(!(r2 > U.hi));
+            unsigned long long go = amask & ok;
             if (!(it < P.max_steps)) go = 0;
             if (__builtin_expect(go != amask, 0)) {
                 if (((amask & ~go) >> lane) & 1) {
@@ -603,10 +655,17 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             }
             double r2n;
             const double r2o = r2, yo = y;
-            rk4_planar(U, r2o, x, y, wx, wy, r2n);
-            if (__builtin_expect(yo * y <= cross_thr, 0)) {  // the planar y IS the disk-normal coordinate up to a positive factor (PlanarFrame)
-                asm volatile("" ::: "memory");
-                if (disk && ((amask >> lane) & 1)) {
+            PlanarMid M;
+            rk4_planar_position(U, r2o, x, y, wx, wy, r2n, M);
+            ok = __builtin_amdgcn_ballot_w64(!(r2n < U.lo)) & __builtin_amdgcn_ballot_w64(!(r2n > U.hi));
+            const unsigned long long crossed = __builtin_amdgcn_ballot_w64(yo * y <= cross_thr);  // the planar y IS the disk-normal coordinate up to a positive factor (PlanarFrame)
+            __builtin_amdgcn_sched_barrier(0);  // the three compares issue HERE, a quarter of a step ahead of the scalar code that reads them
+            rk4_planar_velocity(U, M, wx, wy);
+            if (__builtin_expect(crossed != 0, 0)) {
+                // keeps the lane test in this rare block; naming the new velocity as an input keeps the whole step in front
+                // of the branch (otherwise stage 4 is sunk below it and the compare -> branch latency is exposed again)
+                asm volatile("" ::"v"(wx), "v"(wy) : "memory");
+                if (disk && (((amask & crossed) >> lane) & 1)) {
                     const double unit = lds.snap(5);
                     record_crossing(P, lds, yo, y, r2o, r2n, unit * unit);
                 }
