@@ -5,7 +5,7 @@ import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = tempfile.mkdtemp()
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-save-temps",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-save-temps", *os.environ.get("BS_EXTRA", "").split(),
                        "-c", os.path.join(ROOT, "blackstar_amd/csrc/trace_kernel.hip"), "-o", "/dev/null"], cwd=d, stderr=subprocess.DEVNULL)
 S = open(os.path.join(d, "trace_kernel-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
 for kname, mode in (("trace_frame_kernelILb1E", "FAST"), ("trace_frame_kernelILb0E", "STRICT")):
