@@ -4,6 +4,7 @@ import argparse
 import os
 import sys
 
+os.environ.setdefault("BLACKSTAR_HOST_BANDS", "1")  # ONE launch per frame (what bs_render_device / bench.py do), so per-launch counters are per frame
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import blackstar_amd as bs  # noqa: E402
