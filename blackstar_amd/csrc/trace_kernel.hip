@@ -38,7 +38,6 @@ __device__ __forceinline__ double quadrance(double x, double y, double z) { retu
 // free and keeps the kernel at <= 111 VGPRs with no scratch.
 __device__ __noinline__ double sin_call(double x) { return sin(x); }
 __device__ __noinline__ double exp_call(double x) { return exp(x); }
-__device__ __noinline__ double pow_call(double x, double y) { return pow(x, y); }
 
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
 __device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
@@ -112,16 +111,24 @@ __device__ __forceinline__ double rm5_fast(double q, double c25, double c4375)
 // every step constant of the Nystrom form is a literal: p3 = p2 - c1 p, p4 = (p + W) - 2 R, new p = (p + W) - 2/3 S,
 // new W = W - 2/3 T -- no per-lane constants in registers and no multiply to scale c1.  The guards compare the scaled
 // |X|^2 with the per-lane thresholds lo = 1/s^2 (horizon) and hi = safeDistance/s^2.  A ray aimed at the centre has
-// k = 0: s is floored, the force term is then ~1e-150 of the position and the path a straight line, as it should be.
+// k = 0: s is floored at 1e-6 (|k| h^2/4 at 1e-30, an impact parameter of ~1e-14), the force term is then ~1e-30 of the
+// position and the path a straight line, as it should be.
 // c25 / c4375 / m23: 2.5 pinned in a VGPR pair, 4.375 and -2/3 in SGPR pairs (gfx950's VOP3 takes no literal and one
 // SGPR operand; with immediates the compiler re-materialises 2.5 with two v_mov_b32 in front of every v_fmac).
 struct PlanarUnits {
     double s, inv_s, lo, hi, c25, c4375, m23;
     __device__ __forceinline__ PlanarUnits(const TraceParams &P, double k) : c25(2.5), c4375(4.375), m23(-2.0 / 3.0)
     {
-        const double a = fabs(k) * P.hh2;  // |k| h^2/4
-        s = a > 1e-150 ? pow_call(a, 0.2) : 1e-30;
-        inv_s = 1.0 / s;
+        // 1/s = a^(-1/5), a = |k| h^2/4: seed from the f32 log2/exp2 units (2^-21), one cubic step of the series of
+        // (1-e)^(-1/5), e = 1 - a t^5 (error ~0.09 e^3 < 1e-17), no divide; s = a t^4.  a is floored at 1e-30 (s = 1e-6).
+        const double a = fmax(fabs(k) * P.hh2, 1e-30);
+        double t = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)a));
+        double t2 = t * t, t4 = t2 * t2;
+        const double e = __builtin_fma(-a, t4 * t, 1.0);
+        t = __builtin_fma(t * e, __builtin_fma(0.12, e, 0.2), t);
+        inv_s = t;
+        t2 = t * t; t4 = t2 * t2;
+        s = a * t4;
         lo = inv_s * inv_s;
         hi = P.safe * lo;
         asm volatile("" : "+v"(c25));
