@@ -28,11 +28,6 @@ constexpr int kBlock = 256;  // 4 wavefronts per workgroup; each wavefront trace
 
 __device__ __forceinline__ double quadrance(double x, double y, double z) { return (x * x + y * y) + z * z; }
 
-// Wave-level "any": the ballot builtin on a bool (HIP's __any/__ballot take an int, which always costs a
-// v_cndmask + v_cmp round trip; this form is free when the operand is a fresh compare, and costs that same pair
-// only when it is a loop-carried mask).
-[[maybe_unused]] __device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
-
 // libm calls as REAL calls.  ocml's f64 sin / cos / exp carry a large-argument (Payne-Hanek) path that is never taken
 // here but costs ~30 VGPRs wherever it is inlined; the shading code sits outside the stepping loop, so a call is
 // free and keeps the kernel at <= 111 VGPRs with no scratch.
