@@ -96,7 +96,9 @@ void bs_destroy(bs_ctx *ctx);
 
 /* Replaces: render cfg tree (src/Raytracer.hs:53-67) at its only call site app/Main.hs:109.
  * Blocking.  Fills out_rgb[height*width*3], interleaved RGB f64, row-major (y down), linear light,
- * unclamped, already supersample-reduced -- the `Image S RGB Double` layout the Haskell shim wraps. */
+ * unclamped, already supersample-reduced -- the `Image S RGB Double` layout the Haskell shim wraps.
+ * (A large frame is traced as two consecutive launches of half the rows each, so that the first half's copy to the host
+ * overlaps the second half's kernel; pixels and bs_stats are those of the whole frame.) */
 int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles);
 
 /* Same, but the image stays in HBM: d_out_rgb is a device pointer on the context's device, the work is
@@ -126,8 +128,9 @@ int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double
 
 /* Batch mode (app/Main.hs:68-77 renders a directory of scenes sequentially with the same tree):
  * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin, one host thread per
- * context); outs[i] is a host buffer of cfgs[i].height*width*3 doubles.  Per context the frames are double-buffered:
- * frame k's device-to-host copy overlaps frame k+1's kernel. */
+ * context); outs[i] is a host buffer of cfgs[i].height*width*3 doubles.  Per context two frames are in flight (two device
+ * images, two compute streams, one copy stream): frame k's device-to-host copy and its end-of-frame tail overlap frame
+ * k+1's kernel.  bs_stats is not updated by batch frames. */
 int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs);
 
 /* ---- "next" rows: the two steps after render in app/Main.hs:113-123, kept on the device ---- */
