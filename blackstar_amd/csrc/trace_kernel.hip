@@ -163,7 +163,9 @@ __device__ __forceinline__ void rk4_strict_position(const TraceParams &P, double
     for (int i = 0; i < 3; i++) { v4[i] = v[i] + M.a3[i] * h; M.q4[i] = p[i] + v3[i] * h; }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double sp = ((v[i] + v2[i] * 2) + v3[i] * 2) + v4[i];  // sumK = ((k1 + 2 k2) + 2 k3) + k4, position rows
+        // sumK = ((k1 + 2 k2) + 2 k3) + k4, position rows.  x*2 is exact, so k + x*2 rounds once either way: the FMA form
+        // returns the same bits as the reference's multiply-then-add with one instruction less per term.
+        double sp = __builtin_fma(v3[i], 2.0, __builtin_fma(v2[i], 2.0, v[i])) + v4[i];
         np[i] = p[i] + sp * h6;
     }
     r2n = quadrance(np[0], np[1], np[2]);
@@ -175,7 +177,7 @@ __device__ __forceinline__ void rk4_strict_velocity(const TraceParams &P, double
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double a4 = -(c * M.q4[i]);
-        double sv = ((M.a1[i] + M.a2[i] * 2) + M.a3[i] * 2) + a4;  // velocity rows of sumK
+        double sv = __builtin_fma(M.a3[i], 2.0, __builtin_fma(M.a2[i], 2.0, M.a1[i])) + a4;  // velocity rows of sumK (exact doubling, see above)
         nv[i] = v[i] + sv * P.h6;
     }
 }
