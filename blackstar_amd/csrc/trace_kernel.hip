@@ -116,14 +116,18 @@ struct PlanarUnits {
     {
         // 1/s = a^(-1/5), a = |k| h^2/4: seed from the f32 log2/exp2 units (2^-21), one cubic step of the series of
         // (1-e)^(-1/5), e = 1 - a t^5 (error ~0.09 e^3 < 1e-17), no divide; s = a t^4.  a is floored at 1e-30 (s = 1e-6).
+        // a = ar * 32^m with ar in [1/16, 32) (exact: powers of two), so the f32 seed never leaves its range whatever the
+        // camera distance, and a^(-1/5) = ar^(-1/5) * 2^-m exactly.
         const double a = fmax(fabs(k) * P.hh2, 1e-30);
-        double t = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)a));
+        const int m = __builtin_amdgcn_frexp_exp(a) / 5;
+        const double ar = __builtin_ldexp(a, -5 * m);
+        double t = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)ar));
         double t2 = t * t, t4 = t2 * t2;
-        const double e = __builtin_fma(-a, t4 * t, 1.0);
+        const double e = __builtin_fma(-ar, t4 * t, 1.0);
         t = __builtin_fma(t * e, __builtin_fma(0.12, e, 0.2), t);
-        inv_s = t;
         t2 = t * t; t4 = t2 * t2;
-        s = a * t4;
+        inv_s = __builtin_ldexp(t, -m);
+        s = __builtin_ldexp(ar * t4, m);  // a^(1/5) = ar^(1/5) * 2^m = ar * t^4 * 2^m
         lo = inv_s * inv_s;
         hi = P.safe * lo;
         asm volatile("" : "+v"(c25));

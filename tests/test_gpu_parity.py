@@ -369,6 +369,8 @@ EDGE_CASES = {
     "camera_in_disk_plane_radial_centre_ray": dict(cam_pos=(0.0, 0.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 1.0, 0.0)),
     "camera_inside_horizon": dict(cam_pos=(0.0, 0.5, 0.3)),
     "camera_far_away_safe_distance_from_camera": dict(cam_pos=(0.0, 10.0, -100.0)),
+    # |pos x vel|^2 ~ 1e44: beyond the f32 range the FAST units seed must not depend on; every ray runs into the step cap
+    "camera_absurdly_far": dict(cam_pos=(0.0, 1.0e21, -1.0e22), fov=1.0e-3),
     "small_steps": dict(step_size=0.05),
     "large_steps": dict(step_size=0.9),
     "tiny_steps_long_integration": dict(step_size=0.01),
