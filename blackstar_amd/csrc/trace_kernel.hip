@@ -436,8 +436,8 @@ __device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int x
 // inside it, costs register copies EVERY iteration (exit merges become phis in blocks all lanes run; and a
 // partially masked body cannot update state in place because the compiler's liveness is per register, not
 // per lane).  So: nothing leaves the loop through registers.  When a lane's guard fires it writes its
-// terminal state and step count to its LDS column (a rare block placed BEFORE the RK4 body) and is marked
-// inactive; the body itself runs UNMASKED for all 64 lanes -- a finished lane just keeps stepping, its later
+// terminal state and step count to its LDS column (a rare block placed BEFORE the RK4 body) and leaves the
+// wavefront's active mask; the body itself runs UNMASKED for all 64 lanes -- a finished lane just keeps stepping, its later
 // values are never looked at (f64 VALU has no slow path for the inf/NaN a captured lane can produce) -- and
 // updates the state in place.  The code after the loop reloads everything from LDS.
 // Layout: [word][thread] -- consecutive lanes touch consecutive 8-byte words: conflict-free.
@@ -445,7 +445,7 @@ constexpr int kDiskSlots = 4;
 #ifndef BS_SNAP
 #define BS_SNAP 7
 #endif
-constexpr int kSnapDoubles = BS_SNAP;  // STRICT: vel[3], pos[3], r2; FAST: x, y, vx, vy, r2
+constexpr int kSnapDoubles = BS_SNAP;  // STRICT: vel[3], pos[3], r2; FAST: x, y, wx, wy (in the ray's units), -, the unit of length s
 constexpr int kLaneLdsDoubles = (kSnapDoubles + kDiskSlots) * kBlock;
 static_assert(kSnapDoubles + kDiskSlots >= 2 * kHitSlots, "the star-hit queue reuses the lane columns");
 

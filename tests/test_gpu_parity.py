@@ -2,7 +2,7 @@
 (libblackstar_gpu.so via ctypes); the oracle and the committed golden vectors are only the checkers.
 
 Bars: STRICT mode -- trajectories (step counts, fates, terminal vel/pos, disk crossings, star hit sets)
-bit-exact; colours within 1e-12 (device exp/sin/cos differ from glibc in the last ulp).  FAST mode -- the
+bit-exact; colours within 1e-12 (device exp/sin differ from glibc in the last ulp).  FAST mode -- the
 north_star tolerance, 1e-4 relative (+1e-7 absolute) per channel per pixel.
 """
 import ctypes as C
@@ -58,7 +58,7 @@ def test_device_sqrt_and_divide_are_correctly_rounded(tree_empty):
 
 
 def test_hardware_rsq_seed_precision(tree_empty):
-    """FAST mode refines v_rsq_f64 with one cubic Newton step (error ~ e^3): the seed must be good to ~2^-20."""
+    """FAST mode corrects the v_rsq_f64 seed with a 2nd-order series (error ~ e^3): the seed must be good to ~2^-20."""
     rng = np.random.default_rng(12)
     n = 1 << 18
     a = np.exp(rng.uniform(np.log(1e-4), np.log(1e5), n))
