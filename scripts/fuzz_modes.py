@@ -2,7 +2,8 @@
 """Stress of FAST against STRICT on the GPU (no oracle: STRICT is the one pinned to it by the test suite): N random scenes,
 including the degenerate geometries the orbital-plane reduction and the per-ray units have to survive -- cameras on the
 axes and in the disk plane, the centre of the hole dead ahead (a purely radial ray: k = 0), very near and very far
-cameras, coarse and fine steps, disks inside the photon sphere.  Prints one JSON summary."""
+cameras, coarse and fine steps, disks inside the photon sphere.  Prints one JSON summary.
+Usage: fuzz_modes.py [N_SCENES [SEED]]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +11,7 @@ import blackstar_amd as bs
 from blackstar_amd import _lib, synthetic
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-rng = np.random.default_rng(424242)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 424242)
 tree = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_SMALL)))
 tree.set_max_steps(20000)
 RT, AT = 1e-4, 1e-7
