@@ -109,12 +109,28 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
     };
     // prologue: everything the first tile touches (rows [0, T + r)) straight into the ring, all 256 threads;
     // the loaders also start fetching what tile 1 will lead with.
-    for (int e = tid; e < (kLT + r) * 3 * kLP; e += 256) {
-        const int m = e / ((kLT + r) * 3), q = e - m * (kLT + r) * 3, row = q / 3, c = q - 3 * row;
-        const double val = (row < n && p0 + m < P) ? in[((long)(p0 + m) * n + row) * 3 + c] : 0.0;
-        const int ri = row & (kLR - 1);
-        ring[ri * kLC + 3 * m + c] = val;
-        if (ri < 8) ring[(ri + kLR) * kLC + 3 * m + c] = val;
+    {   // eight loads in flight per thread, THEN their ring writes: one load -> wait -> write per trip exposed the full HBM
+        // latency 18 times per sweep (the 25 us fixed cost of a sweep)
+        constexpr int kU = 8;
+        const int per_px = (kLT + r) * 3, total = per_px * kLP;
+        for (int e0 = tid; e0 < total; e0 += 256 * kU) {
+            double val[kU];
+            int at[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int e = e0 + 256 * u;
+                const int m = e / per_px, q = e - m * per_px, row = q / 3, c = q - 3 * row;
+                val[u] = (e < total && row < n && p0 + m < P) ? in[((long)(p0 + m) * n + row) * 3 + c] : 0.0;
+                at[u] = e < total ? (row & (kLR - 1)) * kLC + 3 * m + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                if (at[u] >= 0) {
+                    ring[at[u]] = val[u];
+                    if (at[u] < 8 * kLC) ring[at[u] + kLR * kLC] = val[u];  // rows 0..7 mirrored past the end
+                }
+            }
+        }
     }
     if (!consumer) fetch(kLT + r);
     __syncthreads();
@@ -124,7 +140,15 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
     if (owner) {  // startVal = foldl1' add (pix <$> take r crds)   (ImageFilters.hs:59)
         const int m = r < n ? r : n;
         s = ring[lane];
-        for (int i = 1; i < m; i++) s = s + ring[(i & (kLR - 1)) * kLC + lane];
+        int i = 1;
+        for (; i + 8 <= m; i += 8) {  // the eight ring reads first, then the eight (ordered) adds
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t8[u] = ring[((i + u) & (kLR - 1)) * kLC + lane];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s = s + t8[u];
+        }
+        for (; i < m; i++) s = s + ring[(i & (kLR - 1)) * kLC + lane];
     }
     const int tiles = (n + kLT - 1) / kLT;
     for (int k = 0; k < tiles; k++) {
