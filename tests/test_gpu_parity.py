@@ -734,3 +734,20 @@ def test_pinned_host_image_buffers(tree):
     assert np.array_equal(bs.render(scenes.with_res(cfg2, 1280, 719), tree, out=big), ref)
     with pytest.raises(ValueError):
         bs.render(cfg, tree, out=big)
+
+
+@pytest.mark.parametrize("mode", [_lib.BS_MODE_STRICT, _lib.BS_MODE_FAST])
+def test_photon_ring_matches_the_reference_repositorys_example_image(mode, tree_empty):
+    """The GPU render of scenes/default.yaml at 1280x720 against the one picture the reference repository holds (example.png,
+    README.md:4; tests/golden/make_reference_ring.py): the thin photon ring inside the shadow sits where the reference's
+    own output has it -- to a fraction of a pixel, at every angle where both show a distinct ring."""
+    from conftest import ring_offsets_vs_reference_example
+    tree_empty.set_mode(mode)
+    try:
+        img = bs.render(scenes.with_res(scenes.DEFAULT, 1280, 720), tree_empty)
+    finally:
+        tree_empty.set_mode(_lib.BS_MODE_STRICT)
+    d, n = ring_offsets_vs_reference_example(img)
+    print(f"ring radius, reference example.png - GPU: mean {d.mean():+.2f} px, std {d.std():.2f}, max |d| {np.abs(d).max():.2f} over {len(d)}/{n} angles")
+    assert len(d) >= 0.85 * n
+    assert abs(d.mean()) < 0.5 and d.std() < 0.8 and np.abs(d).max() <= 2.5

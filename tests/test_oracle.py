@@ -254,3 +254,20 @@ def test_config0_default_640x480_cpu_path(oracle, oracle_index):
     np.testing.assert_allclose(img[g["ys"], g["xs"]], g["samples"], rtol=1e-13, atol=1e-15)
     np.testing.assert_allclose(img.reshape(-1, 3).sum(axis=0), g["channel_sums"], rtol=1e-12)
     assert abs(st["steps"] / st["rays"] - 224.0) < 0.1  # mean 224.0 steps per ray on C1
+
+
+def test_photon_ring_matches_the_reference_repositorys_example_image(oracle, oracle_index_empty):
+    """The only rendered output the reference holds is example.png (README.md:4): the scenes/default.yaml camera at
+    1280x720 from an unknown revision (different disk colour and bloom, real catalogue) -- no pixel golden.  But the thin
+    photon ring inside the shadow depends only on generateRay (fov convention, look-at basis, aspect ratio) and on the
+    geodesic integration: the oracle's ring must sit where the reference's own picture has it."""
+    from conftest import ring_offsets_vs_reference_example
+    img, _ = oracle.render(scenes.with_res(scenes.DEFAULT, 1280, 720), oracle_index_empty, threads=0)
+    d, n = ring_offsets_vs_reference_example(img)
+    print(f"ring radius, reference example.png - oracle: mean {d.mean():+.2f} px, std {d.std():.2f}, max |d| {np.abs(d).max():.2f} over {len(d)}/{n} angles")
+    assert len(d) >= 0.85 * n
+    assert abs(d.mean()) < 0.5 and d.std() < 0.8 and np.abs(d).max() <= 2.5
+    # negative control: the comparison resolves a 2 % change of the field of view (ring radius 114 px -> about 2.3 px)
+    wide = dict(scenes.with_res(scenes.DEFAULT, 1280, 720), fov=1.5 * 1.02)
+    d2, _ = ring_offsets_vs_reference_example(oracle.render(wide, oracle_index_empty, threads=0)[0])
+    assert len(d2) >= 0.7 * n and d2.mean() > 1.5
