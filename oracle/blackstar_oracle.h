@@ -10,7 +10,15 @@
  * deps un-vendored: resolver lts-13.16, stack.yaml:1).  This restatement is
  * pinned instead by (1) an independent numpy restatement (oracle/np_oracle.py),
  * (2) 50-digit mpmath evaluation of the same discrete RK4 map, (3) physics and
- * colour known-answer tests -- see tests/ and DESIGN.md section "Oracle".
+ * colour known-answer tests, and (4) the ONE rendered output the reference
+ * repository holds, example.png (README.md:4: the default.yaml camera at 1280x720
+ * from an unknown revision -- other disk colours and bloom, so no pixel golden):
+ * the thin photon ring inside the shadow depends only on generateRay and on the
+ * integration, and this oracle's ring sits on the reference's to +0.24 +- 0.40 px
+ * at 88 of 90 angles (tests/golden/make_reference_ring.py, tests/test_oracle.py).
+ * That pins the camera model and the geodesics against the reference's own
+ * output; operation order and the third-party colour / normalise / in-radius
+ * semantics stay unpinned -- see tests/ and DESIGN.md section "Oracle".
  *
  * Struct layouts are deliberately identical to include/blackstar_gpu.h so one
  * ctypes.Structure serves both; the code is independent.
