@@ -6,7 +6,6 @@ the `StarTree` you render with, or let a lazily created context on device 0 be u
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import numpy as np

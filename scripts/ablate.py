@@ -2,7 +2,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import blackstar_amd as bs
-from blackstar_amd import _lib, synthetic
+from blackstar_amd import synthetic
 from oracle import scenes
 stars = bs.read_map(synthetic.ppm_catalogue_bytes())
 full = bs.StarTree(stars); empty = bs.StarTree(None)

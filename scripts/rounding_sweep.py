@@ -2,7 +2,6 @@
 """Large randomised check that the device f64 sqrt / divide used by STRICT mode are correctly rounded: hipcc's lowering
 (bare=0) and the scaling-free sequences inside the RK4 RHS (bare=1), 2^27 operand pairs each in the ranges the RHS sees
 (r^2 in [1e-3, 1e5]; numerators 1.5 h^2 in [1e-6, 1e4], denominators r^5) plus a wide log-uniform range."""
-import ctypes as C
 import json
 import os
 import sys
