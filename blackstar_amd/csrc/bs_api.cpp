@@ -47,27 +47,45 @@ struct bs_ctx {
     bs::StarColor *d_colors = nullptr;
     uint32_t *d_cell_start = nullptr;
     size_t n_entries = 0;  // stars + border duplicates in the direction grid
-    unsigned long long *d_counters = nullptr;
-    unsigned long long *h_counters = nullptr;  // pinned
+    // Every render (one launch, or the consecutive launches of one host-delivered frame) owns a LaunchSlot: its tile queue
+    // head + statistics block in HBM, the pinned landing area of that block and its events.  Launches of one context on
+    // DIFFERENT streams therefore never share a queue head (two persistent kernels popping one counter would each skip
+    // the tiles the other took); a slot is reused kSlots renders later, after waiting for its previous owner.
+    struct LaunchSlot {
+        unsigned long long *d_counters = nullptr;  // device, bs::kCounters
+        unsigned long long *h_counters = nullptr;  // pinned, bs::kCounters
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel start / kernel end (timing)
+        hipEvent_t ev_done = nullptr;              // everything of the render (incl. the counter read-back) has been enqueued before it
+        bool used = false;
+        uint64_t rays = 0;
+    };
+    static constexpr int kSlots = 8;
+    LaunchSlot slots[kSlots];
+    unsigned long long *d_counters = nullptr;  // kSlots * bs::kCounters, carved into the slots
+    unsigned long long *h_counters = nullptr;  // pinned, same shape
+    int next_slot = 0;
+    int cur_slot = -1;    // slot of the render being enqueued (first .. last launch)
+    int stats_slot = -1;  // slot whose statistics bs_stats reports
+    void *d_scratch = nullptr;  // persistent device scratch of the batched hooks (bs_star_lookup, bs_trace_rays, ...)
+    size_t scratch_cap = 0;
     double *d_img = nullptr;                   // scratch image for bs_render (host-output variant)
     size_t img_cap = 0;
     double *d_img2 = nullptr;                  // second image + copy stream: bs_render_batch overlaps frame i's D2H with frame i+1's kernel
     size_t img2_cap = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};
-    hipStream_t stream2 = nullptr;                  // bs_render_batch: odd frames run on a second compute stream with their own counters,
-    unsigned long long *d_counters2 = nullptr;      // so that a frame's first wavefronts fill the slots the previous frame's last tiles leave idle
+    hipStream_t stream2 = nullptr;                  // bs_render_batch: odd frames run on a second compute stream, so that a frame's
+                                                    // first wavefronts fill the slots the previous frame's last tiles leave idle
     double *d_post[3] = {nullptr, nullptr, nullptr};  // bloom ping-pong buffers + host-variant staging
     size_t post_cap = 0;
     unsigned char *d_u8 = nullptr;
     size_t u8_cap = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // kernel start / kernel end / counters landed
+    hipEvent_t ev_u0 = nullptr, ev_u1 = nullptr;  // bs_debug_ubench timing
     static constexpr int kMaxHostBands = 8;
     int host_bands = 2;  // bs_render[_rows]: launches per frame (2 measured best: 5.22 ms vs 5.62 with 1 and 5.35 with 4 for a 1080p 4xSS frame), so that band k's device-to-host copy overlaps band k+1's kernel (env BLACKSTAR_HOST_BANDS)
     hipEvent_t ev_band[kMaxHostBands] = {};
     bool pending = false;  // a render has been enqueued whose stats were not read back yet
-    uint64_t last_rays = 0;
     double last_wall_ms = 0;
     bs_stats_t stats{};
 };
@@ -75,7 +93,7 @@ struct bs_ctx {
 namespace {
 
 // row0/row1: the band of OUTPUT rows to render ([0, height) = the frame).
-int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 = 0, int row1 = -1, unsigned long long *counters = nullptr)
+int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 = 0, int row1 = -1)
 {
     std::string err;
     std::memset(&p, 0, sizeof p);
@@ -97,49 +115,79 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
     p.cell_start = ctx->d_cell_start;
-    p.counters = counters ? counters : ctx->d_counters;
+    p.counters = ctx->d_counters;  // enqueue_render substitutes the launch slot's block
     return BS_OK;
 }
 
-// first/last: a frame (or band) delivered as several consecutive launches accumulates ONE set of statistics: the counters
-// are cleared and the start event recorded by the first launch only (later ones reset just the tile queue head), the end
-// event and the counter read-back belong to the last.
-// alt_counters: a private counter block (tile queue + statistics nobody reads) for a frame that may run concurrently with
-// another frame of the same context (bs_render_batch); such a launch records no events and leaves bs_stats alone.
+// On every exit path of a blocking entry point nothing of the call may still be in flight: the caller's buffers are DMA
+// targets, and after an error return the caller is free to release them.  (On the success path the streams have been
+// synchronised already and this costs a few microseconds.)
+struct StreamDrain {
+    bs_ctx *ctx;
+    explicit StreamDrain(bs_ctx *c) : ctx(c) {}
+    StreamDrain(const StreamDrain &) = delete;
+    StreamDrain &operator=(const StreamDrain &) = delete;
+    ~StreamDrain()
+    {
+        if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+        for (hipStream_t s : {ctx->stream, ctx->stream2, ctx->copy_stream})
+            if (s) (void)hipStreamSynchronize(s);
+    }
+};
+
+int ensure_scratch(bs_ctx *ctx, size_t bytes)
+{
+    if (ctx->scratch_cap >= bytes) return BS_OK;
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr;
+    ctx->scratch_cap = 0;
+    const size_t cap = std::max<size_t>(bytes, size_t(1) << 20);
+    if (hipMalloc(&ctx->d_scratch, cap) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc scratch failed");
+    ctx->scratch_cap = cap;
+    return BS_OK;
+}
+
+// first/last: a frame (or band) delivered as several consecutive launches accumulates ONE set of statistics: the first
+// launch takes the next LaunchSlot, clears its counters and records the start event (later ones reset just the tile queue
+// head); the end event, the counter read-back and ev_done belong to the last.
+// quiet: a batch frame (bs_render_batch) -- same slot discipline, but no timing events, no read-back, bs_stats untouched.
 int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_doubles, hipStream_t s, int row0 = 0, int row1 = -1,
-                   bool first = true, bool last = true, unsigned long long *alt_counters = nullptr)
+                   bool first = true, bool last = true, bool quiet = false)
 {
     if (!ctx || !cfg || !d_out) return fail(BS_EINVAL, "null argument");
     bs::TraceParams p;
-    int rc = fill_params(ctx, cfg, p, row0, row1, alt_counters);
+    int rc = fill_params(ctx, cfg, p, row0, row1);
     if (rc) return rc;
-    if (alt_counters) {
-        if (row1 < 0) row1 = cfg->height;
-        if (out_doubles < (size_t)cfg->width * (size_t)(row1 - row0) * 3) return fail(BS_EINVAL, "output buffer too small");
-        p.out = d_out;
-        HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMemsetAsync(alt_counters, 0, bs::kCounters * sizeof(unsigned long long), s));
-        if (bs::launch_trace(p, ctx->mode, s)) return fail(BS_EDEVICE, "kernel launch failed");
-        return BS_OK;
-    }
     if (row1 < 0) row1 = cfg->height;
     if (out_doubles < (size_t)cfg->width * (size_t)(row1 - row0) * 3) return fail(BS_EINVAL, "output buffer too small");
     p.out = d_out;
     HIP_TRY(hipSetDevice(ctx->device));
     if (first) {
-        HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, bs::kCounters * sizeof(unsigned long long), s));
-        HIP_TRY(hipEventRecord(ctx->ev0, s));
-        ctx->last_rays = 0;
-    } else {
-        HIP_TRY(hipMemsetAsync(ctx->d_counters + (bs::kCounters - 1), 0, sizeof(unsigned long long), s));  // tile queue head
+        bs_ctx::LaunchSlot &sl = ctx->slots[ctx->next_slot];
+        if (sl.used) HIP_TRY(hipEventSynchronize(sl.ev_done));  // its owner of kSlots renders ago (normally long finished)
+        ctx->cur_slot = ctx->next_slot;
+        ctx->next_slot = (ctx->next_slot + 1) % bs_ctx::kSlots;
+        sl.rays = 0;
+        HIP_TRY(hipMemsetAsync(sl.d_counters, 0, bs::kCounters * sizeof(unsigned long long), s));
+        if (!quiet) HIP_TRY(hipEventRecord(sl.ev0, s));
     }
+    if (ctx->cur_slot < 0) return fail(BS_EINTERNAL, "continuation launch without a first one");
+    bs_ctx::LaunchSlot &sl = ctx->slots[ctx->cur_slot];
+    if (!first) HIP_TRY(hipMemsetAsync(sl.d_counters + (bs::kCounters - 1), 0, sizeof(unsigned long long), s));  // tile queue head
+    p.counters = sl.d_counters;
     if (bs::launch_trace(p, ctx->mode, s)) return fail(BS_EDEVICE, "kernel launch failed");
-    ctx->last_rays += (uint64_t)p.wt * (uint64_t)(p.band_t1 - p.band_t0);
+    sl.rays += (uint64_t)p.wt * (uint64_t)(p.band_t1 - p.band_t0);
     if (last) {
-        HIP_TRY(hipEventRecord(ctx->ev1, s));
-        HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, bs::kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(ctx->ev2, s));
-        ctx->pending = true;
+        if (!quiet) {
+            HIP_TRY(hipEventRecord(sl.ev1, s));
+            HIP_TRY(hipMemcpyAsync(sl.h_counters, sl.d_counters, bs::kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipEventRecord(sl.ev_done, s));
+        sl.used = true;
+        if (!quiet) {
+            ctx->stats_slot = ctx->cur_slot;
+            ctx->pending = true;
+        }
     }
     return BS_OK;
 }
@@ -148,18 +196,19 @@ int resolve_stats(bs_ctx *ctx)
 {
     if (!ctx->pending) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->ev2));
+    bs_ctx::LaunchSlot &sl = ctx->slots[ctx->stats_slot];
+    HIP_TRY(hipEventSynchronize(sl.ev_done));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
     bs_stats_t &st = ctx->stats;
-    st.rays = ctx->last_rays;
-    st.steps = ctx->h_counters[0];
-    st.capped = ctx->h_counters[1];
-    st.horizon = ctx->h_counters[2];
-    st.escaped = ctx->h_counters[3];
-    st.disk_hits = ctx->h_counters[4];
-    st.star_hits = ctx->h_counters[5];
-    st.wave_iters = ctx->h_counters[6];
+    st.rays = sl.rays;
+    st.steps = sl.h_counters[0];
+    st.capped = sl.h_counters[1];
+    st.horizon = sl.h_counters[2];
+    st.escaped = sl.h_counters[3];
+    st.disk_hits = sl.h_counters[4];
+    st.star_hits = sl.h_counters[5];
+    st.wave_iters = sl.h_counters[6];
     st.kernel_ms = ms;
     st.wall_ms = ctx->last_wall_ms;
     ctx->pending = false;
@@ -216,16 +265,22 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     }
     bool good = ok(hipSetDevice(device), "hipSetDevice") &&
                 ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
-                ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev1), "hipEventCreate") &&
-                ok(hipEventCreate(&ctx->ev2), "hipEventCreate") &&
+                ok(hipEventCreate(&ctx->ev_u0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev_u1), "hipEventCreate") &&
                 ok(hipMalloc((void **)&ctx->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(bs::StarNode)), "hipMalloc nodes") &&
                 ok(hipMalloc((void **)&ctx->d_colors, std::max<size_t>(1, colors.size()) * sizeof(bs::StarColor)), "hipMalloc colors") &&
                 ok(hipMalloc((void **)&ctx->d_cell_start, cell_start.size() * sizeof(uint32_t)), "hipMalloc cell_start") &&
                 ok(hipMemcpy(ctx->d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "upload cell_start") &&
-                ok(hipMalloc((void **)&ctx->d_counters, bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
-                ok(hipHostMalloc((void **)&ctx->h_counters, bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
+                ok(hipMalloc((void **)&ctx->d_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
+                ok(hipHostMalloc((void **)&ctx->h_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
                 ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
                 ok(hipMemcpy(ctx->d_colors, colors.data(), colors.size() * sizeof(bs::StarColor), hipMemcpyHostToDevice), "upload colors");
+    for (int k = 0; good && k < bs_ctx::kSlots; k++) {
+        bs_ctx::LaunchSlot &sl = ctx->slots[k];
+        sl.d_counters = ctx->d_counters + (size_t)k * bs::kCounters;
+        sl.h_counters = ctx->h_counters + (size_t)k * bs::kCounters;
+        good = ok(hipEventCreate(&sl.ev0), "hipEventCreate") && ok(hipEventCreate(&sl.ev1), "hipEventCreate") &&
+               ok(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming), "hipEventCreate");
+    }
     if (!good) {
         std::string keep = g_err;
         bs_destroy(ctx);
@@ -248,7 +303,10 @@ void bs_destroy(bs_ctx *ctx)
         if (ctx->d_img2) (void)hipFree(ctx->d_img2);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
         if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-        if (ctx->d_counters2) (void)hipFree(ctx->d_counters2);
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        for (bs_ctx::LaunchSlot &sl : ctx->slots)
+            for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev_done})
+                if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->ev_frame)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->ev_band)
@@ -257,9 +315,8 @@ void bs_destroy(bs_ctx *ctx)
             if (b) (void)hipFree(b);
         if (ctx->d_u8) (void)hipFree(ctx->d_u8);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-        if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+        if (ctx->ev_u0) (void)hipEventDestroy(ctx->ev_u0);
+        if (ctx->ev_u1) (void)hipEventDestroy(ctx->ev_u1);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -316,6 +373,7 @@ int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, 
     size_t n = (size_t)width * height * 3;
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
+    StreamDrain drain(ctx);
     HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     rc = bs_bloom_device(ctx, ctx->d_post[2], ctx->d_post[2], width, height, strength, divider, ctx->stream);
     if (rc) return rc;
@@ -332,6 +390,7 @@ int bs_supersample(bs_ctx *ctx, const double *in, double *out, int width2, int h
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_post(ctx, n_in);
     if (rc) return rc;
+    StreamDrain drain(ctx);
     HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (bs::launch_supersample(ctx->d_post[2], ctx->d_post[0], width2, height2, ctx->stream)) return fail(BS_EDEVICE, "supersample launch failed");
     HIP_TRY(hipMemcpyAsync(out, ctx->d_post[0], n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -361,6 +420,7 @@ int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
         if (hipMalloc((void **)&ctx->d_u8, n_values) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc failed");
         ctx->u8_cap = n_values;
     }
+    StreamDrain drain(ctx);
     HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_values * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n_values, ctx->stream);
     if (rc) return rc;
@@ -386,6 +446,7 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
         if (hipMalloc((void **)&ctx->d_u8, n) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc failed");
         ctx->u8_cap = n;
     }
+    StreamDrain drain(ctx);
     // doRender (app/Main.hs:105-123): render -> bloom if bloomStrength /= 0 -> writeImg's sRGB + toWord8, all in HBM
     rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
     if (rc) return rc;
@@ -460,6 +521,7 @@ int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double
     // Host delivery of a big image: the frame goes out as a few consecutive launches (sub-bands of rows) and the copy
     // stream moves sub-band k to the caller while sub-band k+1 is being traced -- all but the last copy are hidden behind
     // the kernels (49.8 MB of f64 take about 1 ms to reach host memory that has been touched before, pinned or not).
+    StreamDrain drain(ctx);  // no DMA into out_rgb may outlive this call, whichever way it returns
     const int rows = row1 - row0;
     int nb = need * sizeof(double) >= (size_t(8) << 20) ? ctx->host_bands : 1;
     nb = std::max(1, std::min(nb, std::min(rows / 4, (int)bs_ctx::kMaxHostBands)));
@@ -516,24 +578,23 @@ static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *c
     if (!grow(ctx->d_img, ctx->img_cap) || !grow(ctx->d_img2, ctx->img2_cap)) return fail(BS_ENOMEM, "hipMalloc image failed");
     if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    if (!ctx->d_counters2) HIP_TRY(hipMalloc((void **)&ctx->d_counters2, 2 * bs::kCounters * sizeof(unsigned long long)));
     for (hipEvent_t &e : ctx->ev_frame)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // Frame k: image buf[k&1], compute stream cs[k&1], counter block k&1 -- two frames can be in flight, and the persistent
+    // Frame k: image buf[k&1], compute stream cs[k&1], its own launch slot -- two frames can be in flight, and the persistent
     // wavefronts of frame k+1 take over the slots frame k's wavefronts leave as its tile queue runs dry (the end-of-frame
     // tail and the copy both disappear behind the neighbouring frame).
     double *buf[2] = {ctx->d_img, ctx->d_img2};
     hipStream_t cs[2] = {ctx->stream, ctx->stream2};
-    unsigned long long *ctr[2] = {ctx->d_counters2, ctx->d_counters2 + bs::kCounters};
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // a pending bs_render_device of this context owns d_counters; let it finish
+    // From here on work is in flight whose DMA targets are the caller's outs[]: every return path drains the streams first.
+    StreamDrain drain(ctx);
     int k = 0;
-    int rc = enqueue_render(ctx, &cfgs[first], buf[0], need, cs[0], 0, -1, true, true, ctr[0]);
+    int rc = enqueue_render(ctx, &cfgs[first], buf[0], need, cs[0], 0, -1, true, true, /*quiet=*/true);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_frame[0], cs[0]));
     for (int i = first; i < n_frames; i += step, k++) {
         const int nxt = i + step;
         if (nxt < n_frames) {  // buf[(k+1)&1] is free: its previous copy was waited for before this point
-            rc = enqueue_render(ctx, &cfgs[nxt], buf[(k + 1) & 1], need, cs[(k + 1) & 1], 0, -1, true, true, ctr[(k + 1) & 1]);
+            rc = enqueue_render(ctx, &cfgs[nxt], buf[(k + 1) & 1], need, cs[(k + 1) & 1], 0, -1, true, true, /*quiet=*/true);
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ctx->ev_frame[(k + 1) & 1], cs[(k + 1) & 1]));
         }
@@ -601,20 +662,16 @@ int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n
     if (rc) return rc;
     if (n_rays == 0) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    int32_t *d_yx = nullptr;
-    bs_ray_record *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_yx, n_rays * 2 * sizeof(int32_t)));
-    if (hipMalloc((void **)&d_out, n_rays * sizeof(bs_ray_record)) != hipSuccess) {
-        (void)hipFree(d_yx);
-        return fail(BS_ENOMEM, "hipMalloc records failed");
-    }
-    hipError_t e = hipMemcpyAsync(d_yx, yx, n_rays * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && bs::launch_trace_records(p, ctx->mode, d_yx, n_rays, d_out, ctx->stream)) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n_rays * sizeof(bs_ray_record), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_yx);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_trace_rays: ") + hipGetErrorString(e));
+    const size_t yx_bytes = (n_rays * 2 * sizeof(int32_t) + 255) & ~size_t(255);
+    rc = ensure_scratch(ctx, yx_bytes + n_rays * sizeof(bs_ray_record));
+    if (rc) return rc;
+    int32_t *d_yx = static_cast<int32_t *>(ctx->d_scratch);
+    bs_ray_record *d_out = reinterpret_cast<bs_ray_record *>(static_cast<char *>(ctx->d_scratch) + yx_bytes);
+    StreamDrain drain(ctx);
+    HIP_TRY(hipMemcpyAsync(d_yx, yx, n_rays * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (bs::launch_trace_records(p, ctx->mode, d_yx, n_rays, d_out, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
+    HIP_TRY(hipMemcpyAsync(out, d_out, n_rays * sizeof(bs_ray_record), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
 }
 
@@ -642,18 +699,17 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
     p.colors = ctx->d_colors;
     p.cell_start = ctx->d_cell_start;
     HIP_TRY(hipSetDevice(ctx->device));
-    double *d = nullptr;
-    int32_t *dh = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 6 * n * sizeof(double)));
-    if (hipMalloc((void **)&dh, n * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d); return fail(BS_ENOMEM, "hipMalloc failed"); }
-    hipError_t e = hipMemcpy(d, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && bs::launch_star_lookup(p, d, n, d + 3 * n, dh, ctx->stream)) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(out_rgb, d + 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && out_hits) e = hipMemcpy(out_hits, dh, n * sizeof(int32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    (void)hipFree(dh);
-    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_star_lookup: ") + hipGetErrorString(e));
+    // persistent scratch (grown on demand, kept for the life of the context): [dirs 3n | rgb 3n] doubles, then n hit counts
+    int rc = ensure_scratch(ctx, 6 * n * sizeof(double) + n * sizeof(int32_t));
+    if (rc) return rc;
+    double *d = static_cast<double *>(ctx->d_scratch);
+    int32_t *dh = reinterpret_cast<int32_t *>(d + 6 * n);
+    StreamDrain drain(ctx);
+    HIP_TRY(hipMemcpyAsync(d, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (bs::launch_star_lookup(p, d, n, d + 3 * n, dh, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
+    HIP_TRY(hipMemcpyAsync(out_rgb, d + 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_hits) HIP_TRY(hipMemcpyAsync(out_hits, dh, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
 }
 
@@ -665,12 +721,12 @@ int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms
     HIP_TRY(hipMalloc((void **)&d, 64));
     hipError_t e = hipSuccess;
     if (bs::launch_ubench(kind, blocks, 16, d, ctx->stream)) e = hipErrorLaunchFailure;  // warm-up
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_u0, ctx->stream);
     if (e == hipSuccess && bs::launch_ubench(kind, blocks, iters, d, ctx->stream)) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
-    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_u1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev_u1);
     float ms = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev_u0, ctx->ev_u1);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_debug_ubench: ") + hipGetErrorString(e));
     *out_ms = ms;

@@ -721,9 +721,9 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 }
 
 // Frame kernel: PERSISTENT wavefronts.  The grid is sized to fill the chip once (P.grid_blocks workgroups of 4
-// wavefronts, <= 4 per CU); each workgroup stages the top of the split array in LDS once, then every wavefront
-// independently pulls 8x8-pixel tiles of traced rays off a device-wide counter until the frame is done -- no
-// workgroup barrier after the prologue, no per-tile dispatch, one flush of the statistics per wavefront.
+// wavefronts, <= 4 per CU); every wavefront independently pulls 8x8-pixel tiles of traced rays off a device-wide
+// counter until the frame is done -- no workgroup barrier at all, no per-tile dispatch, one flush of the statistics per
+// wavefront.  (Star data is read straight from the L2-resident direction grid; nothing is staged in LDS up front.)
 // With supersampling the four rays of an output pixel sit in four adjacent lanes (a quad), in the order
 // p(2y,2x), p(2y+1,2x), p(2y,2x+1), p(2y+1,2x+1) of ImageFilters.hs:94-96, and are reduced with lane
 // shuffles, so only the h x w image is ever written.

@@ -11,9 +11,14 @@
  * this library: every entry point that renders requires a HIP device and fails (never falls back).
  *
  * Conventions: caller allocates and owns every buffer; callee never frees caller memory, never calls
- * back, never throws across the ABI.  A bs_ctx belongs to one device; one render at a time per ctx;
- * different contexts may be driven from different OS threads.  Functions returning int return 0 on
- * success and a negative BS_E* code on failure; bs_last_error() gives a thread-local message.
+ * back, never throws across the ABI.  A bs_ctx belongs to one device and is driven by one OS thread at a
+ * time (calls on the same context must not overlap); different contexts may be driven from different
+ * OS threads.  The *_device entry points only enqueue: renders enqueued on DIFFERENT streams of one context
+ * are independent of each other (each takes its own tile-queue/statistics block from a ring of 8; the ninth
+ * waits for the first to finish) and bs_stats reports the one enqueued last.  Every blocking entry point returns
+ * only after all work it enqueued has finished -- also on an error return, so caller buffers may be released.
+ * Functions returning int return 0 on success and a negative BS_E* code on failure; bs_last_error() gives a
+ * thread-local message.
  */
 #ifndef BLACKSTAR_GPU_H
 #define BLACKSTAR_GPU_H
@@ -32,15 +37,18 @@ enum {
     BS_EINVAL = -1,  /* bad argument (null pointer, non-positive resolution, buffer too small, bad hue) */
     BS_EDEVICE = -2, /* no such HIP device / HIP runtime error */
     BS_ENOMEM = -3,  /* host or device allocation failed */
-    BS_ECAPPED = -4, /* reserved */
+    BS_ECAPPED = -4, /* never returned: rays stopped by the step cap are reported through bs_stats_t.capped only */
     BS_EINTERNAL = -5
 };
 
 /* Arithmetic mode of the trace kernel (DESIGN.md "Kernels").
  * STRICT: one IEEE binary64 operation per reference operation, in the reference's order, no FMA
  *         contraction, correctly rounded sqrt and divide -> trajectories bit-identical to the CPU oracle.
- * FAST:   same algorithm with FMA contraction and r^-5 from v_rsq_f64 + one cubic Newton step
- *         (about 1 ulp per RHS, same accuracy class as STRICT); results agree with STRICT to ~1e-12. */
+ * FAST:   the same discrete RK4 map evaluated in the ray's orbital plane with FMA-accumulated stage sums and
+ *         r^-5 from v_rsq_f64 + a 2nd-order series correction.  Step counts, fates and disk crossings equal
+ *         STRICT's on every ray tested; pixel values agree with STRICT to 3.4e-8 absolute / 3.7e-7 relative
+ *         on the BASELINE frames (worst 2.3e-5 relative over a 10 000-scene fuzz: rays grazing the photon
+ *         sphere amplify any rounding difference) -- inside the 1e-4 relative bar, not bit-exact. */
 enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
 
 /* Replaces the `Config` argument of render (src/ConfigFile.hs:16-38), AS PARSED: radii un-squared,
