@@ -25,10 +25,40 @@ class ConfigError(ValueError):
 Vec3 = Tuple[float, float, float]
 
 
+_YAML12_FLOAT = None
+
+
+def _yaml12_number(v: str):
+    """PyYAML resolves scalars by YAML 1.1: a float without a dot (`1e-1`, `5E3`) stays a str.  The reference's decoder
+    (Data.Yaml = libyaml + aeson's number parser) accepts them, so numeric-looking strings are read the YAML 1.2 way."""
+    global _YAML12_FLOAT
+    if _YAML12_FLOAT is None:
+        import re
+        _YAML12_FLOAT = re.compile(r"[-+]?(\.[0-9]+|[0-9]+(\.[0-9]*)?)([eE][-+]?[0-9]+)?")
+    if _YAML12_FLOAT.fullmatch(v.strip()):
+        return float(v)
+    return None
+
+
 def _num(v: Any, what: str) -> float:
+    if isinstance(v, str):
+        f = _yaml12_number(v)
+        if f is not None:
+            return f
     if isinstance(v, bool) or not isinstance(v, (int, float)):
         raise ConfigError(f"{what}: expected a number, got {v!r}")
     return float(v)
+
+
+def _int(v: Any, what: str) -> int:
+    """An aeson `Int` field: any JSON number with an integral value (25, 25.0, 2.5e1) decodes; 25.5 does not."""
+    if isinstance(v, str):
+        f = _yaml12_number(v)
+        if f is not None:
+            v = f
+    if isinstance(v, bool) or not isinstance(v, (int, float)) or float(v) != int(v):
+        raise ConfigError(f"{what}: expected an Int, got {v!r}")
+    return int(v)
 
 
 def _vec3(v: Any, what: str) -> Vec3:
@@ -85,18 +115,15 @@ class Scene:
             if obj.get(k) is not None:  # (.:?) treats an explicit null like a missing key
                 setattr(s, k, _num(obj[k], f"scene.{k}"))
         if obj.get("bloomDivider") is not None:
-            v = obj["bloomDivider"]
-            if isinstance(v, bool) or not isinstance(v, (int, float)) or float(v) != int(v):
-                raise ConfigError(f"scene.bloomDivider: expected an Int, got {v!r}")
-            s.bloomDivider = int(v)
+            s.bloomDivider = _int(obj["bloomDivider"], "scene.bloomDivider")
         if obj.get("diskColor") is not None:
             x, y, z = _vec3(obj["diskColor"], "scene.diskColor")
             s.diskColor = (x / 360, y, z)  # PixelHSI (x / 360) y z  (:51)
         if obj.get("resolution") is not None:
             r = obj["resolution"]
-            if not isinstance(r, (list, tuple)) or len(r) != 2 or any(isinstance(t, bool) or not isinstance(t, int) for t in r):
+            if not isinstance(r, (list, tuple)) or len(r) != 2:
                 raise ConfigError(f"scene.resolution: expected [width, height] of Int, got {r!r}")
-            s.resolution = (int(r[0]), int(r[1]))
+            s.resolution = (_int(r[0], "scene.resolution"), _int(r[1], "scene.resolution"))
         if obj.get("supersampling") is not None:
             if not isinstance(obj["supersampling"], bool):
                 raise ConfigError(f"scene.supersampling: expected Bool, got {obj['supersampling']!r}")

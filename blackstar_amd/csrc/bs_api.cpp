@@ -290,6 +290,15 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     return ctx;
 }
 
+int bs_device_count(void)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return count;
+}
+
 void bs_destroy(bs_ctx *ctx)
 {
     if (!ctx) return;

@@ -73,6 +73,10 @@ def render_sharded(n_frames: int, render_frame: Callable[[int], "object"], rank:
     import torch
     if dist is None:
         import torch.distributed as dist  # noqa: PLC0415
+    if gather_to is not None and world > 1 and world > n_frames:
+        # checked identically on every rank BEFORE anything is rendered or any collective is entered: a rank without a single
+        # frame has no tensor shape to contribute to the gather, and failing there alone would leave the other ranks hanging
+        raise ValueError(f"{world} ranks for {n_frames} frames: use world <= n_frames (or gather_to=None)")
     mine = shard_frames(n_frames, rank, world)
     out: List = []
     rounds = (n_frames + world - 1) // world
@@ -87,9 +91,7 @@ def render_sharded(n_frames: int, render_frame: Callable[[int], "object"], rank:
                 out.append(t)
             continue
         if t is None:
-            if template is None:
-                raise RuntimeError("rank has no frame at all; use world <= n_frames")
-            t = torch.zeros_like(template)
+            t = torch.zeros_like(template)  # template is set: world <= n_frames gives every rank a frame in round 0
         if world == 1:
             out.append(t)
             continue

@@ -101,6 +101,9 @@ typedef struct bs_ctx bs_ctx;
  * device: HIP device ordinal (>= 0).  Returns NULL on error. */
 bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars);
 void bs_destroy(bs_ctx *ctx);
+/* Number of HIP devices this process can see (one bs_ctx per device for bs_render_batch / bs_render_split), or a negative
+ * BS_E* code.  No reference counterpart (the reference has one backend: the host's cores, blackstar.cabal:47). */
+int bs_device_count(void);
 
 /* Replaces: render cfg tree (src/Raytracer.hs:53-67) at its only call site app/Main.hs:109.
  * Blocking.  Fills out_rgb[height*width*3], interleaved RGB f64, row-major (y down), linear light,

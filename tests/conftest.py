@@ -63,8 +63,12 @@ def oracle_index_empty(oracle):
 
 C1_SUMMARY = "summary_c1_default_640x480"
 IMAGE_GOLDENS = ["c2_default_96x54_nostars", "c3_default_aa_96x54", "c4_lensing_disk_96x54", "c5_ani_frame300_80x45",
-                 "odd_default_aa_37x23"]
-TRACE_GOLDENS = ["c1", "c2", "c3", "c4", "c5_f0", "c5_f599"]
+                 "odd_default_aa_37x23",
+                 # the reference's other six scene files (tests/golden/make_golden.py --extra)
+                 "ref_closeup_96x72", "ref_fartheraway_96x54", "ref_lensing_96x72", "ref_wideangle_disk_96x54",
+                 "ref_wideangle_96x51", "ref_wideangle1_96x54"]
+TRACE_GOLDENS = ["c1", "c2", "c3", "c4", "c5_f0", "c5_f599",
+                 "ref_closeup", "ref_fartheraway", "ref_lensing", "ref_wideangle_disk", "ref_wideangle", "ref_wideangle1"]
 
 
 def ring_offsets_vs_reference_example(img):

@@ -97,8 +97,45 @@ def main():
         print(name, len(ys), rec["steps"].mean(), np.bincount(rec["fate"]))
 
 
-if __name__ == "__main__" and "--c1" not in sys.argv:
+if __name__ == "__main__" and "--c1" not in sys.argv and "--extra" not in sys.argv:
     main()
+
+
+# down-scaled frame of each of the reference's other six scene files (aspect kept; supersampling as in the file)
+EXTRA_IMAGE_RES = {"closeup": (96, 72), "fartheraway": (96, 54), "lensing": (96, 72), "wideangle-disk": (96, 54),
+                   "wideangle": (96, 51), "wideangle1": (96, 54)}
+
+
+def extra_scenes():
+    """Goldens for /root/reference/scenes/{closeup,fartheraway,lensing,wideangle-disk,wideangle,wideangle1}.yaml (as restated in
+    oracle/scenes.py): one down-scaled image and 384 per-ray traces at the file's FULL resolution each."""
+    cat = open(os.path.join(HERE, "catalogue_2000.ppm"), "rb").read()
+    stars = parse_catalogue(cat)
+    rng = np.random.default_rng(20260928)
+    for name in scenes.EXTRA_SCENES:
+        cfg_full = scenes.REFERENCE_SCENES[name]
+        key = name.replace("-", "_")
+        w, h = EXTRA_IMAGE_RES[name]
+        cfg = scenes.with_res(cfg_full, w, h)
+        img, rec = no.render(cfg, stars)
+        np.savez_compressed(os.path.join(HERE, f"image_ref_{key}_{w}x{h}.npz"), cfg=json.dumps(cfg), img=img,
+                            total_steps=np.int64(rec["steps"].sum()), fate_counts=np.bincount(rec["fate"], minlength=3),
+                            disk_hits=np.int64(rec["disk_hits"].sum()), star_hits=np.int64(rec["star_hits"].sum()))
+        print(name, img.shape, int(rec["steps"].sum()), np.bincount(rec["fate"], minlength=3), int(rec["disk_hits"].sum()))
+        sc = no.derive(cfg_full)
+        gy, gx = np.meshgrid(np.linspace(0, sc["ht"] - 1, 12).astype(int), np.linspace(0, sc["wt"] - 1, 12).astype(int), indexing="ij")
+        ys = np.concatenate([gy.ravel(), rng.integers(0, sc["ht"], 80), np.full(160, sc["ht"] // 2 + 3)])
+        xs = np.concatenate([gx.ravel(), rng.integers(0, sc["wt"], 80), np.linspace(0, sc["wt"] - 1, 160).astype(int)])
+        rec = no.trace(cfg_full, stars, ys, xs)
+        v0, p0 = no.generate_rays(sc, ys, xs)
+        np.savez_compressed(os.path.join(HERE, f"trace_ref_{key}.npz"), cfg=json.dumps(cfg_full), ys=ys.astype(np.int32), xs=xs.astype(np.int32),
+                            vel0=v0, h2=rec["h2"], vel=rec["vel"], pos=rec["pos"], rgba=rec["rgba"], steps=rec["steps"],
+                            fate=rec["fate"], disk_hits=rec["disk_hits"], star_hits=rec["star_hits"])
+        print("  trace", len(ys), rec["steps"].mean(), np.bincount(rec["fate"]), int(rec["disk_hits"].sum()))
+
+
+if __name__ == "__main__" and "--extra" in sys.argv:
+    extra_scenes()
 
 
 def c1_summary():

@@ -17,6 +17,23 @@ def test_shard_map():
         shard_frames(4, 2, 2)
 
 
+def test_more_ranks_than_frames_fails_on_every_rank_before_any_collective():
+    """world > n_frames with a gather: every rank raises up front (no rank may enter dist.gather while another fails)."""
+    from blackstar_amd.distributed import render_sharded
+
+    class NoCollectives:  # any collective call would be a hang in production
+        def gather(self, *a, **k):
+            raise AssertionError("entered a collective")
+
+    calls = []
+    for rank in range(3):
+        with pytest.raises(ValueError):
+            render_sharded(2, lambda i: calls.append(i), rank, 3, gather_to=0, dist=NoCollectives())
+    assert calls == []
+    # without a gather an idle rank is fine
+    assert render_sharded(2, lambda i: i, 2, 3, gather_to=None, dist=NoCollectives()) == []
+
+
 def _worker(rank, world, port, n_frames, q):
     import torch
     import torch.distributed as dist

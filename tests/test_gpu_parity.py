@@ -751,3 +751,175 @@ def test_photon_ring_matches_the_reference_repositorys_example_image(mode, tree_
     print(f"ring radius, reference example.png - GPU: mean {d.mean():+.2f} px, std {d.std():.2f}, max |d| {np.abs(d).max():.2f} over {len(d)}/{n} angles")
     assert len(d) >= 0.85 * n
     assert abs(d.mean()) < 0.5 and d.std() < 0.8 and np.abs(d).max() <= 2.5
+
+
+# ---- round 2: every scene file the reference ships, the shipped (FAST) mode against the ORACLE at full frame size, the
+# ---- multi-device / multi-stream / error paths of the host layer -------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def full_catalogue(oracle):
+    """The 470,000-star BASELINE catalogue on the GPU and in the oracle (built once per module)."""
+    data = synthetic.ppm_catalogue_bytes()
+    t = bs.StarTree(bs.read_map(data), device=0)
+    ix = oracle.Index(oracle.read_ppm(data))
+    yield t, ix
+    t.close()
+
+
+@pytest.mark.parametrize("name", sorted(scenes.REFERENCE_SCENES))
+def test_reference_scene_files_full_size_rays_vs_oracle(name, full_catalogue, oracle):
+    """/root/reference/scenes/<name>.yaml as the file is written (its own resolution and supersampling flag), 470k-star
+    catalogue: 4096 rays drawn from the full-size frame.  STRICT: step counts, fates, crossings, star hit sets, terminal
+    vel/pos bit-exact vs the oracle.  FAST: the same discrete events, and rgba within the north_star tolerance OF THE ORACLE
+    (not of STRICT)."""
+    t, ix = full_catalogue
+    cfg = scenes.REFERENCE_SCENES[name]
+    f = 2 if cfg["supersampling"] else 1
+    rng = np.random.default_rng(sum(map(ord, name)))
+    ys, xs = rng.integers(0, f * cfg["height"], 4096), rng.integers(0, f * cfg["width"], 4096)
+    orc = oracle.trace_rays(cfg, ix, ys, xs)
+    t.set_mode(_lib.BS_MODE_STRICT)
+    rec = bs.trace_rays(cfg, t, ys, xs)
+    for k in ("steps", "fate", "disk_hits", "star_hits", "vel", "pos"):
+        assert np.array_equal(rec[k], orc[k]), (name, k)
+    np.testing.assert_allclose(rec["rgba"], orc["rgba"], rtol=RTOL_STRICT, atol=ATOL_STRICT)
+    t.set_mode(_lib.BS_MODE_FAST)
+    try:
+        fast = bs.trace_rays(cfg, t, ys, xs)
+    finally:
+        t.set_mode(_lib.BS_MODE_STRICT)
+    for k in ("steps", "fate", "disk_hits", "star_hits"):
+        assert np.array_equal(fast[k], orc[k]), (name, k)
+    bad = np.abs(fast["rgba"] - orc["rgba"]) > ATOL_FAST + RTOL_FAST * np.abs(orc["rgba"])
+    assert bad.sum() == 0, f"{name}: {bad.sum()} rgba values outside 1e-4 of the oracle"
+    if cfg["disk_opacity"] == 0:
+        assert rec["disk_hits"].sum() == 0  # diskOpacity 0 switches the disk test off (src/Raytracer.hs:96)
+    assert (rec["fate"] == 2).sum() == 0
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_c3_full_frame_both_modes_vs_oracle(mode, full_catalogue, oracle):
+    """default-aa.yaml's camera, 470k catalogue, 960x540 output px 4x supersampled = 1920x1080 traced rays (2.07 M rays; the
+    threaded oracle needs a few seconds): EVERY pixel of the shipped FAST mode, and of STRICT, against the oracle."""
+    t, ix = full_catalogue
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 960, 540)
+    ref, ost = oracle.render(cfg, ix, threads=0)
+    t.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+    try:
+        img = bs.render(cfg, t)
+        st = t.stats()
+    finally:
+        t.set_mode(_lib.BS_MODE_STRICT)
+    rtol, atol = (RTOL_FAST, ATOL_FAST) if mode == "fast" else (RTOL_STRICT, ATOL_STRICT)
+    bad = np.abs(img - ref) > atol + rtol * np.abs(ref)
+    assert bad.sum() == 0, f"{bad.sum()} of {bad.size} values outside tolerance (max abs {np.abs(img - ref).max():.3e})"
+    assert (st["horizon"], st["escaped"], st["capped"], st["disk_hits"]) == (ost["horizon"], ost["escaped"], ost["capped"], ost["disk_hits"])
+    assert st["star_hits"] == ost["star_hits"] and st["star_hits"] > 100000
+    if mode == "strict":
+        assert st["steps"] == ost["steps"]
+    print(f"{mode}: max abs err {np.abs(img - ref).max():.3e}, max rel {(np.abs(img - ref) / np.maximum(np.abs(ref), 1e-30))[ref > 1e-3].max():.3e}")
+
+
+def test_renders_on_different_streams_of_one_context_are_independent(tree):
+    """Two (and ten) renders enqueued back to back on DIFFERENT streams of one context, no synchronisation in between: each
+    launch owns its tile queue head and statistics block, so every image is complete and bs_stats reports the last one."""
+    import torch
+    cfg_a = scenes.with_res(scenes.DEFAULT_AA, 640, 360)   # ~0.9 M rays each: long enough to overlap
+    cfg_b = scenes.with_res(scenes.LENSING_DISK, 512, 320)
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        ref_a, ref_b = bs.render(cfg_a, tree), bs.render(cfg_b, tree)
+        st_b = tree.stats()
+        streams = [torch.cuda.Stream() for _ in range(10)]
+        outs = [torch.full((c["height"], c["width"], 3), -1.0, dtype=torch.float64, device="cuda:0") for c in [cfg_a, cfg_b] * 5]
+        for i, (s, o) in enumerate(zip(streams, outs)):
+            bs.render_device(cfg_b if i % 2 else cfg_a, tree, o.data_ptr(), o.numel(), s.cuda_stream)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy(), ref_b if i % 2 else ref_a), f"launch {i} on its own stream lost tiles"
+        st = tree.stats()
+        assert (st["rays"], st["steps"], st["escaped"]) == (st_b["rays"], st_b["steps"], st_b["escaped"])
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+
+
+def test_failing_frame_mid_batch_leaves_nothing_in_flight(tree):
+    """bs_render_batch with an invalid frame (disk hue 360 deg, src/ConfigFile.hs:51 -> toPixelRGB's error) in the middle:
+    the call fails, every frame BEFORE the bad one has been delivered, nothing is written after the call returns, and the
+    context is still usable."""
+    import time
+    L = _lib.lib()
+    good = [scenes.with_res(scenes.ani_frame(i, 600), 640, 360) for i in (0, 100, 200, 300, 400)]
+    bad = dict(good[2], disk_hsi=(1.0, 0.1, 1.0))
+    cfgs_l = [good[0], good[1], bad, good[3], good[4]]
+    cfgs = (_lib.BsConfig * 5)(*[_lib.make_config(c) for c in cfgs_l])
+    outs = [np.full((360, 640, 3), -7.0) for _ in range(5)]
+    ptrs = (C.c_void_p * 5)(*[o.ctypes.data for o in outs])
+    ctxs = (C.c_void_p * 1)(tree.handle)
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        rc = L.bs_render_batch(ctxs, 1, cfgs, 5, ptrs)
+        assert rc == -1 and b"not properly scaled" in L.bs_last_error()
+        snap = [o.copy() for o in outs]
+        assert np.array_equal(outs[0], bs.render(good[0], tree))          # delivered before the failure
+        assert (outs[2] == -7.0).all() and (outs[3] == -7.0).all() and (outs[4] == -7.0).all()
+        time.sleep(0.3)
+        for o, s in zip(outs, snap):
+            assert np.array_equal(o, s), "a DMA landed after the failing call returned"
+        # frame 1 was in flight when frame 2 failed: it is either complete or untouched, never half-written
+        assert np.array_equal(outs[1], bs.render(good[1], tree)) or (outs[1] == -7.0).all()
+        # the context still works, batch included
+        imgs = bs.render_batch(good[:3], [tree])
+        for c, im in zip(good[:3], imgs):
+            assert np.array_equal(im, bs.render(c, tree))
+        # same for the row-band entry point: bad config -> error, buffer untouched
+        buf = np.full((360, 640, 3), -7.0)
+        cb = _lib.make_config(bad)
+        assert L.bs_render(tree.handle, C.byref(cb), buf.ctypes.data, buf.size) == -1 and (buf == -7.0).all()
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+
+
+def test_batch_split_and_stats_on_every_visible_device(catalogue_bytes):
+    """One context per VISIBLE device (hipGetDeviceCount, not device 0 x n): frames round-robin over them (bs_render_batch),
+    one frame in row bands over them (bs_render_split), per-device statistics -- all bit-identical to device 0 alone.
+    On a one-GPU box this degenerates to one context; the 8-GPU node exercises the per-device threads and uploads."""
+    n = _lib.lib().bs_device_count()
+    assert n >= 1
+    import torch
+    assert n == torch.cuda.device_count()
+    stars = bs.read_map(catalogue_bytes)
+    trees = [bs.StarTree(stars, device=d) for d in range(n)]
+    try:
+        for t in trees:
+            t.set_mode(_lib.BS_MODE_FAST)
+        cfgs = [scenes.with_res(scenes.ani_frame(i * 37 % 600, 600), 96, 54) for i in range(2 * n + 1)]
+        ref = [bs.render(c, trees[0]) for c in cfgs]
+        imgs = bs.render_batch(cfgs, trees)
+        for a, b in zip(imgs, ref):
+            assert np.array_equal(a, b)
+        big = scenes.with_res(scenes.LENSING_DISK, 160, 97)
+        assert np.array_equal(bs.render_split(big, trees), bs.render(big, trees[0]))
+        for d, t in enumerate(trees):  # every device renders and reports on its own
+            img = bs.render(cfgs[0], t)
+            assert np.array_equal(img, ref[0]) and t.stats()["rays"] == 4 * 96 * 54
+            o = torch.empty((54, 96, 3), dtype=torch.float64, device=f"cuda:{d}")
+            bs.render_device(cfgs[0], t, o.data_ptr(), o.numel(), torch.cuda.current_stream(d).cuda_stream)
+            torch.cuda.synchronize(d)
+            assert np.array_equal(o.cpu().numpy(), ref[0])
+    finally:
+        for t in trees:
+            t.close()
+
+
+def test_star_lookup_reuses_its_scratch(tree, oracle, oracle_index):
+    """bs_star_lookup (the starLookup replacement) keeps its device buffers across calls: many small calls, then a larger
+    one that makes it grow, all correct."""
+    rng = np.random.default_rng(77)
+    for n in (1, 7, 300, 5, 200000, 12):
+        dirs = rng.normal(size=(n, 3))
+        rgb, hits = bs.star_lookup(tree, 0.4, 1.5, dirs, return_hits=True)
+        for k in rng.integers(0, n, min(n, 50)):
+            ref, nref = oracle.star_lookup(oracle_index, 0.4, 1.5, dirs[k])
+            assert hits[k] == nref
+            np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)

@@ -37,9 +37,11 @@ def test_no_cpu_backend():
 
 
 def test_scene_files_resolve_to_appendix_c():
-    for fn, exp in (("default.yaml", scenes.DEFAULT), ("default-aa.yaml", scenes.DEFAULT_AA), ("lensing-disk.yaml", scenes.LENSING_DISK)):
-        got = bs.Config.from_file(os.path.join(ROOT, "scenes", fn)).to_bs_config()
-        assert got == exp, fn
+    assert len(scenes.REFERENCE_SCENES) == 9  # every scene file the reference ships
+    for name, exp in scenes.REFERENCE_SCENES.items():
+        c = bs.Config.from_file(os.path.join(ROOT, "scenes", name + ".yaml"))
+        assert c.to_bs_config() == exp, name
+        assert (c.scene.bloomStrength, c.scene.bloomDivider) == scenes.REFERENCE_BLOOM[name], name
     c = bs.Config.from_file(os.path.join(ROOT, "scenes", "default.yaml"))
     assert (c.scene.bloomStrength, c.scene.bloomDivider) == (0.15, 25)
     assert c.with_resolution(640, 480).to_bs_config()["width"] == 640
@@ -56,6 +58,13 @@ def test_config_defaults_and_errors():
                 "camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1}\nscene: 3\n", "- 1\n", ": : :"):
         with pytest.raises(bs.ConfigError):
             bs.Config.from_yaml(bad)
+    # numbers the reference's decoder accepts but PyYAML's YAML 1.1 resolver leaves as strings / floats
+    c3 = bs.Config.from_yaml("camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1e0}\n"
+                             "scene: {stepSize: 1e-1, resolution: [1920.0, 1.08e3], bloomDivider: 2.5e1, diskOuter: 12}\n")
+    assert c3.scene.stepSize == 0.1 and c3.scene.resolution == (1920, 1080) and c3.scene.bloomDivider == 25 and c3.camera.fov == 1.0
+    for bad in ("scene: {resolution: [1920.5, 1080]}", "scene: {stepSize: abc}", "scene: {bloomDivider: 2.5}"):
+        with pytest.raises(bs.ConfigError):
+            bs.Config.from_yaml("camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1}\n" + bad + "\n")
     c2 = bs.Config.from_yaml(c.to_yaml())  # ToJSON round trip (hue * 360 and back)
     assert c2.to_bs_config() == pytest.approx(c.to_bs_config())
     p = bs.prepare_scene(bs.Config.from_file(os.path.join(ROOT, "scenes", "default.yaml")), True)  # app/Main.hs:93-103
