@@ -80,6 +80,7 @@ struct bs_ctx {
     size_t post_cap = 0;
     unsigned char *d_u8 = nullptr;
     size_t u8_cap = 0;
+    double *d_srgb_table = nullptr;  // 257 thresholds of the sRGB8 pixel map (bs::srgb8_thresholds)
     hipStream_t stream = nullptr;
     hipEvent_t ev_u0 = nullptr, ev_u1 = nullptr;  // bs_debug_ubench timing
     static constexpr int kMaxHostBands = 8;
@@ -274,6 +275,11 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
                 ok(hipHostMalloc((void **)&ctx->h_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
                 ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
                 ok(hipMemcpy(ctx->d_colors, colors.data(), colors.size() * sizeof(bs::StarColor), hipMemcpyHostToDevice), "upload colors");
+    if (good) {
+        static const std::vector<double> table = [] { std::vector<double> t(257); bs::srgb8_thresholds(t.data()); return t; }();
+        good = ok(hipMalloc((void **)&ctx->d_srgb_table, 257 * sizeof(double)), "hipMalloc srgb table") &&
+               ok(hipMemcpy(ctx->d_srgb_table, table.data(), 257 * sizeof(double), hipMemcpyHostToDevice), "upload srgb table");
+    }
     for (int k = 0; good && k < bs_ctx::kSlots; k++) {
         bs_ctx::LaunchSlot &sl = ctx->slots[k];
         sl.d_counters = ctx->d_counters + (size_t)k * bs::kCounters;
@@ -288,6 +294,13 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
         return nullptr;
     }
     return ctx;
+}
+
+int bs_debug_srgb8_table(double table[257])
+{
+    if (!table) return fail(BS_EINVAL, "null argument");
+    bs::srgb8_thresholds(table);
+    return BS_OK;
 }
 
 int bs_device_count(void)
@@ -323,6 +336,7 @@ void bs_destroy(bs_ctx *ctx)
         for (double *b : ctx->d_post)
             if (b) (void)hipFree(b);
         if (ctx->d_u8) (void)hipFree(ctx->d_u8);
+        if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         if (ctx->ev_u0) (void)hipEventDestroy(ctx->ev_u0);
         if (ctx->ev_u1) (void)hipEventDestroy(ctx->ev_u1);
@@ -370,7 +384,7 @@ int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int h
     size_t n = (size_t)width * height * 3;
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
-    if (bs::launch_bloom((const double *)d_in, (double *)d_out, ctx->d_post[0], ctx->d_post[1], width, height, strength, divider, hip_stream))
+    if (bs::launch_bloom((const double *)d_in, (double *)d_out, ctx->d_post[0], ctx->d_post[1], width, height, strength, divider, ctx->n_cu, hip_stream))
         return fail(BS_EDEVICE, "bloom launch failed");
     return BS_OK;
 }
@@ -411,7 +425,7 @@ int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_valu
 {
     if (!ctx || (n_values && (!d_in || !d_out_u8))) return fail(BS_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (bs::launch_srgb8((const double *)d_in, (unsigned char *)d_out_u8, n_values, hip_stream)) return fail(BS_EDEVICE, "srgb8 launch failed");
+    if (bs::launch_srgb8((const double *)d_in, (unsigned char *)d_out_u8, n_values, ctx->d_srgb_table, hip_stream)) return fail(BS_EDEVICE, "srgb8 launch failed");
     return BS_OK;
 }
 
@@ -459,12 +473,15 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     // doRender (app/Main.hs:105-123): render -> bloom if bloomStrength /= 0 -> writeImg's sRGB + toWord8, all in HBM
     rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
     if (rc) return rc;
-    if (bloom_strength != 0) {
-        rc = bs_bloom_device(ctx, ctx->d_post[2], ctx->d_post[2], cfg->width, cfg->height, bloom_strength, bloom_divider, ctx->stream);
+    if (bloom_strength != 0) {  // bloom's final img + strength * blurred is fused with the sRGB8 map: the bloomed f64 image is never written
+        if (bloom_divider <= 0 || cfg->width / bloom_divider == 0) return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+        if (bs::launch_bloom_srgb8(ctx->d_post[2], ctx->d_u8, ctx->d_post[0], ctx->d_post[1], cfg->width, cfg->height, bloom_strength, bloom_divider,
+                                   ctx->n_cu, ctx->d_srgb_table, ctx->stream))
+            return fail(BS_EDEVICE, "bloom launch failed");
+    } else {
+        rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n, ctx->stream);
         if (rc) return rc;
     }
-    rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n, ctx->stream);
-    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -82,6 +82,9 @@ struct TraceParams {
 
 // Host-side strict math (host_math.cpp, compiled -ffp-contract=off).
 void host_hsi_to_rgb(double hue, double s, double i, double rgb[3], bool *ok);
+// writeImg's pixel map x -> toWord8 (sRGB x) (Raytracer.hs:23-32) as its 255 thresholds: T[k] (k = 1..255) = the smallest double
+// the map sends to a byte >= k, found by bisection with the host's libm `pow`; T[0] = -inf, T[256] = +inf.
+void srgb8_thresholds(double T[257]);
 // Fills every derived field of TraceParams except the device pointers.  Returns false + message on bad input.
 bool derive_params(const bs_config &cfg, TraceParams &p, std::string &err);
 
@@ -101,9 +104,12 @@ int launch_trace(const TraceParams &p, int mode, void *stream);
 int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, size_t n_rays, bs_ray_record *d_out, void *stream);
 int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, double *d_rgb, int32_t *d_hits, void *stream);
 // post_kernels.hip
-int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, void *stream);
+int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu, void *stream);
+// bloom + writeImg's pixel map in one go: only RGB8 is written (d_table: the 257 sRGB8 thresholds, srgb8_thresholds)
+int launch_bloom_srgb8(const double *d_in, unsigned char *d_out_u8, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu,
+                       const double *d_table, void *stream);
 int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *stream);
-int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, void *stream);
+int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, const double *d_table, void *stream);
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
 int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);
 

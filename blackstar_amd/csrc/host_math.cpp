@@ -3,6 +3,7 @@
 // generateRay that do not depend on the pixel: scene constants (src/Raytracer.hs:57-65) and the look-at
 // basis (linear's lookAt, src/Raytracer.hs:47), plus the catalogue record parser (src/StarMap.hs:45-75).
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 
 #include "bs_internal.h"
@@ -33,6 +34,34 @@ inline void normalize(const double v[3], double o[3])
     }
 }
 }  // namespace
+
+namespace {
+// toWord8 (sRGB x): Raytracer.hs:23-32 with massiv-io's toWord8 (clamp to [0,1], * 255, round half to even)
+inline int srgb8_forward(double x)
+{
+    double y = (x < 0.0031308) ? 12.92 * x : (1 + 0.055) * std::pow(x, 1.0 / 2.4) - 0.055;
+    y = y < 0.0 ? 0.0 : (y > 1.0 ? 1.0 : y);
+    return (int)std::rint(255.0 * y);
+}
+}  // namespace
+
+void srgb8_thresholds(double T[257])
+{
+    // Positive doubles are ordered like their bit patterns, and the map is monotone: bisect the patterns in (0, 2.0] for the
+    // first x whose byte reaches k.  (x <= 0 maps to 0, x >= 1 to 255.)
+    T[0] = -HUGE_VAL;
+    T[256] = HUGE_VAL;
+    auto from_bits = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
+    auto to_bits = [](double d) { uint64_t b; std::memcpy(&b, &d, 8); return b; };
+    for (int k = 1; k <= 255; k++) {
+        uint64_t lo = 0, hi = to_bits(2.0);  // byte(lo) = 0 < k <= 255 = byte(hi)
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (srgb8_forward(from_bits(mid)) >= k) hi = mid; else lo = mid;
+        }
+        T[k] = from_bits(hi);
+    }
+}
 
 void host_hsi_to_rgb(double hp, double s, double i, double rgb[3], bool *ok)
 {

@@ -13,6 +13,10 @@
 // reading the H result; 3 passes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
 #include "bs_internal.h"
 
 namespace bs {
@@ -211,6 +215,300 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
     }
 }
 
+// ---- box blur sweep, LDS-DMA version (the default path) --------------------------------------------------------------
+// Same layouts as box_blur_sweep_lds: INPUT chain-major in[(p * n + row) * 3 + c], OUTPUT row-major out[(row * P + p) * 3 + c],
+// so an H sweep followed by a V sweep needs no transpose.  What changed is who does what, driven by measurements of the old
+// kernel (profiles/r01_rgb8_kernel_stats.csv: 1.78 TB/s) and the CDNA4 price list: a CU ingests ~25 GB/s from HBM whatever it
+// does, so ALL 256 CUs have to stream, each a 1/256 slice of the chains.
+//   * One workgroup per CU: px = ceil(P / #CU) adjacent chain-pixels (3 px chains, <= 63), i.e. 216 / 240 workgroups for the
+//     H / V sweep of a 1080p frame instead of 99 / 175.  152 KiB of static LDS keeps it at one workgroup per CU.
+//   * The LOADER wavefront moves 1 KiB (64 lanes x 16 B) of one chain-pixel's contiguous run per `global_load_lds_dwordx4`
+//     straight into that pixel's LDS ring -- no VGPR staging, no ds_write pass, and the prefetch depth (Dp phases = Dp x 3 KiB
+//     per pixel, 48-72 KiB per workgroup) is limited by the ring, not by registers.  Counted `s_waitcnt vmcnt(N)` leaves the
+//     younger batches in flight across the block barriers (raw s_barrier: a fence would drain them).
+//   * The CHAIN wavefront: one lane per chain walks the reference's running sum S <- (S + pix(x+r)) - pix(x-r) in order
+//     (bit-exact), operands from one ring offset + immediates (slot 0 of each ring is mirrored behind the last slot so a
+//     block never wraps).
+//   * blockIdx -> chain group is XCD-aware: workgroup b runs on XCD b % 8, and XCD x gets a CONTIGUOUS range of groups, so the
+//     partial 128-B lines two neighbouring groups write (a group's row is 3 px doubles = 120-192 B) meet in one L2.
+// A phase = 128 rows = exactly 3 chunks per pixel.  Batch p of chunks is what phase p needs beyond phase p-1:
+// [3p + Lr, 3p + 3 + Lr) with Lr = ceil(24 r / 1024) (batch 0: [0, 3 + Lr)).  During phase k the loader issues batch k + Dp into
+// the slots of chunks that died with phase k-1 (ring of S = 3 (1 + Dp) + 2 Lr slots), then waits for batch k+1.
+constexpr int kDmaChunk = 1024;      // bytes per global_load_lds_dwordx4 wave-instruction
+constexpr int kDmaPhaseRows = 128;   // 128 rows x 24 B = 3 chunks
+constexpr int kDmaLds = 152 * 1024;  // static LDS of the kernel (of 160 KiB per CU)
+constexpr int kDmaMaxPx = 21;        // 63 chains = one consumer wavefront
+
+struct SweepPlan {
+    int px;       // chain-pixels per workgroup
+    int S;        // ring slots (1 KiB each) per pixel, + 1 mirror slot
+    int Dp;       // phases of prefetch in flight
+    int Lr;       // chunks the +-r window reaches beyond a phase
+    int stride;   // bytes between the rings of two pixels: (S + 1) * 1024 + 32 (the 32 skews the banks of neighbouring pixels)
+    int groups;   // ceil(P / px)
+    int per_xcd;  // ceil(groups / 8); grid = 8 * per_xcd
+#ifdef BS_SWEEP_PROBE  // scripts/sweep_probe.hip only: switch parts of the kernel off, report shader / wall clocks of workgroup 0
+    int dbg;                     // chain variants: 1 = no tile writes, 2 = no ring reads, 3 = neither
+    unsigned long long *clocks;  // per wavefront of group 0: [2w] shader clocks spent working, [2w+1] in the block loop
+#endif
+};
+
+// One LDS-DMA wave-instruction: lane i's 16 bytes at g land at LDS byte address lds_addr + 16 i (lds_addr wave-uniform, via M0).
+// Issued as inline assembly ON PURPOSE: with the builtin (__builtin_amdgcn_global_load_lds) anywhere in a kernel, hipcc's waitcnt
+// insertion treats lgkmcnt as out of order for the whole loop and puts `s_waitcnt lgkmcnt(0)` in front of every use of an LDS
+// read -- the chain wavefront then stalls a full LDS round trip per batch instead of running its reads 8 rows ahead (seen in the
+// ISA; a 20-line reproducer is in scripts/probe/README).  The loader counts its own vmcnt (wait_vmcnt_le), nobody else needs to.
+__device__ __forceinline__ void dma_1k(const unsigned char *g, const unsigned char *l)
+{
+    const unsigned lds_addr = (unsigned)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char *)l);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int n)
+{
+#define BS_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : n) {
+        BS_W(0) BS_W(1) BS_W(2) BS_W(3) BS_W(4) BS_W(5) BS_W(6) BS_W(7) BS_W(8) BS_W(9) BS_W(10) BS_W(11) BS_W(12) BS_W(13) BS_W(14) BS_W(15)
+        BS_W(16) BS_W(17) BS_W(18) BS_W(19) BS_W(20) BS_W(21) BS_W(22) BS_W(23) BS_W(24) BS_W(25) BS_W(26) BS_W(27) BS_W(28) BS_W(29) BS_W(30) BS_W(31)
+        BS_W(32) BS_W(33) BS_W(34) BS_W(35) BS_W(36) BS_W(37) BS_W(38) BS_W(39) BS_W(40) BS_W(41) BS_W(42) BS_W(43) BS_W(44) BS_W(45) BS_W(46) BS_W(47)
+        BS_W(48) BS_W(49) BS_W(50) BS_W(51) BS_W(52) BS_W(53) BS_W(54) BS_W(55) BS_W(56) BS_W(57) BS_W(58) BS_W(59) BS_W(60) BS_W(61) BS_W(62)
+    default: break;  // >= 63: the counter saturates at 63, so by the time the issuing loop has finished the awaited batch has landed
+    }
+#undef BS_W
+}
+
+// ---- six-wavefront version: the chain wavefront does NOTHING but the chain (the default path) ---------------------------
+// Measured on the two-wavefront kernel above (scripts/probe/sweep_probe.hip -> profiles/r02_sweep_probe.txt): the loader alone
+// streams a sweep in 20-24 us, but the consumer needs ~95 shader clocks per row.  A LONE wavefront on a SIMD is slow at
+// everything: a dependent v_add_f64 issues every ~10-11 clocks (two per row: 22), an LDS instruction holds its issue slot for
+// ~10-20 clocks, a global store for ~20 (64 lanes x 16 B of address + data), and the scalar loop control around them is not
+// free either -- and none of it can be hidden behind another wavefront, because the chain IS one wavefront per group of chains
+// and its time is rows x clocks-per-row whatever the lane count.  So everything that is not the chain is moved off that
+// wavefront:
+//   wave 0  CHAIN   reads its operands from the rings, runs S <- (S + lead) - trail, writes S to an LDS tile: 1 ds_read2_b64 +
+//                   2 v_add_f64 + 1/2 ds_write2_b64 per row, straight-line code for 32 rows, operands fetched 8 rows ahead
+//   wave 1  LOADER  LDS-DMA as above, its issue spread over the blocks of a phase (a burst would hold up the block barrier)
+//   waves 2-5 STORE take the tile of the PREVIOUS 32 rows (8 rows each), multiply by the normalisation (mul normFactor) and
+//                   write it to HBM with all 64 lanes: 64 / (3 px) rows per store instruction
+// One raw barrier per 32 rows.  Forcing the LDS instructions into the latency bubbles between the dependent adds
+// (__builtin_amdgcn_sched_group_barrier) was measured and is SLOWER (58 vs 48 clocks per row): clustered LDS instructions of a
+// lone wavefront pipeline, isolated ones each pay their full issue latency.
+constexpr int kBlkRows = 32;      // rows per CHAIN -> STORE hand-off; 4 blocks per loader phase
+constexpr int kStoreWaves = 4;    // STORE wavefronts, kBlkRows / kStoreWaves rows of the tile each
+constexpr int kSweepThreads = 64 * (2 + kStoreWaves);
+constexpr int kTileColBytes = (kBlkRows + 1) * 8;  // hand-off tile: [chain][row], 33 doubles per chain (odd: conflict-free both ways)
+static_assert(kDmaPhaseRows == 4 * kBlkRows && kDmaPhaseRows * 24 == 3 * kDmaChunk, "a loader phase is 4 blocks = 3 chunks per pixel");
+
+// One block of 32 rows of the CHAIN wavefront, straight-line, four batches of 8 rows.  la/ta hold the operands (leading /
+// trailing samples) of the block's rows 0..7 on entry; with NEXT they hold those of the NEXT block's rows 0..7 on exit.
+template <bool EDGE, bool NEXT, int PROBE = 0>  // PROBE (scripts/probe only): 1 = no tile writes, 2 = no ring reads, 3 = neither
+__device__ __forceinline__ void chain_block(const unsigned char *pL, const unsigned char *pT, unsigned char *tile, int x0, int r, int n, double &s,
+                                            double (&la)[8], double (&ta)[8])
+{
+    double lb[8], tb[8];
+    auto batch = [&](const double(&l)[8], const double(&t)[8], double(&nl)[8], double(&nt)[8], int b, bool load_next) {
+        if (load_next && !(PROBE & 2)) {  // the next batch's 16 operands: 8 ds_read2_b64 in one cluster, consumed 8 rows later
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                nl[u] = *reinterpret_cast<const double *>(pL + 24 * (8 * (b + 1) + u));
+                nt[u] = *reinterpret_cast<const double *>(pT + 24 * (8 * (b + 1) + u));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            double lead = l[u], trail = t[u];
+            if (EDGE) {  // image edges: out-of-range samples are black (ixh / ixv); rows past the end are computed but never stored
+                const int x = x0 + 8 * b + u;
+                lead = (x + r < n) ? lead : 0.0;
+                trail = (x - r >= 0) ? trail : 0.0;
+            }
+            s = (s + lead) - trail;  // accumulate (ImageFilters.hs:61-64)
+            if (!(PROBE & 1)) *reinterpret_cast<double *>(tile + 8 * (8 * b + u)) = s;
+        }
+    };
+    batch(la, ta, lb, tb, 0, true);
+    batch(lb, tb, la, ta, 1, true);
+    batch(la, ta, lb, tb, 2, true);
+    batch(lb, tb, la, ta, 3, NEXT);
+}
+
+__global__ __launch_bounds__(kSweepThreads) void box_blur_sweep_dma(const double *__restrict__ in, double *__restrict__ out, int P, int n, int r, double norm,
+                                                                      const SweepPlan pl)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kDmaLds];
+    const int g = (int)(blockIdx.x & 7u) * pl.per_xcd + (int)(blockIdx.x >> 3);  // XCD-contiguous ranges of chain groups
+    if (g >= pl.groups) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63u);
+    const int p0 = g * pl.px;
+    const int npx = (P - p0) < pl.px ? (P - p0) : pl.px;
+    const int S = pl.S, Dp = pl.Dp, Lr = pl.Lr, stride = pl.stride;
+    const long run_bytes = (long)n * 24;
+    const int nchunks = (int)((run_bytes + kDmaChunk - 1) / kDmaChunk);
+    const int blocks = (n + kBlkRows - 1) / kBlkRows;
+    const int tile_bytes = 3 * pl.px * kTileColBytes;   // one hand-off tile: [3 px chains][kBlkRows (+1 pad) rows]
+    unsigned char *tiles = lds + pl.px * stride;        // two of them behind the rings
+
+    // ---- loader (wave 1) ----
+    const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (long)p0 * run_bytes + lane * 16;  // lane's 16 B of pixel p0's chunk 0
+    const long bytes_left = (long)(P - p0) * run_bytes - lane * 16;  // from gin to the end of the array
+    int v0 = 0, v1 = 0, v2 = 0;  // wave-instruction counts of the batches in flight behind the one that is awaited next
+    auto issue = [&](int c_lo, int c_hi) -> int {  // chunks [c_lo, c_hi) of every pixel of the group
+        int cnt = 0;
+        if (c_hi > nchunks) c_hi = nchunks;
+        for (int j = c_lo; j < c_hi; j++) {
+            const int slot = j % S;
+            long off = (long)j * kDmaChunk;
+            unsigned char *l = lds + slot * kDmaChunk;
+            for (int m = 0; m < npx; m++, off += run_bytes, l += stride) {
+                // lanes past the end of the ARRAY stay out (the last pixel's last chunk); lanes past the end of this pixel's run
+                // read the next pixel's first rows, which nobody looks at.  Lane 0 is always in range, so the instruction issues.
+                if (off + 16 <= bytes_left) {
+                    dma_1k(gin + off, l);
+                    if (slot == 0) dma_1k(gin + off, l + S * kDmaChunk);  // mirror of slot 0 behind the last slot
+                }
+            }
+            cnt += slot == 0 ? 2 * npx : npx;
+        }
+        return cnt;
+    };
+    auto batch_lo = [&](int p) { return p == 0 ? 0 : 3 * p + Lr; };
+
+    // ---- chain (wave 0) ----
+    const int ncol = 3 * npx;
+    const bool active = lane < ncol;
+    const int lm = active ? lane / 3 : 0, lc = active ? lane - 3 * (lane / 3) : 0;
+    const unsigned char *lbase = lds + lm * stride + 8 * lc;
+    const unsigned ring = (unsigned)S * kDmaChunk;
+    unsigned offL = (unsigned)((24l * r) % ring);                  // ring offset of row x + r, x = 0
+    unsigned offT = (unsigned)((ring - (24l * r) % ring) % ring);  // ring offset of row x - r, x = 0
+    double s = 0.0;
+
+    // ---- store (waves 2 .. 2 + kStoreWaves - 1) ----
+    constexpr int kRowsPerStore = kBlkRows / kStoreWaves;
+    const int G = 64 / ncol;                       // rows one store instruction covers
+    const int rsub = lane / ncol, col = lane - rsub * ncol;
+    const bool lane_ok = rsub < G;
+    const size_t ostride = (size_t)P * 3;          // doubles between two output rows
+
+    if (wave == 1) {
+        int c[3] = {0, 0, 0};
+        for (int p = 0; p < Dp; p++) {
+            const int k = issue(batch_lo(p), batch_lo(p + 1));
+            if (p >= 1) c[p - 1] = k;
+        }
+        v0 = c[0]; v1 = c[1]; v2 = c[2];
+        wait_vmcnt_le(v0 + v1 + v2);  // batch 0 has landed
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    double la[8], ta[8];  // CHAIN: operands of the next 8 rows
+    if (wave == 0 && active) {  // startVal = foldl1' add (pix <$> take r crds)   (ImageFilters.hs:59)
+        const int mr = r < n ? r : n;
+        s = *reinterpret_cast<const double *>(lbase);
+        int i = 1;
+        for (; i + 8 <= mr; i += 8) {
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t8[u] = *reinterpret_cast<const double *>(lbase + 24 * (i + u));
+#pragma unroll
+            for (int u = 0; u < 8; u++) s = s + t8[u];
+        }
+        for (; i < mr; i++) s = s + *reinterpret_cast<const double *>(lbase + 24 * i);
+    }
+#ifdef BS_SWEEP_PROBE
+    unsigned long long probe_work = 0, probe_start = __builtin_readcyclecounter();
+#endif
+    // iteration j: CHAIN computes block j into tile j & 1, STORE writes block j - 1 from tile (j - 1) & 1
+    for (int j = 0; j <= blocks; j++) {
+#ifdef BS_SWEEP_PROBE
+        const unsigned long long probe_t = __builtin_readcyclecounter();
+#endif
+        if (wave == 0) {
+            if (j < blocks) {
+                if (active) {
+                    const int x0 = j * kBlkRows;
+                    const unsigned char *pL = lbase + offL, *pT = lbase + offT;
+                    unsigned char *tile = tiles + (j & 1) * tile_bytes + lane * kTileColBytes;
+                    if ((j & 3) == 0) {  // first block of a loader phase: its operands landed with the barrier just passed
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            la[u] = *reinterpret_cast<const double *>(pL + 24 * u);
+                            ta[u] = *reinterpret_cast<const double *>(pT + 24 * u);
+                        }
+                    }
+                    const bool interior = x0 >= r && x0 + (kBlkRows - 1) + r < n;
+                    const bool next = (j & 3) != 3 && j + 1 < blocks;  // fetch block j+1's first operands during block j (same phase: landed)
+#ifdef BS_SWEEP_PROBE
+                    if (pl.dbg == 1) chain_block<false, true, 1>(pL, pT, tile, x0, r, n, s, la, ta);
+                    else if (pl.dbg == 2) chain_block<false, true, 2>(pL, pT, tile, x0, r, n, s, la, ta);
+                    else if (pl.dbg == 3) chain_block<false, true, 3>(pL, pT, tile, x0, r, n, s, la, ta);
+                    else
+#endif
+                    if (next) {
+                        if (interior) chain_block<false, true>(pL, pT, tile, x0, r, n, s, la, ta);
+                        else chain_block<true, true>(pL, pT, tile, x0, r, n, s, la, ta);
+                    } else {
+                        if (interior) chain_block<false, false>(pL, pT, tile, x0, r, n, s, la, ta);
+                        else chain_block<true, false>(pL, pT, tile, x0, r, n, s, la, ta);
+                    }
+                }
+                offL += 24 * kBlkRows; offL = offL >= ring ? offL - ring : offL;
+                offT += 24 * kBlkRows; offT = offT >= ring ? offT - ring : offT;
+            }
+        } else if (wave == 1) {
+            if (j < blocks) {
+                // loader phase k = 4 blocks = 128 rows = 3 chunks per pixel.  Blocks 0..2 of the phase each issue one chunk of batch
+                // k + Dp (into the slots of chunks that died with phase k-1); block 3 waits for batch k+1, which phase k+1 opens with.
+                const int k = j >> 2, q = j & 3;
+                if (q < 3) {
+                    const int c0 = batch_lo(k + Dp);
+                    const int knew = issue(c0 + q, c0 + q + 1);
+                    if (Dp == 1) v0 += knew; else if (Dp == 2) v1 += knew; else v2 += knew;
+                } else {
+                    wait_vmcnt_le(v1 + v2);
+                    v0 = v1; v1 = v2; v2 = 0;
+                }
+            }
+        } else if (j >= 1) {
+            const int jm = j - 1, mw = wave - 2;
+            const int xb = jm * kBlkRows + kRowsPerStore * mw;  // this wave's rows of the block: [xb, xb + kRowsPerStore)
+            const unsigned char *tile = tiles + (jm & 1) * tile_bytes + col * kTileColBytes + 8 * (kRowsPerStore * mw);
+            double *dst = out + ((size_t)(xb + rsub) * P + p0) * 3 + col;
+            const size_t step = (size_t)G * ostride;
+            const int iters = (kRowsPerStore + G - 1) / G;  // wave-uniform
+            for (int it0 = 0; it0 < iters; it0 += 4) {      // four tile reads, then their multiplies and stores
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int rowl = (it0 + q) * G + rsub;
+                    v[q] = *reinterpret_cast<const double *>(tile + 8 * (rowl < kRowsPerStore ? rowl : 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int rowl = (it0 + q) * G + rsub;
+                    if (lane_ok && rowl < kRowsPerStore && xb + rowl < n) dst[q * step] = norm * v[q];  // mul normFactor newRGB (:62-63)
+                }
+                dst += 4 * step;
+            }
+        }
+        // Block barrier WITHOUT a memory fence: only LDS (rings, tiles) is handed over between the wavefronts; a fence would
+        // wait for the LDS-DMA batches in flight and for the STORE wavefronts' stores -- exactly the latency this pipeline hides.
+#ifdef BS_SWEEP_PROBE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        probe_work += __builtin_readcyclecounter() - probe_t;
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#ifdef BS_SWEEP_PROBE
+    if (g == 0 && lane == 0 && pl.clocks) {  // per wavefront of group 0: clocks spent working (up to the barrier) / in the loop
+        pl.clocks[2 * wave] = probe_work;
+        pl.clocks[2 * wave + 1] = __builtin_readcyclecounter() - probe_start;
+    }
+#endif
+}
+
 // [rows][cols] pixels of 3 doubles -> [cols][rows]; 32x32-pixel tiles through LDS so both sides are coalesced.
 __global__ __launch_bounds__(256) void transpose_rgb(const double *__restrict__ in, double *__restrict__ out, int rows, int cols)
 {
@@ -251,45 +549,163 @@ __global__ void supersample_kernel(const double *in, double *out, int w2, int h,
     out[i] = 0.25 * (((a + b) + cc) + d);
 }
 
-// writeImg's pixel map: toWord8 . fmap sRGB   (Raytracer.hs:23-32); toWord8 = round-half-even (255 * clamp01 x)
-__global__ void srgb8_kernel(const double *in, unsigned char *out, size_t n)
+// writeImg's pixel map: toWord8 . fmap sRGB   (Raytracer.hs:23-32); toWord8 = round-half-even (255 * clamp01 x).
+// The map x -> byte is monotone, so it is fully described by 255 thresholds T[k] = the smallest double that maps to a byte
+// >= k.  The HOST finds them once per context by bisection over the bit patterns of x with the reference's own formula
+// evaluated with the host's libm `pow` (host_math.cpp: srgb8_thresholds) -- so the device reproduces the CPU's bytes
+// EXACTLY (no device pow, no 1-LSB flips next to a .5 boundary) with a few float operations per value: an f32 estimate
+// of the byte (v_log_f32 / v_exp_f32, good to ~1e-6 of 255) corrected against the neighbouring thresholds.
+// T has 257 entries: T[0] = -inf, T[1..255], T[256] = +inf.  NaN -> 0 (what the x86 cast of rint(NaN) gives the reference
+// restatement; every comparison with NaN is false).
+__device__ __forceinline__ unsigned srgb8_byte(double x, const double *T)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double x = in[i];
-    double y = (x < 0.0031308) ? 12.92 * x : (1 + 0.055) * pow(x, 1.0 / 2.4) - 0.055;
-    y = y < 0.0 ? 0.0 : (y > 1.0 ? 1.0 : y);  // NaN falls through both compares; rint(NaN)->0 below
-    out[i] = (unsigned char)(int)rint(255.0 * y);
+    const float xf = (float)x;
+    float yf = xf < 0.0031308f ? 12.92f * xf : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (1.0f / 2.4f)) - 0.055f;
+    yf = yf > 0.0f ? yf : 0.0f;   // also catches NaN
+    yf = yf < 1.0f ? yf : 1.0f;
+    int k = (int)(255.0f * yf + 0.5f);
+    // the estimate is off by at most one; the loops are bounded by the table and run zero or one times
+#pragma unroll 1
+    while (k < 255 && x >= T[k + 1]) k++;
+#pragma unroll 1
+    while (k > 0 && x < T[k]) k--;
+    return (unsigned)k;
+}
+
+__global__ __launch_bounds__(256) void srgb8_kernel(const double *__restrict__ in, unsigned char *__restrict__ out, size_t n, const double *__restrict__ table)
+{
+    __shared__ double T[257];
+    for (int i = threadIdx.x; i < 257; i += 256) T[i] = table[i];
+    __syncthreads();
+    // four values per lane -> one 32-bit store
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 4 <= n && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        unsigned v = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v |= srgb8_byte(in[i4 + u], T) << (8 * u);
+        *reinterpret_cast<unsigned *>(out + i4) = v;
+    } else {
+        for (size_t i = i4; i < n && i < i4 + 4; i++) out[i] = (unsigned char)srgb8_byte(in[i], T);
+    }
+}
+
+// bloom's last step fused with writeImg's pixel map: toWord8 (sRGB (img + strength * blurred))   (ImageFilters.hs:84-86 then
+// Raytracer.hs:31-32) -- the combined f64 image is never written (49.8 MB write + read and one launch less per frame).
+__global__ __launch_bounds__(256) void bloom_combine_srgb8(const double *__restrict__ img, const double *__restrict__ blurred, unsigned char *__restrict__ out,
+                                                            size_t n, double strength, const double *__restrict__ table)
+{
+    __shared__ double T[257];
+    for (int i = threadIdx.x; i < 257; i += 256) T[i] = table[i];
+    __syncthreads();
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 4 <= n && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        unsigned v = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v |= srgb8_byte(img[i4 + u] + strength * blurred[i4 + u], T) << (8 * u);
+        *reinterpret_cast<unsigned *>(out + i4) = v;
+    } else {
+        for (size_t i = i4; i < n && i < i4 + 4; i++) out[i] = (unsigned char)srgb8_byte(img[i] + strength * blurred[i], T);
+    }
 }
 
 }  // namespace
 
-int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, void *stream)
+// Geometry of the LDS-DMA sweep for P chain-pixels of n rows, window r, on a chip of n_cu CUs; false = not applicable.
+// single_round: only accept a plan whose workgroups all run at once (one per CU) -- with the LDS this kernel takes, a second
+// round of workgroups costs a whole extra sweep time.
+static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepPlan &pl, bool single_round)
 {
-    hipStream_t s = (hipStream_t)stream;
-    const int r = w / divider;  // boxBlur (w `div` divider) 3 img   (ImageFilters.hs:83)
+    if ((n & 1) || r < 1 || P < 1) return false;  // every chain-pixel's run must start 16-B aligned: n * 24 B a multiple of 16
+    if (reinterpret_cast<uintptr_t>(in) & 15) return false;
+    const long lr = (24l * r + kDmaChunk - 1) / kDmaChunk;
+    if (lr > 64) return false;
+    auto stride_of = [&](int dp) { return (3 * (1 + dp) + 2 * (int)lr + 1) * kDmaChunk + 32; };
+    const int tile_bytes = 2 * 3 * kTileColBytes;  // per pixel: two hand-off tiles of 3 chains x (kBlkRows + 1) doubles
+    const int px0 = std::max(1, std::min(kDmaMaxPx, (P + n_cu - 1) / n_cu));
+    int px = 0, dp = 0;
+    for (int d : {3, 2, 1}) {  // the px that covers the chip with one round of workgroups, as deep a prefetch as the LDS allows
+        if ((long)px0 * (stride_of(d) + tile_bytes) <= kDmaLds) { px = px0; dp = d; break; }
+    }
+    if (!px && !single_round) {  // fewer pixels per workgroup: more workgroups than CUs
+        for (int d : {2, 1}) {
+            const int fit = (int)(kDmaLds / (stride_of(d) + tile_bytes));
+            if (fit >= 1) { px = std::min(px0, fit); dp = d; break; }
+        }
+    }
+    if (!px) return false;
+    pl.px = px;
+    pl.Dp = dp;
+    pl.Lr = (int)lr;
+    pl.S = 3 * (1 + dp) + 2 * (int)lr;
+    pl.stride = stride_of(dp);
+    pl.groups = (P + px - 1) / px;
+    pl.per_xcd = (pl.groups + 7) / 8;
+    return !single_round || pl.groups <= n_cu;
+}
+
+// Sweep paths: "dma" = the six-wavefront LDS-DMA kernel, "lds" = the round-1 register-staged LDS ring (windows up to r = 192),
+// "direct" = transpose + register-prefetch sweep (any size).  Default: dma wherever its plan exists (even dimensions, 16-B aligned
+// input; measured faster than lds at 720p / 1080p / 2160p and windows up to r = 192: scripts/bloom_ab.py), else lds when its
+// ring covers the window (odd sizes), else direct.  env BLACKSTAR_BLOOM_PATH=dma|lds|direct forces one where it applies (A/B and
+// tests), read per call.
+static int bloom_path()
+{
+    const char *e = std::getenv("BLACKSTAR_BLOOM_PATH");
+    if (!e) return 0;
+    if (!std::strcmp(e, "dma")) return 3;
+    if (!std::strcmp(e, "lds")) return 1;
+    if (!std::strcmp(e, "direct")) return 2;
+    return 0;
+}
+
+// The three boxBlur passes (ImageFilters.hs:66-77): src -> ... -> d_b.  d_a, d_b: scratch of w*h*3 doubles, never aliasing src.
+static void blur_passes(const double *src, double *d_a, double *d_b, int w, int h, int r, int n_cu, hipStream_t s)
+{
     const double norm = 1 / (2 * (double)r + 1);
-    const size_t n = (size_t)w * h * 3;
     const dim3 tgrid_hw((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32));  // transposing an h x w image
     const dim3 tgrid_wh((unsigned)((h + 31) / 32), (unsigned)((w + 31) / 32));  // transposing a  w x h image
-    const double *src = d_in;
-    const bool staged = 2 * r + 2 * kLT <= kLR;  // the LDS ring covers the window
+    const int path = bloom_path();
+    const bool lds_fits = 2 * r + 2 * kLT <= kLR;
     for (int pass = 0; pass < 3; pass++) {
-        if (staged) {
-            // H: image layout (h x w) -> transposed layout (w x h); V: transposed -> image layout.  No transpose kernels.
+        SweepPlan ph, pv;
+        bool dma = false;
+        if (path == 0 || path == 3) dma = plan_dma_sweep(src, h, w, r, n_cu, ph, false) && plan_dma_sweep(d_a, w, h, r, n_cu, pv, false);
+        // H: image layout (h x w) -> transposed layout (w x h); V: transposed -> image layout.  No transpose kernels.
+        if (dma) {
+            hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * ph.per_xcd)), dim3(kSweepThreads), 0, s, src, d_a, h, w, r, norm, ph);
+            hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * pv.per_xcd)), dim3(kSweepThreads), 0, s, (const double *)d_a, d_b, w, h, r, norm, pv);
+        } else if (path != 2 && lds_fits) {
             hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((h + kLP - 1) / kLP)), dim3(256), 0, s, src, d_a, h * 3, w, r, norm);
             hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((w + kLP - 1) / kLP)), dim3(256), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);
         } else {
-            // window wider than the ring: transpose, sweep along the slow axis with register prefetch, transpose back
+            // any size (odd dimensions, windows wider than the LDS): transpose, sweep along the slow axis with register prefetch, transpose back
             hipLaunchKernelGGL(transpose_rgb, tgrid_hw, dim3(256), 0, s, src, d_a, h, w);                  // src (h x w) -> A (w x h)
             hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((h * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, h * 3, w, r, norm);
             hipLaunchKernelGGL(transpose_rgb, tgrid_wh, dim3(256), 0, s, (const double *)d_b, d_a, w, h);  // B (w x h) -> A (h x w)
             hipLaunchKernelGGL(box_blur_sweep, dim3((unsigned)((w * 3 + 63) / 64)), dim3(64), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);
         }
-        src = d_b;
+        src = d_b;  // pass p+1 reads B while writing A, then A -> B: A and B never alias
     }
-    // NOTE: pass p+1 reads B while writing A -- A and B never alias, so this is safe.
+}
+
+int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int r = w / divider;  // boxBlur (w `div` divider) 3 img   (ImageFilters.hs:83)
+    const size_t n = (size_t)w * h * 3;
+    blur_passes(d_in, d_a, d_b, w, h, r, n_cu, s);
     hipLaunchKernelGGL(bloom_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (const double *)d_b, d_out, n, strength);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_bloom_srgb8(const double *d_in, unsigned char *d_out_u8, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu,
+                       const double *d_table, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int r = w / divider;
+    const size_t n = (size_t)w * h * 3;
+    blur_passes(d_in, d_a, d_b, w, h, r, n_cu, s);
+    hipLaunchKernelGGL(bloom_combine_srgb8, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, d_in, (const double *)d_b, d_out_u8, n, strength, d_table);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -302,10 +718,10 @@ int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, void *stream)
+int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, const double *d_table, void *stream)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(srgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
+    hipLaunchKernelGGL(srgb8_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n, d_table);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

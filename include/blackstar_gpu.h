@@ -208,6 +208,11 @@ long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size_t cap);
  * (stars + copies in neighbouring faces), or BS_EINVAL. */
 long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_start, int32_t *entry_star, size_t cap);
 
+/* Test hook, host-only: the 257 thresholds of writeImg's pixel map toWord8 . sRGB (src/Raytracer.hs:23-32) that bs_srgb8 and
+ * bs_render_rgb8 compare against on the device: table[k], k = 1..255, is the smallest double whose byte is >= k (found by
+ * bisection with the host libm's pow, once per process); table[0] = -inf, table[256] = +inf. */
+int bs_debug_srgb8_table(double table[257]);
+
 /* Replaces: toPixelRGB on PixelHSI (massiv-io Graphics.ColorSpace; call sites src/Raytracer.hs:65,
  * src/StarMap.hs:114).  Host-only; returns BS_EINVAL if the hue is outside [0,1). */
 int bs_hsi_to_rgb(double hue, double sat, double intensity, double rgb[3]);

@@ -1,0 +1,65 @@
+// sweep_probe.hip -- where does a box-blur sweep's time go?  Builds the product's own box_blur_sweep_dma with BS_SWEEP_PROBE
+// (chain variants without its LDS writes / reads, per-wavefront work clocks of workgroup 0) and times the H and V sweep of a frame.
+// Build (cross-compiles):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scripts/probe/sweep_probe.hip -o scripts/probe/sweep_probe
+#define BS_SWEEP_PROBE 1
+#include "../../blackstar_amd/csrc/post_kernels.hip"
+
+#include <cstdio>
+#include <vector>
+
+using namespace bs;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const int w = argc > 1 ? std::atoi(argv[1]) : 1920, h = argc > 2 ? std::atoi(argv[2]) : 1080, r = argc > 3 ? std::atoi(argv[3]) : 76;
+    const size_t n = (size_t)w * h * 3;
+    double *a = nullptr, *b = nullptr;
+    unsigned long long *clk = nullptr;
+    CK(hipMalloc((void **)&a, n * 8 + 4096));
+    CK(hipMalloc((void **)&b, n * 8 + 4096));
+    CK(hipMalloc((void **)&clk, 256));
+    std::vector<double> host(n);
+    for (size_t i = 0; i < n; i++) host[i] = (double)((i * 2654435761u) % 1000) / 1000.0;
+    CK(hipMemcpy(a, host.data(), n * 8, hipMemcpyHostToDevice));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double norm = 1.0 / (2 * r + 1);
+    struct Sweep { const char *name; int P, n; } sweeps[2] = {{"H", h, w}, {"V", w, h}};
+    for (const Sweep &sw : sweeps) {
+        {   // the four-wavefront kernel (the product path)
+            SweepPlan p4;
+            if (plan_dma_sweep(a, sw.P, sw.n, r, n_cu, p4, false)) {
+                for (int var : {0, 1, 2, 3}) {
+                    const int dp = 0;
+                    SweepPlan q = p4;
+                    q.dbg = var; q.clocks = clk;
+                    if (dp) {
+                        q.Dp = dp; q.S = 3 * (1 + dp) + 2 * q.Lr; q.stride = (q.S + 1) * kDmaChunk + 32;
+                        if ((long)q.px * (q.stride + 2 * 3 * kTileColBytes) > kDmaLds) continue;
+                    }
+                    float best = 1e9f;
+                    for (int it = 0; it < 6; it++) {
+                        CK(hipEventRecord(e0, nullptr));
+                        hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * q.per_xcd)), dim3(kSweepThreads), 0, nullptr, (const double *)a, b, sw.P, sw.n, r, norm, q);
+                        CK(hipEventRecord(e1, nullptr));
+                        CK(hipEventSynchronize(e1));
+                        float ms = 0;
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        if (ms < best) best = ms;
+                    }
+                    unsigned long long c8[12];
+                    CK(hipMemcpy(c8, clk, 96, hipMemcpyDeviceToHost));
+                    std::printf("%s sweep dma4 probe=%d: px=%d Dp=%d S=%d groups=%d: %.1f us (%.1f clk/row at 2.4 GHz)  work/loop clocks per row: chain %.1f/%.1f loader %.1f/%.1f store0 %.1f/%.1f store3 %.1f/%.1f\n",
+                                sw.name, var, q.px, q.Dp, q.S, q.groups, best * 1e3, best * 1e-3 * 2.4e9 / sw.n, (double)c8[0] / sw.n, (double)c8[1] / sw.n,
+                                (double)c8[2] / sw.n, (double)c8[3] / sw.n, (double)c8[4] / sw.n, (double)c8[5] / sw.n, (double)c8[10] / sw.n, (double)c8[11] / sw.n);
+                }
+            }
+        }
+    }
+    return 0;
+}

@@ -319,9 +319,7 @@ def test_bloom_and_srgb8_match_oracle(tree, oracle):
     with pytest.raises(bs._lib.BlackstarError):
         bs.bloom(0.1, 1000, odd, tree)  # radius 0
     u8 = bs.srgb8(got, tree)
-    ref8 = oracle.srgb8(got)
-    diff = np.abs(u8.astype(int) - ref8.astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() < 1e-4  # device pow vs glibc pow may flip a value sitting on a .5 boundary
+    assert np.array_equal(u8, oracle.srgb8(got))  # threshold-table pixel map: the host libm's bytes exactly
     import torch
     t = torch.from_numpy(img).to("cuda:0")
     o = torch.empty_like(t)
@@ -354,12 +352,10 @@ def test_render_rgb8_pipeline(tree, oracle, tmp_path):
     got = bs.render_rgb8(cfg, tree)
     img = bs.render(cfg, tree)
     exp = oracle.srgb8(oracle.bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img))
-    d = np.abs(got.astype(int) - exp.astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert np.array_equal(got, exp)  # bloom bit-exact, fused combine + threshold-table sRGB8 exact
     assert got.max() > 100 and got.shape == (90, 160, 3)
     cfg.scene.bloomStrength = 0.0  # no bloom branch
-    d = np.abs(bs.render_rgb8(cfg, tree).astype(int) - oracle.srgb8(img).astype(int))
-    assert d.max() <= 1
+    assert np.array_equal(bs.render_rgb8(cfg, tree), oracle.srgb8(img))
     bs.write_png(got, str(tmp_path / "o.png"))
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png")), got)
@@ -481,8 +477,7 @@ def test_render_animation_single_rank(tree, tmp_path, oracle):
     for i in (0, 2, 4):
         img = bs.render(cfgs[i], tree)
         exp = oracle.srgb8(oracle.bloom(anim.scene.bloomStrength, anim.scene.bloomDivider, img))
-        d = np.abs(frames[i].numpy().astype(int) - exp.astype(int))
-        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        assert np.array_equal(frames[i].numpy(), exp)
     assert not np.array_equal(frames[0].numpy(), frames[4].numpy())  # the camera moved
 
 
@@ -923,3 +918,79 @@ def test_star_lookup_reuses_its_scratch(tree, oracle, oracle_index):
             ref, nref = oracle.star_lookup(oracle_index, 0.4, 1.5, dirs[k])
             assert hits[k] == nref
             np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
+
+
+# ---- bloom: every path of the sweeps (LDS-DMA ring, the round-1 LDS ring, the direct transpose + register sweep), bit-exact ----
+
+BLOOM_SHAPES = [  # (width, height, divider) -> r = width // divider
+    (1920, 1080, 25),   # the BASELINE frame: r = 76, 216 / 240 workgroups, 5 / 8 chain-pixels each
+    (200, 112, 25),     # fewer chain-pixels than CUs: one pixel per workgroup
+    (640, 360, 5),      # r = 128: Lr = 3
+    (400, 40, 4),       # r = 100 > height: the vertical window is wider than the image (lead always black)
+    (64, 500, 32),      # r = 2: the smallest windows, tall image
+    (5000, 64, 25),     # r = 200: wider than the round-1 ring (-> that path falls back), many chain-pixels in V
+    (7680, 66, 25),     # r = 307: the ring plan has to drop to fewer pixels per workgroup and two phases in flight
+    (130, 258, 1),      # divider 1: r = width = 130 >= width (H window wider than the row), r < height
+    (31, 47, 5),        # odd x odd: chain runs are not 16-B aligned -> direct path
+    (32, 47, 5),        # even width, odd height -> direct path
+    (33, 48, 5),        # odd width, even height -> direct path
+    (2, 2, 1), (8, 2, 3), (2, 300, 1),
+]
+
+
+@pytest.mark.parametrize("w,h,div", BLOOM_SHAPES)
+def test_bloom_paths_bit_exact(w, h, div, tree, oracle, monkeypatch):
+    rng = np.random.default_rng(w * 7 + h)
+    img = rng.uniform(0, 2, (h, w, 3)) * (rng.uniform(0, 1, (h, w, 1)) < 0.2)  # mostly black with bright pixels, like a star field
+    ref = oracle.bloom(0.3, div, img)
+    for path in ("auto", "dma", "lds", "direct"):
+        monkeypatch.setenv("BLACKSTAR_BLOOM_PATH", path)
+        got = bs.bloom(0.3, div, img, tree)
+        assert np.array_equal(got, ref), f"path {path}: {np.abs(got - ref).max():.3e} max abs diff, {(got != ref).sum()} values differ"
+    monkeypatch.delenv("BLACKSTAR_BLOOM_PATH")
+    assert np.array_equal(bs.srgb8(ref, tree), oracle.srgb8(ref))
+
+
+def test_bloom_device_unaligned_and_aliased_buffers(tree, oracle):
+    """bs_bloom_device with in == out (allowed) and with a device pointer that is only 8-byte aligned (the DMA path needs 16:
+    it must notice and take the direct path for the first sweep's input)."""
+    import torch
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 1.5, (90, 160, 3))
+    ref = oracle.bloom(0.15, 25, img)
+    L = _lib.lib()
+    t = torch.from_numpy(img).to("cuda:0")
+    _lib.check(L.bs_bloom_device(tree.handle, t.data_ptr(), t.data_ptr(), 160, 90, 0.15, 25, None), "bloom in place")
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), ref)
+    big = torch.zeros(img.size + 1, dtype=torch.float64, device="cuda:0")
+    view = big[1:]
+    assert view.data_ptr() % 16 == 8
+    view.copy_(torch.from_numpy(img).reshape(-1))
+    out = torch.empty(img.size, dtype=torch.float64, device="cuda:0")
+    _lib.check(L.bs_bloom_device(tree.handle, view.data_ptr(), out.data_ptr(), 160, 90, 0.15, 25, None), "bloom unaligned")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(90, 160, 3), ref)
+
+
+def test_srgb8_is_exact_everywhere(tree, oracle):
+    """The threshold-table pixel map against the host libm formula: dense around every one of the 255 byte boundaries, the
+    linear/power seam, and the specials."""
+    rng = np.random.default_rng(9)
+    a = 0.055
+    k = np.arange(1, 256)
+    y = (k - 0.5) / 255.0
+    xb = np.where(y < 12.92 * 0.0031308, y / 12.92, ((y + a) / (1 + a)) ** 2.4)   # where the byte changes
+    near = (xb[:, None] * (1 + np.linspace(-3e-7, 3e-7, 4001)[None, :])).ravel()
+    ulps = np.concatenate([np.nextafter(xb, np.inf), np.nextafter(xb, -np.inf), xb])
+    for _ in range(6):
+        ulps = np.concatenate([ulps, np.nextafter(ulps, np.inf), np.nextafter(ulps, -np.inf)])
+    special = np.array([0.0, -0.0, -1.0, 1.0, 1.0 + 1e-16, 2.0, 1e300, -1e300, np.inf, -np.inf, np.nan, 5e-324, 0.0031308,
+                        np.nextafter(0.0031308, 0), np.nextafter(0.0031308, 1), 0.5, 1e-10])
+    x = np.concatenate([near, ulps, special, rng.uniform(-0.1, 1.2, 500000), np.exp(rng.uniform(-12, 1, 200000))])
+    x = np.concatenate([x, x[:7]])  # a length that is not a multiple of 4
+    got = bs.srgb8(x, tree)
+    ref = oracle.srgb8(x)
+    bad = np.nonzero(got != ref)[0]
+    assert len(bad) == 0, f"{len(bad)} bytes differ, first x={x[bad[0]]!r} got {got[bad[0]]} want {ref[bad[0]]}"
+    assert set(np.unique(ref)) == set(range(256))

@@ -268,3 +268,19 @@ def test_star_grid_margin_bound():
     du = np.abs(s[:, 0] / s[:, 2] - uv[:, 0]); dv = np.abs(s[:, 1] / s[:, 2] - uv[:, 1])
     assert max(du.max(), dv.max()) < DELTA * 0.97, (du.max(), dv.max())
     assert 2 * DELTA <= 2.0 / G
+
+
+def test_srgb8_threshold_table_is_the_oracles_pixel_map(oracle):
+    """The 255 thresholds the device compares against (bs_debug_srgb8_table, built with the host's libm): each one is exactly
+    where the oracle's toWord8 . sRGB steps from k-1 to k, and the map is monotone on a dense sample in between."""
+    import ctypes as C
+    T = np.zeros(257)
+    assert _lib.lib().bs_debug_srgb8_table(T.ctypes.data_as(C.c_void_p)) == 0
+    assert T[0] == -np.inf and T[256] == np.inf and (np.diff(T[1:256]) > 0).all()
+    k = np.arange(1, 256)
+    assert np.array_equal(oracle.srgb8(T[1:256]), k.astype(np.uint8))
+    assert np.array_equal(oracle.srgb8(np.nextafter(T[1:256], -np.inf)), (k - 1).astype(np.uint8))
+    x = np.sort(np.random.default_rng(5).uniform(0, 1.05, 400000))
+    b = oracle.srgb8(x)
+    assert (np.diff(b.astype(int)) >= 0).all()
+    assert np.array_equal(b, (np.searchsorted(T[1:256], x, side="right")).astype(np.uint8))
