@@ -98,3 +98,46 @@ def ring_offsets_vs_reference_example(img):
             continue
         out.append(r[kr] - r[km])
     return np.array(out), len(th)
+
+
+def disk_inner_edge_offsets_vs_reference_example(img, tau=0.15):
+    """Locus of the accretion disk's INNER edge in a render of the scenes/default.yaml camera at 1280x720 with the ConfigFile
+    default disk radii (diskInner 3, diskOuter 12) against the reference repository's example.png, via
+    tests/golden/reference_example_disk.npz (make_reference_disk_edges.py).  Along each of 180 rays from the shadow's centre, every
+    ONSET of light in `img` (>= 12 px of exact darkness, then a rise past 2.5 tau) is located by where its luminance crosses
+    tau (linear light, R+G+B), and the reference by where ITS (sRGB-decoded, lightly smoothed) luminance crosses the local
+    background + tau.  Onsets are the photon ring (r < 122 px) and the r = diskInner edge of the primary and of the lensed
+    secondary image.  Returns an array of (angle deg, radius px of the onset in img, reference - img in px)."""
+    from scipy import ndimage as ndi
+    g = np.load(os.path.join(GOLDEN, "reference_example_disk.npz"))
+    cx, cy, r, th = float(g["cx"]), float(g["cy"]), g["r"], g["theta"]
+    assert img.shape == (int(g["height"]), int(g["width"]), 3)
+    raw = g["lum3"].astype(np.float64)
+    inside = raw < 60000
+    v = np.clip(raw, 0, 765) / 765.0
+    ref = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4) * 3.0  # linear light, R+G+B
+    lum = img.sum(axis=2)
+    mine = np.stack([ndi.map_coordinates(lum, [cy + r * np.sin(t), cx + r * np.cos(t)], order=1, mode="constant", cval=0.0) for t in th])
+    dr = float(r[1] - r[0])
+    dark, rise, reach = int(12 / dr), int(8 / dr), int(14 / dr)
+
+    def cross(a, level, start):
+        for q in range(max(start, 1), min(start + reach, len(a))):
+            if a[q] >= level > a[q - 1]:
+                return q - 1 + (level - a[q - 1]) / (a[q] - a[q - 1])
+        return None
+
+    out = []
+    for i in range(len(th)):
+        m, rf, lit = mine[i], ndi.gaussian_filter1d(ref[i], 0.75 / dr), mine[i] > 1e-9
+        k = dark
+        while k < len(r) - reach - 12:
+            if lit[k] and not lit[k - dark:k].any() and m[k:k + rise].max() > 2.5 * tau and inside[i, k - dark:k + reach + 12].all():
+                bg = float(np.median(rf[k - dark + 4:k - 8]))
+                cm, cr = cross(m, tau, k - 1), cross(rf, bg + tau, k - int(6 / dr))
+                if bg < 0.35 and cm is not None and cr is not None:  # a star or the disk's own glow in the dark stretch: skip
+                    out.append((np.rad2deg(th[i]), r[k], (cr - cm) * dr))
+                k += reach + 12
+            else:
+                k += 1
+    return np.array(out)

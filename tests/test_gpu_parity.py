@@ -994,3 +994,26 @@ def test_srgb8_is_exact_everywhere(tree, oracle):
     bad = np.nonzero(got != ref)[0]
     assert len(bad) == 0, f"{len(bad)} bytes differ, first x={x[bad[0]]!r} got {got[bad[0]]} want {ref[bad[0]]}"
     assert set(np.unique(ref)) == set(range(256))
+
+
+@pytest.mark.parametrize("mode", [_lib.BS_MODE_STRICT, _lib.BS_MODE_FAST])
+def test_disk_inner_edge_matches_the_reference_repositorys_example_image(mode, tree_empty):
+    """The GPU render of the scene example.png shows (scenes/default.yaml's camera, ConfigFile default disk radii 3 / 12) against
+    the reference repository's own picture: the locus of the disk's inner edge in the primary and in the lensed secondary image
+    (tests/golden/make_reference_disk_edges.py; bar and negative controls as in tests/test_oracle.py)."""
+    from conftest import disk_inner_edge_offsets_vs_reference_example
+    cfg = dict(scenes.with_res(scenes.DEFAULT, 1280, 720, ss=True), disk_inner=3.0, disk_outer=12.0, disk_hsi=(0.16, 0.1, 0.95))
+    tree_empty.set_mode(mode)
+    try:
+        img = bs.render(cfg, tree_empty)
+        bad = bs.render(dict(cfg, disk_inner=3.3), tree_empty)
+    finally:
+        tree_empty.set_mode(_lib.BS_MODE_STRICT)
+    o = disk_inner_edge_offsets_vs_reference_example(img)
+    edge, ring = o[o[:, 1] > 122], o[o[:, 1] <= 122]
+    print(f"disk inner edge, reference - GPU: {len(edge)} angles, mean {edge[:, 2].mean():+.2f} px, std {edge[:, 2].std():.2f}; ring: {len(ring)} angles, mean {ring[:, 2].mean():+.2f}")
+    assert len(edge) >= 120 and -0.5 < edge[:, 2].mean() < 2.2 and edge[:, 2].std() < 2.0
+    assert len(ring) >= 90 and abs(ring[:, 2].mean()) < 0.6 and ring[:, 2].std() < 0.6
+    o2 = disk_inner_edge_offsets_vs_reference_example(bad)
+    e2 = o2[o2[:, 1] > 122]
+    assert not (len(e2) >= 120 and -0.5 < e2[:, 2].mean() < 2.2 and e2[:, 2].std() < 2.0)  # a 10 % larger diskInner is rejected

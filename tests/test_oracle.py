@@ -271,3 +271,42 @@ def test_photon_ring_matches_the_reference_repositorys_example_image(oracle, ora
     wide = dict(scenes.with_res(scenes.DEFAULT, 1280, 720), fov=1.5 * 1.02)
     d2, _ = ring_offsets_vs_reference_example(oracle.render(wide, oracle_index_empty, threads=0)[0])
     assert len(d2) >= 0.7 * n and d2.mean() > 1.5
+
+
+def _example_scene(**over):
+    """The scene example.png shows: scenes/default.yaml's camera at 1280x720, supersampled, with the ConfigFile DEFAULT disk
+    (diskInner 3, diskOuter 12, default colour: src/ConfigFile.hs:74-77) -- see tests/golden/make_reference_disk_edges.py."""
+    return dict(dict(scenes.with_res(scenes.DEFAULT, 1280, 720, ss=True), disk_inner=3.0, disk_outer=12.0, disk_hsi=(0.16, 0.1, 0.95)), **over)
+
+
+def test_disk_inner_edge_matches_the_reference_repositorys_example_image(oracle, oracle_index_empty):
+    """example.png again (cf. the photon-ring test), second feature: the locus of the disk's inner edge, r = diskInner, in the
+    primary image (above the shadow) and in the lensed secondary image (below it) -- about 150 angles.  It is where findColor's
+    y-plane sign-change test with the interpolated r2ave first exceeds diskInner^2 (src/Raytracer.hs:96-102), reached by rays
+    that pass the hole at 3 .. 6 Schwarzschild radii: a different family from the ring's.  The older revision that produced the
+    picture uses another intensity law (narrower profile, B/R = 0.79), which delays ITS threshold crossing by 1-2 px: the bar
+    is 'within 2.2 px on average'; a 10 % change of diskInner moves the locus by 4 px and is rejected."""
+    from conftest import disk_inner_edge_offsets_vs_reference_example
+    img, _ = oracle.render(_example_scene(), oracle_index_empty, threads=0)
+    o = disk_inner_edge_offsets_vs_reference_example(img)
+    edge, ring = o[o[:, 1] > 122], o[o[:, 1] <= 122]
+    lower, upper = edge[edge[:, 0] < 180], edge[edge[:, 0] >= 180]  # lensed secondary image / primary image
+    print(f"disk inner edge, reference - oracle: {len(edge)} angles, mean {edge[:, 2].mean():+.2f} px, std {edge[:, 2].std():.2f}, max |d| {np.abs(edge[:, 2]).max():.2f} "
+          f"(lensed image: {len(lower)} angles {lower[:, 2].mean():+.2f}; primary: {len(upper)} angles {upper[:, 2].mean():+.2f}); "
+          f"ring: {len(ring)} angles, mean {ring[:, 2].mean():+.2f}, std {ring[:, 2].std():.2f}")
+    assert len(lower) >= 20 and len(upper) >= 80 and len(ring) >= 90
+    assert _edge_locus_accepted(edge)
+    assert abs(ring[:, 2].mean()) < 0.6 and ring[:, 2].std() < 0.6
+    # negative controls: a 10 % change of diskInner either way moves the locus by about 4 px (or out of the matching window) ...
+    for inner in (3.3, 2.7):
+        o2 = disk_inner_edge_offsets_vs_reference_example(oracle.render(_example_scene(disk_inner=inner), oracle_index_empty, threads=0)[0])
+        assert not _edge_locus_accepted(o2[o2[:, 1] > 122]), inner
+    # ... and it is the ConfigFile default radius, not default.yaml's 1.8, that the picture shows
+    o3 = disk_inner_edge_offsets_vs_reference_example(oracle.render(_example_scene(disk_inner=1.8, disk_outer=13.0), oracle_index_empty, threads=0)[0])
+    assert not _edge_locus_accepted(o3[o3[:, 1] > 122])
+
+
+def _edge_locus_accepted(edge):
+    """The bar of the disk-edge pin: onsets matched at >= 120 of the 180 angles, reference - render between -0.5 and +2.2 px on
+    average (the older revision's intensity law delays its threshold crossing by 1-2 px), scatter below 2 px."""
+    return len(edge) >= 120 and -0.5 < edge[:, 2].mean() < 2.2 and edge[:, 2].std() < 2.0
