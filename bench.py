@@ -174,7 +174,9 @@ def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
     def entry(ms, note):
         return {"ms": ms, "Mpixel_s": W * H / ms / 1e3, "note": note}
 
+    t0 = time.perf_counter()
     pinned = bs.alloc_image(tree, H, W)
+    res["bs_host_alloc_ms"] = (time.perf_counter() - t0) * 1e3  # why the shim allocates its page-locked image buffer ONCE
     bs.render(cfg, tree, out=pinned)
     res["bs_render_pinned"] = entry(med(lambda: bs.render(cfg, tree, out=pinned), 5),
                                     "bs_render into a bs_host_alloc buffer: kernel (two half-frame launches) + 49.8 MB D2H, blocking")
