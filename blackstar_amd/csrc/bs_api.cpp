@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +40,7 @@ struct bs_ctx {
     int mode = BS_MODE_FAST;
     int max_steps = 100000;
     int disk_slots = 4;
+    bool fast_guard = true;      // FAST mode re-traces photon-sphere-grazing rays in STRICT (env BLACKSTAR_FAST_GUARD=0 turns it off for A/B)
     int n_cu = 256;
     int blocks_per_cu = 4;       // resident workgroups per CU (VGPR/LDS-limited); env BLACKSTAR_BLOCKS_PER_CU for A/B builds
     int stagger_cycles = 16000;  // first-tile phase offset per SIMD slot (env BLACKSTAR_STAGGER overrides; 0 = off)
@@ -104,6 +106,7 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 
     p.band_t0 = p.ss ? 2 * row0 : row0;
     p.band_t1 = p.ss ? 2 * row1 : row1;
     p.max_steps = ctx->max_steps;
+    if (!ctx->fast_guard) p.guard_steps = INT32_MAX;
     p.disk_slots = ctx->disk_slots;
     {
         const long tiles = (long)((p.wt + 7) / 8) * ((p.band_t1 - p.band_t0 + 7) / 8);
@@ -118,6 +121,17 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 
     p.cell_start = ctx->d_cell_start;
     p.counters = ctx->d_counters;  // enqueue_render substitutes the launch slot's block
     return BS_OK;
+}
+
+// The arithmetic a frame is traced with.  FAST's error model (rounding differences of ~1 ulp per right-hand side, amplified by
+// the discrete map) needs the RK4 step to resolve the field: with stepSize above 0.5 Schwarzschild radii a single step past the
+// hole amplifies a perturbation by >10x and FAST and STRICT trajectories part ways (scripts/fuzz_worst.py: terminal directions
+// 4e-3 apart at stepSize 1.0, all of the fuzz's largest colour deviations), so such frames are traced with STRICT arithmetic even
+// in FAST mode -- the reference's default is 0.3 and every scene file it ships uses that.  (BLACKSTAR_FAST_GUARD=0: off, for A/B.)
+int effective_mode(const bs_ctx *ctx, const bs_config *cfg)
+{
+    if (ctx->mode == BS_MODE_FAST && ctx->fast_guard && !(cfg->step_size <= 0.5)) return BS_MODE_STRICT;
+    return ctx->mode;
 }
 
 // On every exit path of a blocking entry point nothing of the call may still be in flight: the caller's buffers are DMA
@@ -176,7 +190,7 @@ int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_
     bs_ctx::LaunchSlot &sl = ctx->slots[ctx->cur_slot];
     if (!first) HIP_TRY(hipMemsetAsync(sl.d_counters + (bs::kCounters - 1), 0, sizeof(unsigned long long), s));  // tile queue head
     p.counters = sl.d_counters;
-    if (bs::launch_trace(p, ctx->mode, s)) return fail(BS_EDEVICE, "kernel launch failed");
+    if (bs::launch_trace(p, effective_mode(ctx, cfg), s)) return fail(BS_EDEVICE, "kernel launch failed");
     sl.rays += (uint64_t)p.wt * (uint64_t)(p.band_t1 - p.band_t0);
     if (last) {
         if (!quiet) {
@@ -244,6 +258,7 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     ctx->device = device;
     ctx->n_stars = n_stars;
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
+    if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_MODE")) {
@@ -695,7 +710,7 @@ int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n
     bs_ray_record *d_out = reinterpret_cast<bs_ray_record *>(static_cast<char *>(ctx->d_scratch) + yx_bytes);
     StreamDrain drain(ctx);
     HIP_TRY(hipMemcpyAsync(d_yx, yx, n_rays * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (bs::launch_trace_records(p, ctx->mode, d_yx, n_rays, d_out, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
+    if (bs::launch_trace_records(p, effective_mode(ctx, cfg), d_yx, n_rays, d_out, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
     HIP_TRY(hipMemcpyAsync(out, d_out, n_rays * sizeof(bs_ray_record), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;

@@ -68,6 +68,7 @@ struct TraceParams {
     int32_t ss;                  // supersampling
     int32_t out_w, out_h;
     int32_t max_steps;
+    int32_t guard_steps;         // FAST mode: rays that take more steps than this are re-traced with STRICT arithmetic (derive_params)
     int32_t n_entries;           // entries in nodes/colors (stars + border duplicates)
     int32_t grid_blocks;         // persistent workgroups launched (<= 4 per CU)
     int32_t stagger_cycles;      // first-tile phase offset per SIMD slot, in shader cycles (0 = off)

@@ -134,6 +134,15 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
     p.star_intensity = c.star_intensity;
     p.star_saturation = c.star_saturation;
     p.star_a = std::log(2.0) / 50;  // StarMap.hs:108  a = log 2 / dynamic
+    // FAST mode's guard (trace_kernel.hip: trace_ray): a ray that needs more steps than the longest straight path through the
+    // scene, N0 = (|camera| + sqrt safeDistance) / stepSize, plus one photon-sphere circumference (2 pi 1.5 ~ 9.4 -> 9.0 / stepSize
+    // steps) has orbited the hole about once; every further orbit multiplies ANY rounding difference by e^(2 pi) ~ 535.  Measured
+    // (scripts/fast_guard_probe.py, profiles/r02_fast_guard_probe.txt): FAST - STRICT grows 10x per 10 excess steps at h = 0.3, is
+    // <= 1.2e-7 relative below 30 and reaches 1e-6 .. 2e-5 beyond; 4 .. 16 rays per million are beyond.  Those are re-traced in STRICT.
+    {
+        const double n0 = (p.rcam + std::sqrt(p.safe)) / c.step_size + 9.0 / c.step_size;
+        p.guard_steps = (n0 > 0 && n0 < 2.0e9) ? (int32_t)std::ceil(n0) : INT32_MAX;
+    }
     return true;
 }
 

@@ -694,12 +694,17 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
     int ncross = lds.count();
     int fate = !live ? -1 : fate_code;
     double rgba[4] = {0, 0, 0, 0};  // colorize' starts from PixelRGBA 0 0 0 0 (:86)
-    if (ncross < kOverflow) {
+    // FAST only: a ray that took more than P.guard_steps steps has circled the photon sphere, where every orbit multiplies any
+    // rounding difference by ~535 -- its result is recomputed with STRICT arithmetic (bit-exact trajectories), so FAST's
+    // deviation from the reference stays that of the well-conditioned rays.  A few rays per million; see derive_params.
+    const bool guarded = FAST && live && steps > P.guard_steps;
+    if (ncross < kOverflow && !guarded) {
         for (int k = 0; k < ncross; k++) shade_disk(P, lds.slot(k), rgba);  // blend the recorded layers, oldest first
-    } else if (live) {  // more crossings than slots: the simple restatement redoes this ray
+    } else if (live) {  // more crossings than slots, or a guarded ray: the simple restatement redoes this ray
         double out[10];
         int iout[3];
-        trace_ray_simple<FAST>(P, yi, xi, out, iout);
+        if (guarded) trace_ray_simple<false>(P, yi, xi, out, iout);
+        else trace_ray_simple<FAST>(P, yi, xi, out, iout);
         for (int i = 0; i < 3; i++) { v[i] = out[i]; p[i] = out[3 + i]; }
         for (int i = 0; i < 4; i++) rgba[i] = out[6 + i];
         steps = iout[0]; fate = iout[1]; ncross = iout[2];

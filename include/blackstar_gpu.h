@@ -48,7 +48,11 @@ enum {
  *         r^-5 from v_rsq_f64 + a 2nd-order series correction.  Step counts, fates and disk crossings equal
  *         STRICT's on every ray tested; pixel values agree with STRICT to 3.4e-8 absolute / 3.7e-7 relative
  *         on the BASELINE frames (worst 2.3e-5 relative over a 10 000-scene fuzz: rays grazing the photon
- *         sphere amplify any rounding difference) -- inside the 1e-4 relative bar, not bit-exact. */
+ *         sphere amplify any rounding difference) -- inside the 1e-4 relative bar, not bit-exact.
+ *         Two guards keep it there: a ray that orbits the hole (more steps than the longest straight path plus one
+ *         photon-sphere circumference; a few per million) is re-traced with STRICT arithmetic inside the same kernel,
+ *         and a frame whose stepSize exceeds 0.5 (the RK4 step no longer resolves the field next to the hole) is
+ *         traced in STRICT altogether.  The reference's default stepSize is 0.3. */
 enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
 
 /* Replaces the `Config` argument of render (src/ConfigFile.hs:16-38), AS PARSED: radii un-squared,

@@ -61,4 +61,5 @@ for i in range(N):
     if (bad or f) and len(out["bad"]) < 5:
         out["bad"].append(dict(index=i, cfg=cfg, outside=bad, strict=(sa["horizon"], sa["escaped"], sa["capped"], sa["steps"]),
                                fast=(sb["horizon"], sb["escaped"], sb["capped"], sb["steps"])))
+out["fast_guard"] = os.environ.get("BLACKSTAR_FAST_GUARD", "1")
 print(json.dumps(out))

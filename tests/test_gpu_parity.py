@@ -1017,3 +1017,53 @@ def test_disk_inner_edge_matches_the_reference_repositorys_example_image(mode, t
     o2 = disk_inner_edge_offsets_vs_reference_example(bad)
     e2 = o2[o2[:, 1] > 122]
     assert not (len(e2) >= 120 and -0.5 < e2[:, 2].mean() < 2.2 and e2[:, 2].std() < 2.0)  # a 10 % larger diskInner is rejected
+
+
+def test_fast_mode_retraces_photon_sphere_grazing_rays_in_strict(catalogue_bytes, monkeypatch):
+    """FAST's guard: a ray that takes more than N0 + 9 / stepSize steps (N0 = the longest straight path, one photon-sphere
+    circumference on top) has orbited the hole, where every orbit multiplies rounding differences by ~535; FAST recomputes it with
+    STRICT arithmetic.  With the guard those rays come out STRICT's to the bit; without it (BLACKSTAR_FAST_GUARD=0) they are where
+    FAST's largest deviations sit."""
+    cfg = scenes.DEFAULT_AA
+    cam = float(np.linalg.norm(cfg["cam_pos"]))
+    guard = int(np.ceil((cam + np.sqrt(max(2500.0, 2 * cam * cam))) / cfg["step_size"] + 9.0 / cfg["step_size"]))
+    stars = bs.read_map(catalogue_bytes)
+    t = bs.StarTree(stars, device=0)
+    monkeypatch.setenv("BLACKSTAR_FAST_GUARD", "0")
+    t_off = bs.StarTree(stars, device=0)
+    monkeypatch.delenv("BLACKSTAR_FAST_GUARD")
+    try:
+        # the photon ring: scan radially across the shadow edge, densely, to catch rays that circle the hole
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_c3.npz"))
+        rng = np.random.default_rng(3)
+        cx, cy = 2 * 1087.5, 2 * 514.5   # centre of the shadow of the default camera at 1920x1080, in traced pixels
+        th = rng.uniform(0, 2 * np.pi, 400000)
+        rad = rng.uniform(335.0, 350.0, 400000)  # the ring sits at ~114 px at 1280x720 -> 114 * 1.5 * 2 = 342 traced px
+        xs = np.clip(np.rint(cx + rad * np.cos(th)).astype(int), 0, 3839)
+        ys = np.clip(np.rint(cy + rad * np.sin(th)).astype(int), 0, 2159)
+        del g
+        t.set_mode(_lib.BS_MODE_STRICT)
+        strict = bs.trace_rays(cfg, t, ys, xs)
+        t.set_mode(_lib.BS_MODE_FAST)
+        fast = bs.trace_rays(cfg, t, ys, xs)
+        t_off.set_mode(_lib.BS_MODE_FAST)
+        raw = bs.trace_rays(cfg, t_off, ys, xs)
+        hot = strict["steps"] > guard
+        assert hot.sum() >= 20, f"only {hot.sum()} rays beyond {guard} steps in the sample (max {strict['steps'].max()})"
+        assert np.array_equal(fast["steps"], strict["steps"]) and np.array_equal(fast["fate"], strict["fate"])
+        # guarded rays: STRICT's terminal state and colour exactly
+        for k in ("vel", "pos", "rgba", "disk_hits", "star_hits"):
+            assert np.array_equal(fast[k][hot], strict[k][hot]), k
+        # the unguarded kernel differs on them (that is what the guard removes) and agrees with the guarded one elsewhere
+        assert not np.array_equal(raw["vel"][hot], strict["vel"][hot])
+        assert np.array_equal(raw["rgba"][~hot], fast["rgba"][~hot])
+        dev = lambda a: (np.abs(a["rgba"] - strict["rgba"]) / (np.abs(strict["rgba"]) + 1e-3)).max()
+        print(f"{hot.sum()} of {len(hot)} ring rays beyond {guard} steps; worst FAST deviation with guard {dev(fast):.2e}, without {dev(raw):.2e}")
+        assert dev(fast) <= dev(raw) and dev(fast) < 2e-6
+        # whole frames: identical statistics, every pixel inside the bar either way
+        small = scenes.with_res(cfg, 480, 270)
+        a, b = bs.render(small, t), bs.render(small, t_off)
+        assert (np.abs(a - b) <= ATOL_FAST + RTOL_FAST * np.abs(b)).all() and t.stats()["steps"] == t_off.stats()["steps"]
+    finally:
+        t.close()
+        t_off.close()
