@@ -34,13 +34,17 @@ def render_batch(cfgs: Sequence, trees: Sequence[StarTree], outs: Sequence[np.nd
     return outs
 
 
-def render_split(cfg, trees: Sequence[StarTree]) -> np.ndarray:
+def render_split(cfg, trees: Sequence[StarTree], out: np.ndarray = None) -> np.ndarray:
     """ONE frame over several StarTrees (one per GPU): tree k renders the k-th contiguous band of rows (`bs_render_split`).
-    Bit-identical to render(cfg, trees[0])."""
+    Bit-identical to render(cfg, trees[0]).  `out`: the (h, w, 3) float64 buffer to fill; a page-locked one (alloc_image) is
+    written by every GPU's kernel directly, each into its own band."""
     if not trees:
         raise ValueError("need at least one StarTree")
     c = _lib.make_config(cfg.to_bs_config() if isinstance(cfg, Config) else cfg)
-    out = np.empty((c.height, c.width, 3), np.float64)
+    if out is None:
+        out = np.empty((c.height, c.width, 3), np.float64)
+    elif out.shape != (c.height, c.width, 3) or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous float64 array of shape {(c.height, c.width, 3)}")
     ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
     _lib.check(_lib.lib().bs_render_split(ctxs, len(trees), C.byref(c), out.ctypes.data, out.size), "bs_render_split")
     return out

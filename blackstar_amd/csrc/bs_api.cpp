@@ -40,6 +40,7 @@ struct bs_ctx {
     int mode = BS_MODE_FAST;
     int max_steps = 100000;
     int disk_slots = 4;
+    bool zero_copy = true;       // page-locked caller buffers are written by the kernel itself (env BLACKSTAR_ZERO_COPY=0: always stage + copy)
     bool fast_guard = true;      // FAST mode re-traces photon-sphere-grazing rays in STRICT (env BLACKSTAR_FAST_GUARD=0 turns it off for A/B)
     int n_cu = 256;
     int blocks_per_cu = 4;       // resident workgroups per CU (VGPR/LDS-limited); env BLACKSTAR_BLOCKS_PER_CU for A/B builds
@@ -150,6 +151,27 @@ struct StreamDrain {
     }
 };
 
+// Zero copy: if a caller's HOST buffer is page-locked (bs_host_alloc, hipHostMalloc, hipHostRegister) the device can write it
+// directly over PCIe, so the kernel's own image stores deliver the frame -- no device image, no copy, and the transfer is
+// spread over the whole kernel instead of trailing it.  Measured (scripts/zero_copy_probe.py, profiles/r02_zero_copy.txt):
+// bs_render of the C3 frame 5.45 -> 4.57 ms (kernel 4.38), C2 2.14 -> 1.49 ms (49.8 MB in 1.47 ms = 34 GB/s while tracing), C4
+// 21.6 -> 18.7 ms; the kernel time itself does not change (11 GB/s average is far below what PCIe takes in 96-B segments).
+// Returns the device alias of `host`, or nullptr for pageable memory (which takes the staged path).  BLACKSTAR_ZERO_COPY=0: off.
+double *device_alias_of_pinned(const bs_ctx *ctx, const void *host, size_t bytes)
+{
+    if (!ctx->zero_copy || !host || bytes == 0) return nullptr;
+    hipPointerAttribute_t a, b;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer) {
+        (void)hipGetLastError();  // pageable memory is reported as an error: not one of ours
+        return nullptr;
+    }
+    if (hipPointerGetAttributes(&b, static_cast<const char *>(host) + bytes - 1) != hipSuccess || b.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();  // the buffer runs past the page-locked range
+        return nullptr;
+    }
+    return static_cast<double *>(a.devicePointer);
+}
+
 int ensure_scratch(bs_ctx *ctx, size_t bytes)
 {
     if (ctx->scratch_cap >= bytes) return BS_OK;
@@ -259,6 +281,7 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     ctx->n_stars = n_stars;
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
     if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
+    if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_MODE")) {
@@ -552,6 +575,14 @@ int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double
     size_t need = (size_t)cfg->width * (size_t)(row1 - row0) * 3;
     if (out_doubles < need) return fail(BS_EINVAL, "output buffer too small");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (double *alias = device_alias_of_pinned(ctx, out_rgb, need * sizeof(double))) {  // page-locked buffer: the kernel writes it
+        StreamDrain drain(ctx);
+        int rc = enqueue_render(ctx, cfg, alias, need, ctx->stream, row0, row1);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return BS_OK;
+    }
     if (ctx->img_cap < need) {
         if (ctx->d_img) (void)hipFree(ctx->d_img);
         ctx->d_img = nullptr;
@@ -559,7 +590,7 @@ int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double
         if (hipMalloc((void **)&ctx->d_img, need * sizeof(double)) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc image failed");
         ctx->img_cap = need;
     }
-    // Host delivery of a big image: the frame goes out as a few consecutive launches (sub-bands of rows) and the copy
+    // Host delivery of a big image into PAGEABLE memory: the frame goes out as a few consecutive launches (sub-bands of rows) and the copy
     // stream moves sub-band k to the caller while sub-band k+1 is being traced -- all but the last copy are hidden behind
     // the kernels (49.8 MB of f64 take about 1 ms to reach host memory that has been touched before, pinned or not).
     StreamDrain drain(ctx);  // no DMA into out_rgb may outlive this call, whichever way it returns
@@ -606,6 +637,32 @@ static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *c
     for (int i = first; i < n_frames; i += step) {
         if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
         need = std::max(need, (size_t)cfgs[i].width * cfgs[i].height * 3);
+    }
+    {   // every frame's buffer page-locked: the kernels write them directly, two frames in flight on two streams, no copies
+        std::vector<double *> alias;
+        bool all = true;
+        for (int i = first; i < n_frames && all; i += step) {
+            double *a = device_alias_of_pinned(ctx, outs[i], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double));
+            all = a != nullptr;
+            alias.push_back(a);
+        }
+        if (all) {
+            if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->ev_frame)
+                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+            StreamDrain drain(ctx);
+            int k = 0;
+            for (int i = first; i < n_frames; i += step, k++) {
+                if (k >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_frame[k & 1]));  // at most two frames in flight
+                int rc = enqueue_render(ctx, &cfgs[i], alias[k], (size_t)cfgs[i].width * cfgs[i].height * 3, cs[k & 1], 0, -1, true, true, /*quiet=*/true);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(ctx->ev_frame[k & 1], cs[k & 1]));
+            }
+            HIP_TRY(hipStreamSynchronize(cs[0]));
+            HIP_TRY(hipStreamSynchronize(cs[1]));
+            return BS_OK;
+        }
     }
     auto grow = [&](double *&buf, size_t &cap) {
         if (cap >= need) return true;

@@ -112,8 +112,11 @@ int bs_device_count(void);
 /* Replaces: render cfg tree (src/Raytracer.hs:53-67) at its only call site app/Main.hs:109.
  * Blocking.  Fills out_rgb[height*width*3], interleaved RGB f64, row-major (y down), linear light,
  * unclamped, already supersample-reduced -- the `Image S RGB Double` layout the Haskell shim wraps.
- * (A large frame is traced as two consecutive launches of half the rows each, so that the first half's copy to the host
- * overlaps the second half's kernel; pixels and bs_stats are those of the whole frame.) */
+ * If out_rgb is page-locked memory (bs_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) the kernel writes it
+ * directly over PCIe -- no device image and no copy: the call costs the kernel time (C3 frame: 4.6 ms).  Into pageable memory the
+ * frame is traced as two consecutive launches of half the rows each, so that the first half's copy to the host overlaps the
+ * second half's kernel (5.4 ms into a buffer that has been touched before, 9 ms into a fresh one: first-touch page faults).
+ * Pixels and bs_stats are those of the whole frame either way. */
 int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles);
 
 /* Same, but the image stays in HBM: d_out_rgb is a device pointer on the context's device, the work is
@@ -123,8 +126,9 @@ int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t 
 
 /* Page-locked host memory for images ("pinned buffers, no per-frame hipMalloc").  Any host pointer works
  * as an output buffer, but a FRESH pageable buffer costs the operating system's first-touch page faults on top of the copy
- * (measured for a 1080p f64 frame: 10.0 ms per bs_render into newly allocated memory, 5.2 ms into a buffer that is reused
- * or comes from here; kernel 4.6 ms).  Memory from bs_host_alloc never faults and is written by the copy engine directly.
+ * (measured for a 1080p f64 frame: 9.0 ms per bs_render into newly allocated memory, 5.4 ms into a pageable buffer that is
+ * reused, 4.6 ms into one from here; kernel 4.4 ms).  Memory from bs_host_alloc never faults and is written by the trace kernel
+ * itself (zero copy) in bs_render / bs_render_rows / bs_render_split / bs_render_batch.
  * It belongs to the caller until bs_host_free (it may outlive the context; Haskell: newForeignPtr with bs_host_free as
  * finalizer).  Returns NULL on failure. */
 void *bs_host_alloc(bs_ctx *ctx, size_t bytes);

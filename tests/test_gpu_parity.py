@@ -1067,3 +1067,56 @@ def test_fast_mode_retraces_photon_sphere_grazing_rays_in_strict(catalogue_bytes
     finally:
         t.close()
         t_off.close()
+
+
+def test_zero_copy_delivery_into_page_locked_buffers(tree, catalogue_bytes, monkeypatch):
+    """A page-locked output buffer (bs_host_alloc) is written by the trace kernel itself -- in bs_render, in the middle of a
+    buffer (bs_render_rows / bs_render_split hand out interior pointers), and in bs_render_batch -- with the same pixels and
+    statistics as the staged path (pageable buffers, or BLACKSTAR_ZERO_COPY=0), including a batch that mixes both kinds."""
+    L = _lib.lib()
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 320, 181)
+    tree.set_mode(_lib.BS_MODE_FAST)
+    monkeypatch.setenv("BLACKSTAR_ZERO_COPY", "0")
+    staged_tree = bs.StarTree(bs.read_map(catalogue_bytes), device=0)
+    monkeypatch.delenv("BLACKSTAR_ZERO_COPY")
+    staged_tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        ref = bs.render(cfg, tree)                      # pageable -> staged
+        st_ref = tree.stats()
+        pinned = bs.alloc_image(tree, 181, 320)
+        pinned[:] = -3.0
+        assert np.array_equal(bs.render(cfg, tree, out=pinned), ref)   # zero copy
+        st = tree.stats()
+        assert {k: st[k] for k in ("rays", "steps", "horizon", "escaped", "disk_hits", "star_hits")} == \
+               {k: st_ref[k] for k in ("rays", "steps", "horizon", "escaped", "disk_hits", "star_hits")}
+        pinned[:] = -3.0
+        assert np.array_equal(bs.render(cfg, staged_tree, out=pinned), ref)   # same buffer, zero copy switched off
+        # a band into the MIDDLE of a page-locked buffer: interior pointer, neighbours untouched
+        big = bs.alloc_image(tree, 3 * 181, 320)
+        big[:] = -5.0
+        c = _lib.make_config(cfg)
+        band = big[181 + 40:181 + 100]
+        _lib.check(L.bs_render_rows(tree.handle, C.byref(c), 40, 100, band.ctypes.data, band.size), "bs_render_rows")
+        assert np.array_equal(band, ref[40:100]) and (big[:181 + 40] == -5.0).all() and (big[181 + 100:] == -5.0).all()
+        # one frame split over contexts, every band written in place
+        extra = [bs.StarTree(bs.read_map(catalogue_bytes), device=0) for _ in range(2)]
+        try:
+            for t in extra:
+                t.set_mode(_lib.BS_MODE_FAST)
+            pinned[:] = -3.0
+            assert np.array_equal(bs.render_split(cfg, [tree] + extra, out=pinned), ref)
+        finally:
+            for t in extra:
+                t.close()
+        # batches: all page-locked (two kernels in flight, no copies), and mixed with pageable buffers (staged for all)
+        cfgs = [scenes.with_res(scenes.ani_frame(i, 600), 200, 112) for i in (0, 150, 300, 450, 599)]
+        refs = [bs.render(c_, tree) for c_ in cfgs]
+        outs = [bs.alloc_image(tree, 112, 200) for _ in cfgs]
+        for got, want in zip(bs.render_batch(cfgs, [tree], outs=outs), refs):
+            assert np.array_equal(got, want)
+        mixed = [bs.alloc_image(tree, 112, 200) if i % 2 else np.empty((112, 200, 3)) for i in range(len(cfgs))]
+        for got, want in zip(bs.render_batch(cfgs, [tree], outs=mixed), refs):
+            assert np.array_equal(got, want)
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+        staged_tree.close()
