@@ -186,9 +186,11 @@ def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
                                              "bs_render into ONE pageable buffer reused across calls: kernel (two half-frame launches) + 49.8 MB staged D2H")
     res["bs_render_pageable"] = entry(med(lambda: bs.render(cfg, tree, out=np.empty((H, W, 3))), 3),
                                       "bs_render into a freshly allocated pageable buffer every call (first-touch page faults included)")
-    bs.render_rgb8(cfg_obj, tree)
-    res["bs_render_rgb8"] = entry(med(lambda: bs.render_rgb8(cfg_obj, tree), 5),
-                                  "render + bloom + sRGB8 on the device, 6.2 MB RGB8 D2H (doRender up to the PNG encoder), blocking")
+    pinned8 = bs.alloc_image(tree, H, W, dtype=np.uint8)
+    bs.render_rgb8(cfg_obj, tree, out=pinned8)
+    res["bs_render_rgb8"] = entry(med(lambda: bs.render_rgb8(cfg_obj, tree, out=pinned8), 5),
+                                  "render + bloom + sRGB8 on the device, 6.2 MB RGB8 written into a page-locked host buffer by the last kernel "
+                                  "(doRender up to the PNG encoder), blocking")
     # STRICT mode of the same frame, image resident in HBM like the headline
     tree.set_mode(_lib.BS_MODE_STRICT)
     try:

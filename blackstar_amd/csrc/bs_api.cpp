@@ -507,20 +507,23 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
         if (hipMalloc((void **)&ctx->d_u8, n) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc failed");
         ctx->u8_cap = n;
     }
+    // a page-locked out_rgb8 is written by the sRGB8 kernel itself (zero copy), otherwise staged through d_u8
+    unsigned char *u8_target = ctx->d_u8;
+    if (double *alias = device_alias_of_pinned(ctx, out_rgb8, n)) u8_target = reinterpret_cast<unsigned char *>(alias);
     StreamDrain drain(ctx);
     // doRender (app/Main.hs:105-123): render -> bloom if bloomStrength /= 0 -> writeImg's sRGB + toWord8, all in HBM
     rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
     if (rc) return rc;
     if (bloom_strength != 0) {  // bloom's final img + strength * blurred is fused with the sRGB8 map: the bloomed f64 image is never written
         if (bloom_divider <= 0 || cfg->width / bloom_divider == 0) return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
-        if (bs::launch_bloom_srgb8(ctx->d_post[2], ctx->d_u8, ctx->d_post[0], ctx->d_post[1], cfg->width, cfg->height, bloom_strength, bloom_divider,
+        if (bs::launch_bloom_srgb8(ctx->d_post[2], u8_target, ctx->d_post[0], ctx->d_post[1], cfg->width, cfg->height, bloom_strength, bloom_divider,
                                    ctx->n_cu, ctx->d_srgb_table, ctx->stream))
             return fail(BS_EDEVICE, "bloom launch failed");
     } else {
-        rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n, ctx->stream);
+        rc = bs_srgb8_device(ctx, ctx->d_post[2], u8_target, n, ctx->stream);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (u8_target == ctx->d_u8) HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BS_OK;

@@ -73,11 +73,15 @@ def render_device(cfg, startree: StarTree, d_out_ptr: int, out_doubles: int, str
     _lib.check(_lib.lib().bs_render_device(startree.handle, C.byref(c), d_out_ptr, out_doubles, stream_ptr or None), "bs_render_device")
 
 
-def render_rgb8(cfg: Config, startree: StarTree) -> np.ndarray:
+def render_rgb8(cfg: Config, startree: StarTree, out: np.ndarray = None) -> np.ndarray:
     """doRender's pipeline (app/Main.hs:105-123) on the device: render, bloom if scene.bloomStrength /= 0, sRGB + 8-bit.
-    Returns (h, w, 3) uint8 -- what writeImg hands to the PNG encoder."""
+    Returns (h, w, 3) uint8 -- what writeImg hands to the PNG encoder.  `out`: the buffer to fill (e.g. alloc_image(tree, h, w,
+    dtype=np.uint8): page-locked, written by the last kernel directly)."""
     c = _bs_config(cfg)
-    out = np.empty((c.height, c.width, 3), np.uint8)
+    if out is None:
+        out = np.empty((c.height, c.width, 3), np.uint8)
+    elif out.shape != (c.height, c.width, 3) or out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous uint8 array of shape {(c.height, c.width, 3)}")
     _lib.check(_lib.lib().bs_render_rgb8(startree.handle, C.byref(c), float(cfg.scene.bloomStrength), int(cfg.scene.bloomDivider),
                                          out.ctypes.data, out.size), "bs_render_rgb8")
     return out

@@ -354,8 +354,11 @@ def test_render_rgb8_pipeline(tree, oracle, tmp_path):
     exp = oracle.srgb8(oracle.bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img))
     assert np.array_equal(got, exp)  # bloom bit-exact, fused combine + threshold-table sRGB8 exact
     assert got.max() > 100 and got.shape == (90, 160, 3)
+    pinned8 = bs.alloc_image(tree, 90, 160, dtype=np.uint8)  # page-locked: the last kernel writes it directly
+    assert np.array_equal(bs.render_rgb8(cfg, tree, out=pinned8), exp)
     cfg.scene.bloomStrength = 0.0  # no bloom branch
     assert np.array_equal(bs.render_rgb8(cfg, tree), oracle.srgb8(img))
+    assert np.array_equal(bs.render_rgb8(cfg, tree, out=pinned8), oracle.srgb8(img))
     bs.write_png(got, str(tmp_path / "o.png"))
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png")), got)
