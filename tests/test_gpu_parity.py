@@ -1123,3 +1123,21 @@ def test_zero_copy_delivery_into_page_locked_buffers(tree, catalogue_bytes, monk
     finally:
         tree.set_mode(_lib.BS_MODE_STRICT)
         staged_tree.close()
+
+
+def test_bloom_randomised_shapes_bit_exact(tree, oracle):
+    """Seeded fuzz of the box-blur paths: 48 random sizes (even and odd, up to 1500 x 900) and dividers (radius 1 .. width),
+    bright-pixel images; every result bit-identical to the oracle.  Plus the 4K frame (r = 153: the ring no longer fits one
+    workgroup per CU, several rounds of workgroups) and 8K x 96 (r = 307)."""
+    rng = np.random.default_rng(20260928)
+    shapes = [(int(rng.integers(2, 1500)), int(rng.integers(2, 900))) for _ in range(48)]
+    shapes = [(w & ~1, h & ~1) if i % 3 else (w, h) for i, (w, h) in enumerate(shapes)]   # two thirds even x even (the LDS-DMA path)
+    shapes = [(max(w, 2), max(h, 2)) for w, h in shapes] + [(3840, 2160), (7680, 96)]
+    for w, h in shapes:
+        div = int(rng.integers(1, max(2, min(w, 60))))
+        if w >= 3840:
+            div = 25
+        img = rng.uniform(0, 3, (h, w, 3)) * (rng.uniform(0, 1, (h, w, 1)) < 0.1)
+        got = bs.bloom(0.4, div, img, tree)
+        ref = oracle.bloom(0.4, div, img)
+        assert np.array_equal(got, ref), f"{w}x{h} divider {div} (r = {w // div}): {(got != ref).sum()} values differ, max {np.abs(got - ref).max():.3e}"
