@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
 // the slots of chunks that died with phase k-1 (ring of S = 3 (1 + Dp) + 2 Lr slots), then waits for batch k+1.
 constexpr int kDmaChunk = 1024;      // bytes per global_load_lds_dwordx4 wave-instruction
 constexpr int kDmaPhaseRows = 128;   // 128 rows x 24 B = 3 chunks
-constexpr int kDmaLds = 152 * 1024;  // static LDS of the kernel (of 160 KiB per CU)
+constexpr int kDmaLds = 152 * 1024;  // static LDS of the sweep kernel (of 160 KiB per CU): one workgroup per CU, and the plan's budget
 constexpr int kDmaMaxPx = 21;        // 63 chains = one consumer wavefront
 
 struct SweepPlan {
@@ -247,6 +247,7 @@ struct SweepPlan {
     int stride;   // bytes between the rings of two pixels: (S + 1) * 1024 + 32 (the 32 skews the banks of neighbouring pixels)
     int groups;   // ceil(P / px)
     int per_xcd;  // ceil(groups / 8); grid = 8 * per_xcd
+    int lds_bytes;  // LDS the plan needs: rings + hand-off tiles (<= kDmaLds, the kernel's static allocation)
 #ifdef BS_SWEEP_PROBE  // scripts/sweep_probe.hip only: switch parts of the kernel off, report shader / wall clocks of workgroup 0
     int dbg;                     // chain variants: 1 = no tile writes, 2 = no ring reads, 3 = neither
     unsigned long long *clocks;  // per wavefront of group 0: [2w] shader clocks spent working, [2w+1] in the block loop
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void bloom_combine_srgb8(const double *__restr
 // Geometry of the LDS-DMA sweep for P chain-pixels of n rows, window r, on a chip of n_cu CUs; false = not applicable.
 // single_round: only accept a plan whose workgroups all run at once (one per CU) -- with the LDS this kernel takes, a second
 // round of workgroups costs a whole extra sweep time.
-static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepPlan &pl, bool single_round)
+static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepPlan &pl, bool single_round, int lds_budget = kDmaLds)
 {
     if ((n & 1) || r < 1 || P < 1) return false;  // every chain-pixel's run must start 16-B aligned: n * 24 B a multiple of 16
     if (reinterpret_cast<uintptr_t>(in) & 15) return false;
@@ -624,11 +625,11 @@ static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepP
     const int px0 = std::max(1, std::min(kDmaMaxPx, (P + n_cu - 1) / n_cu));
     int px = 0, dp = 0;
     for (int d : {3, 2, 1}) {  // the px that covers the chip with one round of workgroups, as deep a prefetch as the LDS allows
-        if ((long)px0 * (stride_of(d) + tile_bytes) <= kDmaLds) { px = px0; dp = d; break; }
+        if ((long)px0 * (stride_of(d) + tile_bytes) <= lds_budget) { px = px0; dp = d; break; }
     }
     if (!px && !single_round) {  // fewer pixels per workgroup: more workgroups than CUs
         for (int d : {2, 1}) {
-            const int fit = (int)(kDmaLds / (stride_of(d) + tile_bytes));
+            const int fit = (int)(lds_budget / (stride_of(d) + tile_bytes));
             if (fit >= 1) { px = std::min(px0, fit); dp = d; break; }
         }
     }
@@ -640,6 +641,7 @@ static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepP
     pl.stride = stride_of(dp);
     pl.groups = (P + px - 1) / px;
     pl.per_xcd = (pl.groups + 7) / 8;
+    pl.lds_bytes = px * (pl.stride + tile_bytes);
     return !single_round || pl.groups <= n_cu;
 }
 
@@ -666,6 +668,7 @@ static void blur_passes(const double *src, double *d_a, double *d_b, int w, int 
     const dim3 tgrid_wh((unsigned)((h + 31) / 32), (unsigned)((w + 31) / 32));  // transposing a  w x h image
     const int path = bloom_path();
     const bool lds_fits = 2 * r + 2 * kLT <= kLR;
+
     for (int pass = 0; pass < 3; pass++) {
         SweepPlan ph, pv;
         bool dma = false;
