@@ -284,3 +284,22 @@ def test_srgb8_threshold_table_is_the_oracles_pixel_map(oracle):
     b = oracle.srgb8(x)
     assert (np.diff(b.astype(int)) >= 0).all()
     assert np.array_equal(b, (np.searchsorted(T[1:256], x, side="right")).astype(np.uint8))
+
+
+def test_bench_cli_contract_without_a_gpu():
+    """bench.py: the flags the driver passes exist, N > 1 without a launcher is accepted (self-launching), and on a box
+    without a HIP device every form fails loudly instead of falling back to anything."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--launcher", "--gather", "--mode", "--workload"):
+        assert flag in out.stdout
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the no-device behaviour cannot be observed here")
+    for args in (["--steps", "1", "--warmup", "0"], ["--gpus", "2", "--steps", "1", "--warmup", "0"]):
+        r = subprocess.run([sys.executable, bench] + args, capture_output=True, text=True, timeout=300,
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout) and "{" not in r.stdout
