@@ -1,16 +1,18 @@
 // post_kernels.hip -- the two steps that follow render in the reference's doRender (app/Main.hs:113-123):
 //   bloom / boxBlur   src/ImageFilters.hs:28-86     
 //   sRGB + toWord8    src/Raytracer.hs:23-32        
-// Both are HBM-bound byte/float streaming, kept on the device so a frame can leave the GPU as 6.2 MB of RGB8
-// instead of 49.8 MB of f64.
+// Both are kept on the device so a frame can leave the GPU as 6.2 MB of RGB8 instead of 49.8 MB of f64.
 //
 // boxBlur is a RUNNING sum in the reference -- S <- (S + pix(x+r)) - pix(x-r), out = S/(2r+1) -- so each
 // row (column) is a sequential floating-point chain; reproducing its bits means walking it in order.  The
 // parallelism is across chains: one lane per (row, channel) for the horizontal sweep, one per (column,
-// channel) for the vertical one.  Both run as a sweep along the slow axis of a row-major array (the
-// horizontal one on a transposed copy) so that adjacent lanes touch adjacent doubles.  Quirks preserved: the window is [x-r+1, x+r] (2r
+// channel) for the vertical one.  Quirks preserved: the window is [x-r+1, x+r] (2r
 // samples) but the normalisation is 1/(2r+1); out-of-range pixels read as 0; each pass is H then V with V
 // reading the H result; 3 passes.
+// Three implementations of one sweep, all bit-exact (blur_passes picks): box_blur_sweep_dma (the default: LDS-DMA loader,
+// a chain wavefront, four store wavefronts -- see its header for the measurements that shaped it), box_blur_sweep_lds (round 1:
+// register-staged LDS ring; takes the sizes whose chain runs are not 16-byte aligned) and box_blur_sweep between two
+// transposes (any size).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(64) void box_blur_sweep(const double *__restrict__ 
     }
 }
 
-// LDS-staged variant of the same sweep (used whenever the window fits): one workgroup owns kLC adjacent chains.
+// LDS-staged variant of the same sweep (round 1; now the path for odd dimensions, windows up to r = 192): one workgroup owns kLC adjacent chains.
 // Its INPUT is chain-major -- in[(p * n + row) * 3 + c] for chain (pixel p, channel c) -- and its OUTPUT row-major --
 // out[(row * P + p) * 3 + c]: the horizontal sweep reads the image as it is (p = y, row = x) and writes it transposed,
 // the vertical sweep reads that (p = x, row = y) and writes the image layout back, so no transpose kernels are needed:
@@ -77,7 +79,6 @@ __global__ __launch_bounds__(64) void box_blur_sweep(const double *__restrict__ 
 constexpr int kLP = 11;    // pixels (chain triples) per workgroup
 constexpr int kLC = 3 * kLP;  // 33 chains per workgroup: whole RGB pixels; odd row stride in the ring
 constexpr int kLT = 64;    // rows per tile
-static_assert(true, "");
 constexpr int kLR = 512;   // ring rows (power of two): 512 * 33 * 8 B = 132 KiB of LDS -> supports r <= (512 - 128) / 2 = 192
 
 __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restrict__ in, double *__restrict__ out, int chains, int n, int r, double norm)
