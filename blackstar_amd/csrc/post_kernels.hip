@@ -266,6 +266,14 @@ __device__ __forceinline__ void dma_1k(const unsigned char *g, const unsigned ch
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory");
 }
 
+// The same with the global address as a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: a loader that walks
+// chunks and pixels then needs only scalar arithmetic per wave-instruction (about 7 SALU + the DMA itself).
+__device__ __forceinline__ void dma_1k_uniform(const unsigned char *base_uniform, unsigned lane_off, const unsigned char *l)
+{
+    const unsigned lds_addr = (unsigned)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char *)l);
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(base_uniform), "v"(lane_off), "s"(lds_addr) : "memory");
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt_le(int n)
 {
@@ -511,6 +519,292 @@ __global__ __launch_bounds__(kSweepThreads) void box_blur_sweep_dma(const double
 #endif
 }
 
+// ---- rotating version: THREE chain wavefronts take turns (the default path) -------------------------------------------
+// In the six-wavefront kernel the chain wavefront still spends 54-58 clocks per row, of which only 21 are the two dependent adds;
+// the rest is its own LDS traffic (operand reads 17, result writes 15), which a lone in-order wavefront cannot overlap with
+// the adds.  But the chain only hands ONE number per lane from row to row.  So three wavefronts take turns, block by block (32
+// rows): in interval j the wavefront j mod 3 does nothing but the 64 dependent adds of block j -- operands already in its
+// registers, each result kept in the register of the leading sample it consumed, S taken from and returned to a 512-byte LDS
+// slot -- while the other two do their LDS work off the critical path: the one that finished block j-1 writes its 32 results
+// to the hand-off tile and fetches the first operands of block j+2, the one that finished block j-2 fetches the rest of the
+// operands of block j+1.  Critical path per row: the adds plus 1/32 of a barrier and of an LDS round trip for S (measured:
+// 26 clocks per row inside the compute intervals).
+//   waves 0-2 CHAIN (rotating)   wave 3 LOADER (LDS-DMA)   waves 4-7 STORE (tile of block j-2 -> HBM in interval j)
+// A lone wavefront needs ~10 clocks per instruction of ANY kind, so an interval is as long as its busiest wavefront's
+// instruction count: the loader and the store wavefronts are written for few instructions (running chunk state and scalar
+// address arithmetic in the loader, per-lane constants hoisted out of the store loop).  Measured and rejected: no store
+// wavefronts, the chain wavefronts writing their rows to HBM in their off intervals (one wavefront per SIMD) -- 16 global stores
+// per interval cost more than the tile writes (287 vs 266 us for the bloom of a 1080p frame).
+constexpr int kChainWaves = 3;
+constexpr int kRotThreads = 64 * (kChainWaves + 1 + kStoreWaves);
+
+__global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *__restrict__ in, double *__restrict__ out, int P, int n, int r, double norm,
+                                                                   const SweepPlan pl)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kDmaLds];
+    asm volatile("" ::"s"(in), "s"(out), "s"(P), "s"(n), "s"(r), "s"(norm), "s"(pl.px), "s"(pl.S), "s"(pl.Dp), "s"(pl.Lr), "s"(pl.stride),
+                 "s"(pl.groups), "s"(pl.per_xcd));  // see box_blur_sweep_dma: no scalar load may stay pending on any role's path
+    const int g = (int)(blockIdx.x & 7u) * pl.per_xcd + (int)(blockIdx.x >> 3);  // XCD-contiguous ranges of chain groups
+    if (g >= pl.groups) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63u);
+    const int p0 = g * pl.px;
+    const int npx = (P - p0) < pl.px ? (P - p0) : pl.px;
+    const int S = pl.S, Dp = pl.Dp, Lr = pl.Lr, stride = pl.stride;
+    const long run_bytes = (long)n * 24;
+    const int nchunks = (int)((run_bytes + kDmaChunk - 1) / kDmaChunk);
+    const int blocks = (n + kBlkRows - 1) / kBlkRows;
+    const int tile_bytes = 3 * pl.px * kTileColBytes;        // one hand-off tile: [3 px chains][kBlkRows (+1 pad) rows]
+    unsigned char *tiles = lds + pl.px * stride;             // two of them behind the rings ...
+    double *s_hand = reinterpret_cast<double *>(tiles + 2 * tile_bytes);  // ... then the running sums in transit, one per chain
+
+    // ---- loader (wave 3): chunks are issued in increasing order, one call = the next chunk of every pixel of the group ----
+    const unsigned char *gin_u = reinterpret_cast<const unsigned char *>(in) + (long)p0 * run_bytes;  // wave-uniform: pixel p0, chunk 0
+    const long group_bytes = (long)(P - p0) * run_bytes;  // from gin_u to the end of the array
+    const unsigned lane16 = (unsigned)lane * 16u;
+    int ld_chunk = 0, ld_slot = 0;  // next chunk to issue and its ring slot
+    auto issue_next = [&]() -> int {
+        if (ld_chunk >= nchunks) return 0;
+        const unsigned char *gsrc = gin_u + (long)ld_chunk * kDmaChunk;
+        unsigned char *l = lds + ld_slot * kDmaChunk;
+        // only the LAST chunk of a run can reach past it (into the next pixels' rows, which nobody looks at) -- and past the end of
+        // the ARRAY there is nothing to read: `safe` pixels' chunks lie wholly inside it, the others are issued lane by lane
+        int safe = npx;
+        const long chunk_end = (long)(ld_chunk + 1) * kDmaChunk;
+        if (ld_chunk + 1 >= nchunks) {
+            const long fit = chunk_end <= group_bytes ? (group_bytes - chunk_end) / run_bytes + 1 : 0;
+            safe = fit < npx ? (int)fit : npx;
+        }
+        for (int m = 0; m < safe; m++, gsrc += run_bytes, l += stride) {
+            dma_1k_uniform(gsrc, lane16, l);
+            if (ld_slot == 0) dma_1k_uniform(gsrc, lane16, l + S * kDmaChunk);  // mirror of slot 0 behind the last slot
+        }
+        for (int m = safe; m < npx; m++, gsrc += run_bytes, l += stride) {  // lane 0 is in range, so the instruction issues
+            const long left = group_bytes - ((long)ld_chunk * kDmaChunk + (long)m * run_bytes);
+            if ((long)lane16 + 16 <= left) {
+                dma_1k(gsrc + lane16, l);
+                if (ld_slot == 0) dma_1k(gsrc + lane16, l + S * kDmaChunk);
+            }
+        }
+        const int cnt = ld_slot == 0 ? 2 * npx : npx;
+        ld_chunk++;
+        ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
+        return cnt;
+    };
+    int v0 = 0, v1 = 0, v2 = 0;  // wave-instruction counts of the batches in flight behind the one that is awaited next
+
+    // ---- chain (waves 0..2) ----
+    const int ncol = 3 * npx;
+    const bool active = lane < ncol;
+    const int lm = active ? lane / 3 : 0, lc = active ? lane - 3 * (lane / 3) : 0;
+    const unsigned char *lbase = lds + lm * stride + 8 * lc;
+    const unsigned ring = (unsigned)S * kDmaChunk;
+    // ring offsets of rows x + r and x - r for x = the first row of this wavefront's NEXT block to fetch (block `wave` at first)
+    unsigned offL = (unsigned)((24l * r + 24l * kBlkRows * wave) % ring);
+    unsigned offT = (unsigned)(((ring - (24l * r) % ring) + 24l * kBlkRows * wave) % ring);
+    const unsigned adv = (unsigned)((24l * kBlkRows * kChainWaves) % ring);
+    // operands of the block this wavefront computes next; after the compute L holds the block's RESULTS (each result takes the
+    // register of the leading sample it consumed) until they are written to the tile, one interval later
+    double L[kBlkRows], T[kBlkRows];
+    double s = 0.0;
+    auto fetch = [&](int u0, int u1) {  // operands of rows [u0, u1) of the block at (offL, offT)
+        const unsigned char *pL = lbase + offL, *pT = lbase + offT;
+#pragma unroll
+        for (int u = 0; u < kBlkRows; u++) {
+            if (u >= u0 && u < u1) {
+                L[u] = *reinterpret_cast<const double *>(pL + 24 * u);
+                T[u] = *reinterpret_cast<const double *>(pT + 24 * u);
+            }
+        }
+    };
+    auto advance = [&]() {
+        offL += adv; offL = offL >= ring ? offL - ring : offL;
+        offT += adv; offT = offT >= ring ? offT - ring : offT;
+    };
+
+    // ---- store (waves 4..7): 8 rows of every block each.  A lane takes TWO adjacent chains of one row (one ds_read2_b64, one
+    // 16-byte store), so a store instruction covers 64 / ceil(3 px / 2) rows: all 8 at px = 5, five at px = 8.  (One store
+    // wavefront for all 32 rows, the other three leaving their SIMDs to the chain wavefronts, was measured: 291 vs 226 us.) ----
+    constexpr int kRowsPerStore = kBlkRows / kStoreWaves;
+    const int cpairs = (ncol + 1) / 2;     // column pairs per row (the last one is a single column when 3 px is odd)
+    const int G = 64 / cpairs;             // rows one store instruction covers
+    const int rsub = lane / cpairs, cp = lane - rsub * cpairs;
+    const bool has2 = 2 * cp + 1 < ncol;   // this lane's second column exists
+    const size_t ostride = (size_t)P * 3;  // doubles between two output rows
+    const int mw = wave - (kChainWaves + 1);
+    const int row0 = kRowsPerStore * (mw > 0 ? mw : 0) + rsub;                                      // this lane's first row within a block
+    const int iters = (kRowsPerStore + G - 1) / G;                                    // store instructions per block (wave-uniform)
+    const int my_iters = rsub < G ? (kRowsPerStore - rsub + G - 1) / G : 0;           // ... in which this lane has a row
+    const unsigned tile_lane = (unsigned)(2 * cp * kTileColBytes + 8 * row0);         // this lane's first byte within a tile
+    const size_t step = (size_t)G * ostride;                                          // doubles between the rows of two store instructions
+    double *dst_blk = out + ((size_t)row0 * P + p0) * 3 + 2 * cp;                     // this lane's first output of block 0
+    struct __attribute__((packed, aligned(8))) Pair { double a, b; };                 // 16-byte store at 8-byte alignment
+
+    if (wave == kChainWaves) {
+        // batches 0 .. Dp-1 (batch p = what phase p needs beyond phase p-1: chunks [3p + Lr, 3p + 3 + Lr), batch 0 from chunk 0)
+        int c[3] = {0, 0, 0};
+        for (int p = 0; p < Dp; p++) {
+            int cnt = 0;
+            const int hi = 3 * p + 3 + Lr;
+            while (ld_chunk < hi && ld_chunk < nchunks) cnt += issue_next();
+            if (p >= 1) c[p - 1] = cnt;
+        }
+        v0 = c[0]; v1 = c[1]; v2 = c[2];
+        wait_vmcnt_le(v0 + v1 + v2);  // batch 0 has landed
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (wave < kChainWaves && active) {
+        if (wave == 0) {  // startVal = foldl1' add (pix <$> take r crds)   (ImageFilters.hs:59)
+            const int mr = r < n ? r : n;
+            s = *reinterpret_cast<const double *>(lbase);
+            int i = 1;
+            for (; i + 8 <= mr; i += 8) {
+                double t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = *reinterpret_cast<const double *>(lbase + 24 * (i + u));
+#pragma unroll
+                for (int u = 0; u < 8; u++) s = s + t8[u];
+            }
+            for (; i < mr; i++) s = s + *reinterpret_cast<const double *>(lbase + 24 * i);
+            s_hand[lane] = s;
+        }
+        if (wave < blocks) { fetch(0, kBlkRows); advance(); }  // blocks 0, 1, 2 lie in loader phase 0: landed
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // Interval `it` (it = 0 .. blocks + 1): chain wave it % 3 computes block it; STORE writes block it - 2; a raw barrier WITHOUT a
+    // memory fence closes the interval (only LDS -- rings, tiles, s_hand -- is handed over between the wavefronts; a fence would
+    // wait for the LDS-DMA batches in flight and for the stores).  Every wavefront executes exactly blocks + 2 of them.  The
+    // roles are separate straight-line loops, so that the 128 operand registers of a chain wavefront are updated in ONE
+    // sequence (a role switch inside a common loop made the register allocator spill them).
+    const int n_int = blocks + 2;
+#ifdef BS_SWEEP_PROBE
+    unsigned long long probe_work = 0, probe_start = __builtin_readcyclecounter();
+#define BS_INTERVAL_END()                                                  \
+    do {                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+        probe_work += __builtin_readcyclecounter() - probe_t;              \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+        probe_t = __builtin_readcyclecounter();                            \
+    } while (0)
+    unsigned long long probe_t = __builtin_readcyclecounter(), probe_compute = 0;
+#else
+#define BS_INTERVAL_END() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+    if (wave < kChainWaves) {
+        int it = 0;
+        for (; it < wave && it < n_int; it++) BS_INTERVAL_END();  // lead-in: this wavefront's first block is block `wave`
+        for (int b = wave; it < n_int; b += kChainWaves) {
+            // interval b: COMPUTE block b -- nothing but the chain
+            if (active && b < blocks) {
+                const int x0 = b * kBlkRows;
+                s = s_hand[lane];
+                if (x0 >= r && x0 + (kBlkRows - 1) + r < n) {
+#pragma unroll
+                    for (int u = 0; u < kBlkRows; u++) {
+                        s = (s + L[u]) - T[u];  // accumulate (ImageFilters.hs:61-64)
+                        L[u] = s;
+                    }
+                } else {  // image edges: out-of-range samples are black (ixh / ixv); rows past the end are computed but never stored
+#pragma unroll
+                    for (int u = 0; u < kBlkRows; u++) {
+                        const int x = x0 + u;
+                        const double lead = (x + r < n) ? L[u] : 0.0, trail = (x - r >= 0) ? T[u] : 0.0;
+                        s = (s + lead) - trail;
+                        L[u] = s;
+                    }
+                }
+                s_hand[lane] = s;
+            }
+#ifdef BS_SWEEP_PROBE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            probe_compute += __builtin_readcyclecounter() - probe_t;
+#endif
+            BS_INTERVAL_END();
+            if (++it >= n_int) break;
+            // interval b + 1: results of block b -> tile; the first operands of block b + 3
+            if (active) {
+                if (b < blocks) {
+                    unsigned char *tile = tiles + (b & 1) * tile_bytes + lane * kTileColBytes;
+#pragma unroll
+                    for (int u = 0; u < kBlkRows; u++) *reinterpret_cast<double *>(tile + 8 * u) = L[u];
+                }
+                if (b + kChainWaves < blocks) fetch(0, 8);
+            }
+            BS_INTERVAL_END();
+            if (++it >= n_int) break;
+            // interval b + 2: the rest of the operands of block b + 3
+            if (active && b + kChainWaves < blocks) { fetch(8, kBlkRows); advance(); }
+            BS_INTERVAL_END();
+            ++it;
+        }
+    } else if (wave == kChainWaves) {
+        // loader phase k = 4 intervals = 128 rows = 3 chunks per pixel.  The chain wavefronts fetch the operands of block b in
+        // intervals b - 2 and b - 1, so batch k+1 (what phase k+1 needs beyond phase k) has to have landed when interval
+        // 4k + 2 opens: interval 1 of the phase waits for it.  Batch k + Dp goes into the slots of chunks that died with phase k-1.
+        for (int it = 0; it < n_int; it++) {
+            const int q = it & 3;
+            int knew = 0;
+            if (Dp >= 2) {  // one chunk per interval (a burst would hold up the barrier): the batch is not needed for another phase
+                if (q < 3) knew = issue_next();
+            } else if (q == 0) {  // Dp = 1: batch k+1 itself, needed when interval 4k + 2 opens
+                knew = issue_next();
+                knew += issue_next();
+            } else if (q == 1) {
+                knew = issue_next();
+            }
+            if (Dp == 1) v0 += knew; else if (Dp == 2) v1 += knew; else v2 += knew;
+            if (q == 1) {
+                // everything older than the batches behind batch k+1 has landed.  With Dp >= 2 the newest batch is still being
+                // issued (its third chunk follows in interval 2): its count so far is exactly what is outstanding behind batch k+1.
+                wait_vmcnt_le(v1 + v2);
+                if (Dp == 1) v0 = 0;
+            }
+            if (q == 3 && Dp >= 2) { v0 = v1; v1 = v2; v2 = 0; }  // the phase's batch is complete: shift the window
+            BS_INTERVAL_END();
+        }
+    } else {
+        for (int it = 0; it < n_int; it++) {
+            if (it >= 2 && it - 2 < blocks) {  // STORE block it - 2
+                const int jm = it - 2;
+                const unsigned char *tp = tiles + (jm & 1) * tile_bytes + tile_lane;
+                double *dst = dst_blk;
+                int lim = my_iters;  // store instructions in which this lane has a row that exists
+                if ((jm + 1) * kBlkRows > n) {  // (wave-uniform) the image ends inside this block
+                    const int rows_left = n - jm * kBlkRows - row0;
+                    const int cap = rows_left <= 0 ? 0 : (rows_left + G - 1) / G;
+                    lim = lim < cap ? lim : cap;
+                }
+                for (int i = 0; i < iters; i++) {  // (lanes without a row read harmless bytes)
+                    const double va = *reinterpret_cast<const double *>(tp), vb = *reinterpret_cast<const double *>(tp + kTileColBytes);
+                    if (i < lim) {  // mul normFactor newRGB (ImageFilters.hs:62-63)
+                        if (has2) {
+                            Pair pr;
+                            pr.a = norm * va;
+                            pr.b = norm * vb;
+                            *reinterpret_cast<Pair *>(dst) = pr;
+                        } else {
+                            *dst = norm * va;
+                        }
+                    }
+                    tp += 8 * G;
+                    dst += step;
+                }
+                dst_blk += (size_t)kBlkRows * ostride;
+            }
+            BS_INTERVAL_END();
+        }
+    }
+#undef BS_INTERVAL_END
+#ifdef BS_SWEEP_PROBE
+    if (g == 0 && lane == 0 && pl.clocks) {  // per wavefront of group 0: clocks up to the barriers (chain: in COMPUTE intervals only) / in the loop
+        pl.clocks[2 * wave] = wave < kChainWaves ? probe_compute : probe_work;
+        pl.clocks[2 * wave + 1] = __builtin_readcyclecounter() - probe_start;
+    }
+#endif
+}
+
 // [rows][cols] pixels of 3 doubles -> [cols][rows]; 32x32-pixel tiles through LDS so both sides are coalesced.
 __global__ __launch_bounds__(256) void transpose_rgb(const double *__restrict__ in, double *__restrict__ out, int rows, int cols)
 {
@@ -656,6 +950,7 @@ static int bloom_path()
     const char *e = std::getenv("BLACKSTAR_BLOOM_PATH");
     if (!e) return 0;
     if (!std::strcmp(e, "dma")) return 3;
+    if (!std::strcmp(e, "rot")) return 4;
     if (!std::strcmp(e, "lds")) return 1;
     if (!std::strcmp(e, "direct")) return 2;
     return 0;
@@ -673,9 +968,14 @@ static void blur_passes(const double *src, double *d_a, double *d_b, int w, int 
     for (int pass = 0; pass < 3; pass++) {
         SweepPlan ph, pv;
         bool dma = false;
-        if (path == 0 || path == 3) dma = plan_dma_sweep(src, h, w, r, n_cu, ph, false) && plan_dma_sweep(d_a, w, h, r, n_cu, pv, false);
+        const bool rot = path == 0 || path == 4;  // three rotating chain wavefronts (default) / one chain wavefront ("dma")
+        if (path == 0 || path == 3 || path == 4)
+            dma = plan_dma_sweep(src, h, w, r, n_cu, ph, false, kDmaLds - 1024) && plan_dma_sweep(d_a, w, h, r, n_cu, pv, false, kDmaLds - 1024);
         // H: image layout (h x w) -> transposed layout (w x h); V: transposed -> image layout.  No transpose kernels.
-        if (dma) {
+        if (dma && rot) {
+            hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * ph.per_xcd)), dim3(kRotThreads), 0, s, src, d_a, h, w, r, norm, ph);
+            hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * pv.per_xcd)), dim3(kRotThreads), 0, s, (const double *)d_a, d_b, w, h, r, norm, pv);
+        } else if (dma) {
             hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * ph.per_xcd)), dim3(kSweepThreads), 0, s, src, d_a, h, w, r, norm, ph);
             hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * pv.per_xcd)), dim3(kSweepThreads), 0, s, (const double *)d_a, d_b, w, h, r, norm, pv);
         } else if (path != 2 && lds_fits) {

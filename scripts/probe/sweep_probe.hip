@@ -31,7 +31,30 @@ int main(int argc, char **argv)
     const double norm = 1.0 / (2 * r + 1);
     struct Sweep { const char *name; int P, n; } sweeps[2] = {{"H", h, w}, {"V", w, h}};
     for (const Sweep &sw : sweeps) {
-        {   // the four-wavefront kernel (the product path)
+        {   // the rotating three-chain-wavefront kernel (the product path)
+            SweepPlan p8;
+            if (plan_dma_sweep(a, sw.P, sw.n, r, n_cu, p8, false, kDmaLds - 1024)) {
+                p8.dbg = 0; p8.clocks = clk;
+                float best = 1e9f;
+                for (int it = 0; it < 6; it++) {
+                    CK(hipEventRecord(e0, nullptr));
+                    hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * p8.per_xcd)), dim3(kRotThreads), 0, nullptr, (const double *)a, b, sw.P, sw.n, r, norm, p8);
+                    CK(hipEventRecord(e1, nullptr));
+                    CK(hipEventSynchronize(e1));
+                    float ms = 0;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                unsigned long long c16[16];
+                CK(hipMemcpy(c16, clk, 128, hipMemcpyDeviceToHost));
+                for (int q = 8; q < 14; q++) c16[q] = 0;
+                std::printf("%s sweep rot: px=%d Dp=%d S=%d groups=%d: %.1f us (%.1f clk/row at 2.4 GHz)  work/loop clocks per row:", sw.name, p8.px, p8.Dp, p8.S, p8.groups,
+                            best * 1e3, best * 1e-3 * 2.4e9 / sw.n);
+                for (int wv = 0; wv < 8; wv++) std::printf(" w%d %.1f/%.1f", wv, (double)c16[2 * wv] / sw.n, (double)c16[2 * wv + 1] / sw.n);
+                std::printf("\n");
+            }
+        }
+        {   // the six-wavefront kernel
             SweepPlan p4;
             if (plan_dma_sweep(a, sw.P, sw.n, r, n_cu, p4, false)) {
                 for (int var : {0, 1, 2, 3}) {
