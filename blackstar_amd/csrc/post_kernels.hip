@@ -9,8 +9,8 @@
 // channel) for the vertical one.  Quirks preserved: the window is [x-r+1, x+r] (2r
 // samples) but the normalisation is 1/(2r+1); out-of-range pixels read as 0; each pass is H then V with V
 // reading the H result; 3 passes.
-// Three implementations of one sweep, all bit-exact (blur_passes picks): box_blur_sweep_dma (the default: LDS-DMA loader,
-// a chain wavefront, four store wavefronts -- see its header for the measurements that shaped it), box_blur_sweep_lds (round 1:
+// Three implementations of one sweep, all bit-exact (blur_passes picks): box_blur_sweep_rot (the default: LDS-DMA loader,
+// three chain wavefronts taking turns, four store wavefronts -- see its header for the measurements that shaped it), box_blur_sweep_lds (round 1:
 // register-staged LDS ring; takes the sizes whose chain runs are not 16-byte aligned) and box_blur_sweep between two
 // transposes (any size).
 #include <hip/hip_runtime.h>
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void box_blur_sweep_lds(const double *__restri
 //     straight into that pixel's LDS ring -- no VGPR staging, no ds_write pass, and the prefetch depth (Dp phases = Dp x 3 KiB
 //     per pixel, 48-72 KiB per workgroup) is limited by the ring, not by registers.  Counted `s_waitcnt vmcnt(N)` leaves the
 //     younger batches in flight across the block barriers (raw s_barrier: a fence would drain them).
-//   * The CHAIN wavefront: one lane per chain walks the reference's running sum S <- (S + pix(x+r)) - pix(x-r) in order
+//   * CHAIN wavefronts: one lane per chain walks the reference's running sum S <- (S + pix(x+r)) - pix(x-r) in order
 //     (bit-exact), operands from one ring offset + immediates (slot 0 of each ring is mirrored behind the last slot so a
 //     block never wraps).
 //   * blockIdx -> chain group is XCD-aware: workgroup b runs on XCD b % 8, and XCD x gets a CONTIGUOUS range of groups, so the
@@ -250,8 +250,8 @@ struct SweepPlan {
     int per_xcd;  // ceil(groups / 8); grid = 8 * per_xcd
     int lds_bytes;  // LDS the plan needs: rings + hand-off tiles (<= kDmaLds, the kernel's static allocation)
 #ifdef BS_SWEEP_PROBE  // scripts/sweep_probe.hip only: switch parts of the kernel off, report shader / wall clocks of workgroup 0
-    int dbg;                     // chain variants: 1 = no tile writes, 2 = no ring reads, 3 = neither
-    unsigned long long *clocks;  // per wavefront of group 0: [2w] shader clocks spent working, [2w+1] in the block loop
+    int dbg;                     // unused
+    unsigned long long *clocks;  // per wavefront of group 0: [2w] shader clocks (chain: in compute intervals; others: up to the barriers), [2w+1] in the loop
 #endif
 };
 
@@ -288,239 +288,23 @@ __device__ __forceinline__ void wait_vmcnt_le(int n)
 #undef BS_W
 }
 
-// ---- six-wavefront version: the chain wavefront does NOTHING but the chain (the default path) ---------------------------
-// Measured on the two-wavefront kernel above (scripts/probe/sweep_probe.hip -> profiles/r02_sweep_probe.txt): the loader alone
-// streams a sweep in 20-24 us, but the consumer needs ~95 shader clocks per row.  A LONE wavefront on a SIMD is slow at
-// everything: a dependent v_add_f64 issues every ~10-11 clocks (two per row: 22), an LDS instruction holds its issue slot for
-// ~10-20 clocks, a global store for ~20 (64 lanes x 16 B of address + data), and the scalar loop control around them is not
-// free either -- and none of it can be hidden behind another wavefront, because the chain IS one wavefront per group of chains
-// and its time is rows x clocks-per-row whatever the lane count.  So everything that is not the chain is moved off that
-// wavefront:
-//   wave 0  CHAIN   reads its operands from the rings, runs S <- (S + lead) - trail, writes S to an LDS tile: 1 ds_read2_b64 +
-//                   2 v_add_f64 + 1/2 ds_write2_b64 per row, straight-line code for 32 rows, operands fetched 8 rows ahead
-//   wave 1  LOADER  LDS-DMA as above, its issue spread over the blocks of a phase (a burst would hold up the block barrier)
-//   waves 2-5 STORE take the tile of the PREVIOUS 32 rows (8 rows each), multiply by the normalisation (mul normFactor) and
-//                   write it to HBM with all 64 lanes: 64 / (3 px) rows per store instruction
-// One raw barrier per 32 rows.  Forcing the LDS instructions into the latency bubbles between the dependent adds
-// (__builtin_amdgcn_sched_group_barrier) was measured and is SLOWER (58 vs 48 clocks per row): clustered LDS instructions of a
-// lone wavefront pipeline, isolated ones each pay their full issue latency.
-constexpr int kBlkRows = 32;      // rows per CHAIN -> STORE hand-off; 4 blocks per loader phase
-constexpr int kStoreWaves = 4;    // STORE wavefronts, kBlkRows / kStoreWaves rows of the tile each
-constexpr int kSweepThreads = 64 * (2 + kStoreWaves);
+// ---- what a LONE wavefront costs (the measurements that shaped the kernel below) ---------------------------------------
+// scripts/probe/sweep_probe.hip -> profiles/r02_sweep_probe*.txt, on intermediate versions of this kernel: the loader alone
+// streams a sweep in 20-24 us, but a lone wavefront on a SIMD is slow at everything: a dependent v_add_f64 issues every ~10.5
+// clocks (two per row: 21), an LDS instruction holds its issue slot for ~10-20 clocks (operand reads 17 per row, result
+// writes 15), a global store for ~20 (64 lanes x 16 B of address + data), scalar loop control is not free either -- and none
+// of it can be hidden behind another wavefront, because a chain IS one lane of one wavefront and its time is rows x clocks per
+// row whatever the lane count.  Versions and their chain-wavefront clocks per row: consumer doing everything (round-1
+// structure, and a first LDS-DMA version) 92-98; chain wavefront + store wavefronts 54-58; forcing the LDS instructions into the
+// add latency bubbles with sched_group_barrier 58 (worse than the compiler's clustering, 48: isolated LDS instructions of a lone
+// wavefront do not pipeline); three rotating chain wavefronts (below) 26 inside the compute intervals.
+constexpr int kBlkRows = 32;      // rows per block: the unit the chain wavefronts take turns on; 4 blocks per loader phase
+constexpr int kStoreWaves = 4;    // STORE wavefronts, kBlkRows / kStoreWaves rows of a block each
 constexpr int kTileColBytes = (kBlkRows + 1) * 8;  // hand-off tile: [chain][row], 33 doubles per chain (odd: conflict-free both ways)
 static_assert(kDmaPhaseRows == 4 * kBlkRows && kDmaPhaseRows * 24 == 3 * kDmaChunk, "a loader phase is 4 blocks = 3 chunks per pixel");
 
-// One block of 32 rows of the CHAIN wavefront, straight-line, four batches of 8 rows.  la/ta hold the operands (leading /
-// trailing samples) of the block's rows 0..7 on entry; with NEXT they hold those of the NEXT block's rows 0..7 on exit.
-template <bool EDGE, bool NEXT, int PROBE = 0>  // PROBE (scripts/probe only): 1 = no tile writes, 2 = no ring reads, 3 = neither
-__device__ __forceinline__ void chain_block(const unsigned char *pL, const unsigned char *pT, unsigned char *tile, int x0, int r, int n, double &s,
-                                            double (&la)[8], double (&ta)[8])
-{
-    double lb[8], tb[8];
-    auto batch = [&](const double(&l)[8], const double(&t)[8], double(&nl)[8], double(&nt)[8], int b, bool load_next) {
-        if (load_next && !(PROBE & 2)) {  // the next batch's 16 operands: 8 ds_read2_b64 in one cluster, consumed 8 rows later
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                nl[u] = *reinterpret_cast<const double *>(pL + 24 * (8 * (b + 1) + u));
-                nt[u] = *reinterpret_cast<const double *>(pT + 24 * (8 * (b + 1) + u));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            double lead = l[u], trail = t[u];
-            if (EDGE) {  // image edges: out-of-range samples are black (ixh / ixv); rows past the end are computed but never stored
-                const int x = x0 + 8 * b + u;
-                lead = (x + r < n) ? lead : 0.0;
-                trail = (x - r >= 0) ? trail : 0.0;
-            }
-            s = (s + lead) - trail;  // accumulate (ImageFilters.hs:61-64)
-            if (!(PROBE & 1)) *reinterpret_cast<double *>(tile + 8 * (8 * b + u)) = s;
-        }
-    };
-    batch(la, ta, lb, tb, 0, true);
-    batch(lb, tb, la, ta, 1, true);
-    batch(la, ta, lb, tb, 2, true);
-    batch(lb, tb, la, ta, 3, NEXT);
-}
-
-__global__ __launch_bounds__(kSweepThreads) void box_blur_sweep_dma(const double *__restrict__ in, double *__restrict__ out, int P, int n, int r, double norm,
-                                                                      const SweepPlan pl)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kDmaLds];
-    const int g = (int)(blockIdx.x & 7u) * pl.per_xcd + (int)(blockIdx.x >> 3);  // XCD-contiguous ranges of chain groups
-    if (g >= pl.groups) return;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = (int)(threadIdx.x & 63u);
-    const int p0 = g * pl.px;
-    const int npx = (P - p0) < pl.px ? (P - p0) : pl.px;
-    const int S = pl.S, Dp = pl.Dp, Lr = pl.Lr, stride = pl.stride;
-    const long run_bytes = (long)n * 24;
-    const int nchunks = (int)((run_bytes + kDmaChunk - 1) / kDmaChunk);
-    const int blocks = (n + kBlkRows - 1) / kBlkRows;
-    const int tile_bytes = 3 * pl.px * kTileColBytes;   // one hand-off tile: [3 px chains][kBlkRows (+1 pad) rows]
-    unsigned char *tiles = lds + pl.px * stride;        // two of them behind the rings
-
-    // ---- loader (wave 1) ----
-    const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (long)p0 * run_bytes + lane * 16;  // lane's 16 B of pixel p0's chunk 0
-    const long bytes_left = (long)(P - p0) * run_bytes - lane * 16;  // from gin to the end of the array
-    int v0 = 0, v1 = 0, v2 = 0;  // wave-instruction counts of the batches in flight behind the one that is awaited next
-    auto issue = [&](int c_lo, int c_hi) -> int {  // chunks [c_lo, c_hi) of every pixel of the group
-        int cnt = 0;
-        if (c_hi > nchunks) c_hi = nchunks;
-        for (int j = c_lo; j < c_hi; j++) {
-            const int slot = j % S;
-            long off = (long)j * kDmaChunk;
-            unsigned char *l = lds + slot * kDmaChunk;
-            for (int m = 0; m < npx; m++, off += run_bytes, l += stride) {
-                // lanes past the end of the ARRAY stay out (the last pixel's last chunk); lanes past the end of this pixel's run
-                // read the next pixel's first rows, which nobody looks at.  Lane 0 is always in range, so the instruction issues.
-                if (off + 16 <= bytes_left) {
-                    dma_1k(gin + off, l);
-                    if (slot == 0) dma_1k(gin + off, l + S * kDmaChunk);  // mirror of slot 0 behind the last slot
-                }
-            }
-            cnt += slot == 0 ? 2 * npx : npx;
-        }
-        return cnt;
-    };
-    auto batch_lo = [&](int p) { return p == 0 ? 0 : 3 * p + Lr; };
-
-    // ---- chain (wave 0) ----
-    const int ncol = 3 * npx;
-    const bool active = lane < ncol;
-    const int lm = active ? lane / 3 : 0, lc = active ? lane - 3 * (lane / 3) : 0;
-    const unsigned char *lbase = lds + lm * stride + 8 * lc;
-    const unsigned ring = (unsigned)S * kDmaChunk;
-    unsigned offL = (unsigned)((24l * r) % ring);                  // ring offset of row x + r, x = 0
-    unsigned offT = (unsigned)((ring - (24l * r) % ring) % ring);  // ring offset of row x - r, x = 0
-    double s = 0.0;
-
-    // ---- store (waves 2 .. 2 + kStoreWaves - 1) ----
-    constexpr int kRowsPerStore = kBlkRows / kStoreWaves;
-    const int G = 64 / ncol;                       // rows one store instruction covers
-    const int rsub = lane / ncol, col = lane - rsub * ncol;
-    const bool lane_ok = rsub < G;
-    const size_t ostride = (size_t)P * 3;          // doubles between two output rows
-
-    if (wave == 1) {
-        int c[3] = {0, 0, 0};
-        for (int p = 0; p < Dp; p++) {
-            const int k = issue(batch_lo(p), batch_lo(p + 1));
-            if (p >= 1) c[p - 1] = k;
-        }
-        v0 = c[0]; v1 = c[1]; v2 = c[2];
-        wait_vmcnt_le(v0 + v1 + v2);  // batch 0 has landed
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-    double la[8], ta[8];  // CHAIN: operands of the next 8 rows
-    if (wave == 0 && active) {  // startVal = foldl1' add (pix <$> take r crds)   (ImageFilters.hs:59)
-        const int mr = r < n ? r : n;
-        s = *reinterpret_cast<const double *>(lbase);
-        int i = 1;
-        for (; i + 8 <= mr; i += 8) {
-            double t8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) t8[u] = *reinterpret_cast<const double *>(lbase + 24 * (i + u));
-#pragma unroll
-            for (int u = 0; u < 8; u++) s = s + t8[u];
-        }
-        for (; i < mr; i++) s = s + *reinterpret_cast<const double *>(lbase + 24 * i);
-    }
-#ifdef BS_SWEEP_PROBE
-    unsigned long long probe_work = 0, probe_start = __builtin_readcyclecounter();
-#endif
-    // iteration j: CHAIN computes block j into tile j & 1, STORE writes block j - 1 from tile (j - 1) & 1
-    for (int j = 0; j <= blocks; j++) {
-#ifdef BS_SWEEP_PROBE
-        const unsigned long long probe_t = __builtin_readcyclecounter();
-#endif
-        if (wave == 0) {
-            if (j < blocks) {
-                if (active) {
-                    const int x0 = j * kBlkRows;
-                    const unsigned char *pL = lbase + offL, *pT = lbase + offT;
-                    unsigned char *tile = tiles + (j & 1) * tile_bytes + lane * kTileColBytes;
-                    if ((j & 3) == 0) {  // first block of a loader phase: its operands landed with the barrier just passed
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            la[u] = *reinterpret_cast<const double *>(pL + 24 * u);
-                            ta[u] = *reinterpret_cast<const double *>(pT + 24 * u);
-                        }
-                    }
-                    const bool interior = x0 >= r && x0 + (kBlkRows - 1) + r < n;
-                    const bool next = (j & 3) != 3 && j + 1 < blocks;  // fetch block j+1's first operands during block j (same phase: landed)
-#ifdef BS_SWEEP_PROBE
-                    if (pl.dbg == 1) chain_block<false, true, 1>(pL, pT, tile, x0, r, n, s, la, ta);
-                    else if (pl.dbg == 2) chain_block<false, true, 2>(pL, pT, tile, x0, r, n, s, la, ta);
-                    else if (pl.dbg == 3) chain_block<false, true, 3>(pL, pT, tile, x0, r, n, s, la, ta);
-                    else
-#endif
-                    if (next) {
-                        if (interior) chain_block<false, true>(pL, pT, tile, x0, r, n, s, la, ta);
-                        else chain_block<true, true>(pL, pT, tile, x0, r, n, s, la, ta);
-                    } else {
-                        if (interior) chain_block<false, false>(pL, pT, tile, x0, r, n, s, la, ta);
-                        else chain_block<true, false>(pL, pT, tile, x0, r, n, s, la, ta);
-                    }
-                }
-                offL += 24 * kBlkRows; offL = offL >= ring ? offL - ring : offL;
-                offT += 24 * kBlkRows; offT = offT >= ring ? offT - ring : offT;
-            }
-        } else if (wave == 1) {
-            if (j < blocks) {
-                // loader phase k = 4 blocks = 128 rows = 3 chunks per pixel.  Blocks 0..2 of the phase each issue one chunk of batch
-                // k + Dp (into the slots of chunks that died with phase k-1); block 3 waits for batch k+1, which phase k+1 opens with.
-                const int k = j >> 2, q = j & 3;
-                if (q < 3) {
-                    const int c0 = batch_lo(k + Dp);
-                    const int knew = issue(c0 + q, c0 + q + 1);
-                    if (Dp == 1) v0 += knew; else if (Dp == 2) v1 += knew; else v2 += knew;
-                } else {
-                    wait_vmcnt_le(v1 + v2);
-                    v0 = v1; v1 = v2; v2 = 0;
-                }
-            }
-        } else if (j >= 1) {
-            const int jm = j - 1, mw = wave - 2;
-            const int xb = jm * kBlkRows + kRowsPerStore * mw;  // this wave's rows of the block: [xb, xb + kRowsPerStore)
-            const unsigned char *tile = tiles + (jm & 1) * tile_bytes + col * kTileColBytes + 8 * (kRowsPerStore * mw);
-            double *dst = out + ((size_t)(xb + rsub) * P + p0) * 3 + col;
-            const size_t step = (size_t)G * ostride;
-            const int iters = (kRowsPerStore + G - 1) / G;  // wave-uniform
-            for (int it0 = 0; it0 < iters; it0 += 4) {      // four tile reads, then their multiplies and stores
-                double v[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int rowl = (it0 + q) * G + rsub;
-                    v[q] = *reinterpret_cast<const double *>(tile + 8 * (rowl < kRowsPerStore ? rowl : 0));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int rowl = (it0 + q) * G + rsub;
-                    if (lane_ok && rowl < kRowsPerStore && xb + rowl < n) dst[q * step] = norm * v[q];  // mul normFactor newRGB (:62-63)
-                }
-                dst += 4 * step;
-            }
-        }
-        // Block barrier WITHOUT a memory fence: only LDS (rings, tiles) is handed over between the wavefronts; a fence would
-        // wait for the LDS-DMA batches in flight and for the STORE wavefronts' stores -- exactly the latency this pipeline hides.
-#ifdef BS_SWEEP_PROBE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        probe_work += __builtin_readcyclecounter() - probe_t;
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-#ifdef BS_SWEEP_PROBE
-    if (g == 0 && lane == 0 && pl.clocks) {  // per wavefront of group 0: clocks spent working (up to the barrier) / in the loop
-        pl.clocks[2 * wave] = probe_work;
-        pl.clocks[2 * wave + 1] = __builtin_readcyclecounter() - probe_start;
-    }
-#endif
-}
-
 // ---- rotating version: THREE chain wavefronts take turns (the default path) -------------------------------------------
-// In the six-wavefront kernel the chain wavefront still spends 54-58 clocks per row, of which only 21 are the two dependent adds;
+// With ONE chain wavefront (and store wavefronts for the rest) the chain wavefront still spends 54-58 clocks per row, of which only 21 are the two dependent adds;
 // the rest is its own LDS traffic (operand reads 17, result writes 15), which a lone in-order wavefront cannot overlap with
 // the adds.  But the chain only hands ONE number per lane from row to row.  So three wavefronts take turns, block by block (32
 // rows): in interval j the wavefront j mod 3 does nothing but the 64 dependent adds of block j -- operands already in its
@@ -542,8 +326,10 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
                                                                    const SweepPlan pl)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kDmaLds];
+    // Every kernel argument is consumed HERE, by all wavefronts: a scalar load whose result only one role uses would stay
+    // "pending" on the other roles' paths, and the compiler then treats lgkmcnt as out of order there.
     asm volatile("" ::"s"(in), "s"(out), "s"(P), "s"(n), "s"(r), "s"(norm), "s"(pl.px), "s"(pl.S), "s"(pl.Dp), "s"(pl.Lr), "s"(pl.stride),
-                 "s"(pl.groups), "s"(pl.per_xcd));  // see box_blur_sweep_dma: no scalar load may stay pending on any role's path
+                 "s"(pl.groups), "s"(pl.per_xcd));
     const int g = (int)(blockIdx.x & 7u) * pl.per_xcd + (int)(blockIdx.x >> 3);  // XCD-contiguous ranges of chain groups
     if (g >= pl.groups) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -940,7 +726,7 @@ static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepP
     return !single_round || pl.groups <= n_cu;
 }
 
-// Sweep paths: "dma" = the six-wavefront LDS-DMA kernel, "lds" = the round-1 register-staged LDS ring (windows up to r = 192),
+// Sweep paths: "dma" = the LDS-DMA kernel with rotating chain wavefronts (box_blur_sweep_rot), "lds" = the round-1 register-staged LDS ring (windows up to r = 192),
 // "direct" = transpose + register-prefetch sweep (any size).  Default: dma wherever its plan exists (even dimensions, 16-B aligned
 // input; measured faster than lds at 720p / 1080p / 2160p and windows up to r = 192: scripts/bloom_ab.py), else lds when its
 // ring covers the window (odd sizes), else direct.  env BLACKSTAR_BLOOM_PATH=dma|lds|direct forces one where it applies (A/B and
@@ -950,7 +736,6 @@ static int bloom_path()
     const char *e = std::getenv("BLACKSTAR_BLOOM_PATH");
     if (!e) return 0;
     if (!std::strcmp(e, "dma")) return 3;
-    if (!std::strcmp(e, "rot")) return 4;
     if (!std::strcmp(e, "lds")) return 1;
     if (!std::strcmp(e, "direct")) return 2;
     return 0;
@@ -968,16 +753,12 @@ static void blur_passes(const double *src, double *d_a, double *d_b, int w, int 
     for (int pass = 0; pass < 3; pass++) {
         SweepPlan ph, pv;
         bool dma = false;
-        const bool rot = path == 0 || path == 4;  // three rotating chain wavefronts (default) / one chain wavefront ("dma")
-        if (path == 0 || path == 3 || path == 4)
+        if (path == 0 || path == 3)
             dma = plan_dma_sweep(src, h, w, r, n_cu, ph, false, kDmaLds - 1024) && plan_dma_sweep(d_a, w, h, r, n_cu, pv, false, kDmaLds - 1024);
         // H: image layout (h x w) -> transposed layout (w x h); V: transposed -> image layout.  No transpose kernels.
-        if (dma && rot) {
+        if (dma) {
             hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * ph.per_xcd)), dim3(kRotThreads), 0, s, src, d_a, h, w, r, norm, ph);
             hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * pv.per_xcd)), dim3(kRotThreads), 0, s, (const double *)d_a, d_b, w, h, r, norm, pv);
-        } else if (dma) {
-            hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * ph.per_xcd)), dim3(kSweepThreads), 0, s, src, d_a, h, w, r, norm, ph);
-            hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * pv.per_xcd)), dim3(kSweepThreads), 0, s, (const double *)d_a, d_b, w, h, r, norm, pv);
         } else if (path != 2 && lds_fits) {
             hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((h + kLP - 1) / kLP)), dim3(256), 0, s, src, d_a, h * 3, w, r, norm);
             hipLaunchKernelGGL(box_blur_sweep_lds, dim3((unsigned)((w + kLP - 1) / kLP)), dim3(256), 0, s, (const double *)d_a, d_b, w * 3, h, r, norm);

@@ -20,7 +20,7 @@ for (h, w, div) in ((1080, 1920, 25), (2160, 3840, 25), (720, 1280, 25), (1080, 
     img = torch.from_numpy(a).cuda()
     out = torch.empty_like(img)
     ref = c_oracle.bloom(0.15, div, a) if h * w <= 1920 * 1080 else None
-    for path in ("rot", "dma", "lds"):
+    for path in ("dma", "lds", "direct"):
         os.environ["BLACKSTAR_BLOOM_PATH"] = path
         fn = lambda: _lib.check(L.bs_bloom_device(tree.handle, img.data_ptr(), out.data_ptr(), w, h, 0.15, div, None), "bloom")
         for _ in range(3):

@@ -1,5 +1,7 @@
-// sweep_probe.hip -- where does a box-blur sweep's time go?  Builds the product's own box_blur_sweep_dma with BS_SWEEP_PROBE
-// (chain variants without its LDS writes / reads, per-wavefront work clocks of workgroup 0) and times the H and V sweep of a frame.
+// sweep_probe.hip -- where does a box-blur sweep's time go?  Builds the product's own box_blur_sweep_rot with BS_SWEEP_PROBE
+// (per-wavefront clocks of workgroup 0: chain wavefronts in their compute intervals, the others up to the barriers) and times the
+// H and V sweep of a frame.  NOTE: the timers (s_memtime, two per interval) inflate every interval by a few hundred clocks --
+// compare variants with scripts/bloom_ab.py on the product build, use this for attribution only.
 // Build (cross-compiles):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scripts/probe/sweep_probe.hip -o scripts/probe/sweep_probe
 #define BS_SWEEP_PROBE 1
 #include "../../blackstar_amd/csrc/post_kernels.hip"
@@ -47,40 +49,10 @@ int main(int argc, char **argv)
                 }
                 unsigned long long c16[16];
                 CK(hipMemcpy(c16, clk, 128, hipMemcpyDeviceToHost));
-                for (int q = 8; q < 14; q++) c16[q] = 0;
                 std::printf("%s sweep rot: px=%d Dp=%d S=%d groups=%d: %.1f us (%.1f clk/row at 2.4 GHz)  work/loop clocks per row:", sw.name, p8.px, p8.Dp, p8.S, p8.groups,
                             best * 1e3, best * 1e-3 * 2.4e9 / sw.n);
                 for (int wv = 0; wv < 8; wv++) std::printf(" w%d %.1f/%.1f", wv, (double)c16[2 * wv] / sw.n, (double)c16[2 * wv + 1] / sw.n);
                 std::printf("\n");
-            }
-        }
-        {   // the six-wavefront kernel
-            SweepPlan p4;
-            if (plan_dma_sweep(a, sw.P, sw.n, r, n_cu, p4, false)) {
-                for (int var : {0, 1, 2, 3}) {
-                    const int dp = 0;
-                    SweepPlan q = p4;
-                    q.dbg = var; q.clocks = clk;
-                    if (dp) {
-                        q.Dp = dp; q.S = 3 * (1 + dp) + 2 * q.Lr; q.stride = (q.S + 1) * kDmaChunk + 32;
-                        if ((long)q.px * (q.stride + 2 * 3 * kTileColBytes) > kDmaLds) continue;
-                    }
-                    float best = 1e9f;
-                    for (int it = 0; it < 6; it++) {
-                        CK(hipEventRecord(e0, nullptr));
-                        hipLaunchKernelGGL(box_blur_sweep_dma, dim3((unsigned)(8 * q.per_xcd)), dim3(kSweepThreads), 0, nullptr, (const double *)a, b, sw.P, sw.n, r, norm, q);
-                        CK(hipEventRecord(e1, nullptr));
-                        CK(hipEventSynchronize(e1));
-                        float ms = 0;
-                        CK(hipEventElapsedTime(&ms, e0, e1));
-                        if (ms < best) best = ms;
-                    }
-                    unsigned long long c8[12];
-                    CK(hipMemcpy(c8, clk, 96, hipMemcpyDeviceToHost));
-                    std::printf("%s sweep dma4 probe=%d: px=%d Dp=%d S=%d groups=%d: %.1f us (%.1f clk/row at 2.4 GHz)  work/loop clocks per row: chain %.1f/%.1f loader %.1f/%.1f store0 %.1f/%.1f store3 %.1f/%.1f\n",
-                                sw.name, var, q.px, q.Dp, q.S, q.groups, best * 1e3, best * 1e-3 * 2.4e9 / sw.n, (double)c8[0] / sw.n, (double)c8[1] / sw.n,
-                                (double)c8[2] / sw.n, (double)c8[3] / sw.n, (double)c8[4] / sw.n, (double)c8[5] / sw.n, (double)c8[10] / sw.n, (double)c8[11] / sw.n);
-                }
             }
         }
     }
