@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
         ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
         return cnt;
     };
-    int v0 = 0, v1 = 0, v2 = 0;  // wave-instruction counts of the batches in flight behind the one that is awaited next
+    int v1 = 0, v2 = 0;  // wave-instruction counts of the (up to two) batches in flight BEHIND the one that is awaited next
 
     // ---- chain (waves 0..2) ----
     const int ncol = 3 * npx;
@@ -426,21 +426,24 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
     double *dst_blk = out + ((size_t)row0 * P + p0) * 3 + 2 * cp;                     // this lane's first output of block 0
     struct __attribute__((packed, aligned(8))) Pair { double a, b; };                 // 16-byte store at 8-byte alignment
 
+    // batch p = what phase p needs beyond phase p-1: chunks [3p + Lr, 3p + 3 + Lr), batch 0 from chunk 0.  Batch 0 first, alone:
+    // the start value and the chain wavefronts' first operands need nothing else, and batches 1 .. Dp-1 are issued while they run.
     if (wave == kChainWaves) {
-        // batches 0 .. Dp-1 (batch p = what phase p needs beyond phase p-1: chunks [3p + Lr, 3p + 3 + Lr), batch 0 from chunk 0)
-        int c[3] = {0, 0, 0};
-        for (int p = 0; p < Dp; p++) {
-            int cnt = 0;
-            const int hi = 3 * p + 3 + Lr;
-            while (ld_chunk < hi && ld_chunk < nchunks) cnt += issue_next();
-            if (p >= 1) c[p - 1] = cnt;
-        }
-        v0 = c[0]; v1 = c[1]; v2 = c[2];
-        wait_vmcnt_le(v0 + v1 + v2);  // batch 0 has landed
+        while (ld_chunk < 3 + Lr && ld_chunk < nchunks) issue_next();
+        wait_vmcnt_le(0);  // batch 0 has landed
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    if (wave < kChainWaves && active) {
+    if (wave == kChainWaves) {
+        int c[3] = {0, 0, 0};
+        for (int p = 1; p < Dp; p++) {
+            int cnt = 0;
+            const int hi = 3 * p + 3 + Lr;
+            while (ld_chunk < hi && ld_chunk < nchunks) cnt += issue_next();
+            c[p - 1] = cnt;
+        }
+        v1 = c[1]; v2 = c[2];  // (c[0] is batch 1, the one awaited first: its own count is never needed)
+    } else if (wave < kChainWaves && active) {
         if (wave == 0) {  // startVal = foldl1' add (pix <$> take r crds)   (ImageFilters.hs:59)
             const int mr = r < n ? r : n;
             s = *reinterpret_cast<const double *>(lbase);
@@ -540,14 +543,13 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
             } else if (q == 1) {
                 knew = issue_next();
             }
-            if (Dp == 1) v0 += knew; else if (Dp == 2) v1 += knew; else v2 += knew;
+            if (Dp == 2) v1 += knew; else if (Dp >= 3) v2 += knew;
             if (q == 1) {
                 // everything older than the batches behind batch k+1 has landed.  With Dp >= 2 the newest batch is still being
                 // issued (its third chunk follows in interval 2): its count so far is exactly what is outstanding behind batch k+1.
                 wait_vmcnt_le(v1 + v2);
-                if (Dp == 1) v0 = 0;
             }
-            if (q == 3 && Dp >= 2) { v0 = v1; v1 = v2; v2 = 0; }  // the phase's batch is complete: shift the window
+            if (q == 3 && Dp >= 2) { v1 = v2; v2 = 0; }  // the phase's batch is complete: shift the window
             BS_INTERVAL_END();
         }
     } else {
