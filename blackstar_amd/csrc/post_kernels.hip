@@ -250,7 +250,7 @@ struct SweepPlan {
     int per_xcd;  // ceil(groups / 8); grid = 8 * per_xcd
     int lds_bytes;  // LDS the plan needs: rings + hand-off tiles (<= kDmaLds, the kernel's static allocation)
 #ifdef BS_SWEEP_PROBE  // scripts/sweep_probe.hip only: switch parts of the kernel off, report shader / wall clocks of workgroup 0
-    int dbg;                     // unused
+    int dbg;                     // see box_blur_sweep_rot
     unsigned long long *clocks;  // per wavefront of group 0: [2w] shader clocks (chain: in compute intervals; others: up to the barriers), [2w+1] in the loop
 #endif
 };
@@ -468,17 +468,23 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
     // roles are separate straight-line loops, so that the 128 operand registers of a chain wavefront are updated in ONE
     // sequence (a role switch inside a common loop made the register allocator spill them).
     const int n_int = blocks + 2;
-#ifdef BS_SWEEP_PROBE
+#ifdef BS_SWEEP_PROBE  // dbg bits: 16 = per-interval timers (they cost a few hundred clocks per interval); 1 = STORE wavefronts idle,
+                       // 2 = loader idle, 4 = chain wavefronts skip their off-interval LDS work (tile writes, operand fetches)
+    const int dbg = pl.dbg;
     unsigned long long probe_work = 0, probe_start = __builtin_readcyclecounter();
-#define BS_INTERVAL_END()                                                  \
-    do {                                                                   \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
-        probe_work += __builtin_readcyclecounter() - probe_t;              \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
-        probe_t = __builtin_readcyclecounter();                            \
+#define BS_INTERVAL_END()                                                      \
+    do {                                                                       \
+        if (dbg & 16) {                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+            probe_work += __builtin_readcyclecounter() - probe_t;              \
+        }                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        \
+        if (dbg & 16) probe_t = __builtin_readcyclecounter();                  \
     } while (0)
     unsigned long long probe_t = __builtin_readcyclecounter(), probe_compute = 0;
+#define BS_DBG(bit) (dbg & (bit))
 #else
+#define BS_DBG(bit) false
 #define BS_INTERVAL_END() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
     if (wave < kChainWaves) {
@@ -507,13 +513,15 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
                 s_hand[lane] = s;
             }
 #ifdef BS_SWEEP_PROBE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            probe_compute += __builtin_readcyclecounter() - probe_t;
+            if (dbg & 16) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                probe_compute += __builtin_readcyclecounter() - probe_t;
+            }
 #endif
             BS_INTERVAL_END();
             if (++it >= n_int) break;
             // interval b + 1: results of block b -> tile; the first operands of block b + 3
-            if (active) {
+            if (active && !BS_DBG(4)) {
                 if (b < blocks) {
                     unsigned char *tile = tiles + (b & 1) * tile_bytes + lane * kTileColBytes;
 #pragma unroll
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
             BS_INTERVAL_END();
             if (++it >= n_int) break;
             // interval b + 2: the rest of the operands of block b + 3
-            if (active && b + kChainWaves < blocks) { fetch(8, kBlkRows); advance(); }
+            if (active && b + kChainWaves < blocks && !BS_DBG(4)) { fetch(8, kBlkRows); advance(); }
             BS_INTERVAL_END();
             ++it;
         }
@@ -535,7 +543,8 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
         for (int it = 0; it < n_int; it++) {
             const int q = it & 3;
             int knew = 0;
-            if (Dp >= 2) {  // one chunk per interval (a burst would hold up the barrier): the batch is not needed for another phase
+            if (BS_DBG(2)) {
+            } else if (Dp >= 2) {  // one chunk per interval (a burst would hold up the barrier): the batch is not needed for another phase
                 if (q < 3) knew = issue_next();
             } else if (q == 0) {  // Dp = 1: batch k+1 itself, needed when interval 4k + 2 opens
                 knew = issue_next();
@@ -553,38 +562,75 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
             BS_INTERVAL_END();
         }
     } else {
-        for (int it = 0; it < n_int; it++) {
-            if (it >= 2 && it - 2 < blocks) {  // STORE block it - 2
+        // STORE, software-pipelined across the barrier: in interval `it` the tile of block it - 2 is READ into one register set
+        // while the values read in the previous interval (block it - 3) are multiplied and written to HBM from the other -- the
+        // wavefront reaches the barrier after max(LDS round trip, store issue), not their sum, and its stores never pace an
+        // interval.  (The tile may be overwritten from interval it + 1 on; by then it is in registers.)
+        constexpr int kMaxIt = 4;  // store instructions per block and wavefront: ceil(8 / G) with G >= 2
+        struct Held { double a[kMaxIt], b[kMaxIt]; double *dst; int lim; };
+        Held hx, hy;
+        hx.lim = hy.lim = 0; hx.dst = hy.dst = dst_blk;
+#pragma unroll
+        for (int q = 0; q < kMaxIt; q++) hx.a[q] = hx.b[q] = hy.a[q] = hy.b[q] = 0.0;
+        auto read_block = [&](Held &h, int it) {  // tile of block it - 2 -> registers (lanes without a row read harmless bytes)
+            h.lim = 0;
+            if (it >= 2 && it - 2 < blocks && !BS_DBG(1)) {
                 const int jm = it - 2;
                 const unsigned char *tp = tiles + (jm & 1) * tile_bytes + tile_lane;
-                double *dst = dst_blk;
                 int lim = my_iters;  // store instructions in which this lane has a row that exists
                 if ((jm + 1) * kBlkRows > n) {  // (wave-uniform) the image ends inside this block
                     const int rows_left = n - jm * kBlkRows - row0;
                     const int cap = rows_left <= 0 ? 0 : (rows_left + G - 1) / G;
                     lim = lim < cap ? lim : cap;
                 }
-                for (int i = 0; i < iters; i++) {  // (lanes without a row read harmless bytes)
-                    const double va = *reinterpret_cast<const double *>(tp), vb = *reinterpret_cast<const double *>(tp + kTileColBytes);
-                    if (i < lim) {  // mul normFactor newRGB (ImageFilters.hs:62-63)
-                        if (has2) {
-                            Pair pr;
-                            pr.a = norm * va;
-                            pr.b = norm * vb;
-                            *reinterpret_cast<Pair *>(dst) = pr;
-                        } else {
-                            *dst = norm * va;
-                        }
-                    }
-                    tp += 8 * G;
-                    dst += step;
-                }
+                h.lim = lim;
+                h.dst = dst_blk;
                 dst_blk += (size_t)kBlkRows * ostride;
+#pragma unroll
+                for (int q = 0; q < kMaxIt; q++) {
+                    if (q < iters) {
+                        h.a[q] = *reinterpret_cast<const double *>(tp + (8 * G) * q);
+                        h.b[q] = *reinterpret_cast<const double *>(tp + (8 * G) * q + kTileColBytes);
+                    }
+                }
             }
+        };
+        auto write_block = [&](const Held &h) {  // mul normFactor newRGB (ImageFilters.hs:62-63) -> HBM
+#pragma unroll
+            for (int q = 0; q < kMaxIt; q++) {
+                if (q < h.lim) {
+                    double *d = h.dst + q * step;
+                    if (has2) {
+                        Pair pr;
+                        pr.a = norm * h.a[q];
+                        pr.b = norm * h.b[q];
+                        *reinterpret_cast<Pair *>(d) = pr;
+                    } else {
+                        *d = norm * h.a[q];
+                    }
+                }
+            }
+        };
+        int it = 0;
+        for (; it + 1 < n_int; it += 2) {
+            read_block(hx, it);
+            write_block(hy);
             BS_INTERVAL_END();
+            read_block(hy, it + 1);
+            write_block(hx);
+            BS_INTERVAL_END();
+        }
+        if (it < n_int) {  // odd number of intervals
+            read_block(hx, it);
+            write_block(hy);
+            BS_INTERVAL_END();
+            write_block(hx);
+        } else {
+            write_block(hy);
         }
     }
 #undef BS_INTERVAL_END
+#undef BS_DBG
 #ifdef BS_SWEEP_PROBE
     if (g == 0 && lane == 0 && pl.clocks) {  // per wavefront of group 0: clocks up to the barriers (chain: in COMPUTE intervals only) / in the loop
         pl.clocks[2 * wave] = wave < kChainWaves ? probe_compute : probe_work;

@@ -36,23 +36,28 @@ int main(int argc, char **argv)
         {   // the rotating three-chain-wavefront kernel (the product path)
             SweepPlan p8;
             if (plan_dma_sweep(a, sw.P, sw.n, r, n_cu, p8, false, kDmaLds - 1024)) {
-                p8.dbg = 0; p8.clocks = clk;
-                float best = 1e9f;
-                for (int it = 0; it < 6; it++) {
-                    CK(hipEventRecord(e0, nullptr));
-                    hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * p8.per_xcd)), dim3(kRotThreads), 0, nullptr, (const double *)a, b, sw.P, sw.n, r, norm, p8);
-                    CK(hipEventRecord(e1, nullptr));
-                    CK(hipEventSynchronize(e1));
-                    float ms = 0;
-                    CK(hipEventElapsedTime(&ms, e0, e1));
-                    if (ms < best) best = ms;
+                for (int dbg : {0, 1, 2, 4, 5, 7, 16}) {
+                    p8.dbg = dbg; p8.clocks = clk;
+                    float best = 1e9f;
+                    for (int it = 0; it < 6; it++) {
+                        CK(hipEventRecord(e0, nullptr));
+                        hipLaunchKernelGGL(box_blur_sweep_rot, dim3((unsigned)(8 * p8.per_xcd)), dim3(kRotThreads), 0, nullptr, (const double *)a, b, sw.P, sw.n, r, norm, p8);
+                        CK(hipEventRecord(e1, nullptr));
+                        CK(hipEventSynchronize(e1));
+                        float ms = 0;
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        if (ms < best) best = ms;
+                    }
+                    unsigned long long c16[16];
+                    CK(hipMemcpy(c16, clk, 128, hipMemcpyDeviceToHost));
+                    std::printf("%s sweep rot dbg=%2d: px=%d Dp=%d S=%d groups=%d: %.1f us, loop %.1f clk/row", sw.name, dbg, p8.px, p8.Dp, p8.S, p8.groups, best * 1e3,
+                                (double)c16[1] / sw.n);
+                    if (dbg & 16) {
+                        std::printf("; with interval timers, work clocks per row:");
+                        for (int wv = 0; wv < 8; wv++) std::printf(" w%d %.1f", wv, (double)c16[2 * wv] / sw.n);
+                    }
+                    std::printf("\n");
                 }
-                unsigned long long c16[16];
-                CK(hipMemcpy(c16, clk, 128, hipMemcpyDeviceToHost));
-                std::printf("%s sweep rot: px=%d Dp=%d S=%d groups=%d: %.1f us (%.1f clk/row at 2.4 GHz)  work/loop clocks per row:", sw.name, p8.px, p8.Dp, p8.S, p8.groups,
-                            best * 1e3, best * 1e-3 * 2.4e9 / sw.n);
-                for (int wv = 0; wv < 8; wv++) std::printf(" w%d %.1f/%.1f", wv, (double)c16[2 * wv] / sw.n, (double)c16[2 * wv + 1] / sw.n);
-                std::printf("\n");
             }
         }
     }
