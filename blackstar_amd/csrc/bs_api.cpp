@@ -81,6 +81,9 @@ struct bs_ctx {
                                                     // first wavefronts fill the slots the previous frame's last tiles leave idle
     double *d_post[3] = {nullptr, nullptr, nullptr};  // bloom ping-pong buffers + host-variant staging
     size_t post_cap = 0;
+    hipEvent_t ev_post = nullptr;     // recorded behind the last user of d_post[0..1]; a user on another stream waits for it first
+    hipStream_t post_stream = nullptr;
+    bool post_busy = false;
     unsigned char *d_u8 = nullptr;
     size_t u8_cap = 0;
     double *d_srgb_table = nullptr;  // 257 thresholds of the sRGB8 pixel map (bs::srgb8_thresholds)
@@ -169,6 +172,8 @@ double *device_alias_of_pinned(const bs_ctx *ctx, const void *host, size_t bytes
         (void)hipGetLastError();  // the buffer runs past the page-locked range
         return nullptr;
     }
+    // page-locked for ANOTHER device only (hipHostMalloc / hipHostRegister there without the Portable flag): not ours to write
+    if (a.device != ctx->device && !(a.allocationFlags & hipHostMallocPortable)) return nullptr;
     return static_cast<double *>(a.devicePointer);
 }
 
@@ -181,6 +186,29 @@ int ensure_scratch(bs_ctx *ctx, size_t bytes)
     const size_t cap = std::max<size_t>(bytes, size_t(1) << 20);
     if (hipMalloc(&ctx->d_scratch, cap) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc scratch failed");
     ctx->scratch_cap = cap;
+    return BS_OK;
+}
+
+int resolve_stats(bs_ctx *ctx)
+{
+    if (!ctx->pending) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    bs_ctx::LaunchSlot &sl = ctx->slots[ctx->stats_slot];
+    HIP_TRY(hipEventSynchronize(sl.ev_done));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
+    bs_stats_t &st = ctx->stats;
+    st.rays = sl.rays;
+    st.steps = sl.h_counters[0];
+    st.capped = sl.h_counters[1];
+    st.horizon = sl.h_counters[2];
+    st.escaped = sl.h_counters[3];
+    st.disk_hits = sl.h_counters[4];
+    st.star_hits = sl.h_counters[5];
+    st.wave_iters = sl.h_counters[6];
+    st.kernel_ms = ms;
+    st.wall_ms = ctx->last_wall_ms;
+    ctx->pending = false;
     return BS_OK;
 }
 
@@ -200,6 +228,10 @@ int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_
     p.out = d_out;
     HIP_TRY(hipSetDevice(ctx->device));
     if (first) {
+        if (ctx->pending && ctx->stats_slot == ctx->next_slot) {  // bs_stats still owes the numbers of this slot's previous owner
+            rc = resolve_stats(ctx);
+            if (rc) return rc;
+        }
         bs_ctx::LaunchSlot &sl = ctx->slots[ctx->next_slot];
         if (sl.used) HIP_TRY(hipEventSynchronize(sl.ev_done));  // its owner of kSlots renders ago (normally long finished)
         ctx->cur_slot = ctx->next_slot;
@@ -226,29 +258,6 @@ int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_
             ctx->pending = true;
         }
     }
-    return BS_OK;
-}
-
-int resolve_stats(bs_ctx *ctx)
-{
-    if (!ctx->pending) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    bs_ctx::LaunchSlot &sl = ctx->slots[ctx->stats_slot];
-    HIP_TRY(hipEventSynchronize(sl.ev_done));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
-    bs_stats_t &st = ctx->stats;
-    st.rays = sl.rays;
-    st.steps = sl.h_counters[0];
-    st.capped = sl.h_counters[1];
-    st.horizon = sl.h_counters[2];
-    st.escaped = sl.h_counters[3];
-    st.disk_hits = sl.h_counters[4];
-    st.star_hits = sl.h_counters[5];
-    st.wave_iters = sl.h_counters[6];
-    st.kernel_ms = ms;
-    st.wall_ms = ctx->last_wall_ms;
-    ctx->pending = false;
     return BS_OK;
 }
 
@@ -374,6 +383,7 @@ void bs_destroy(bs_ctx *ctx)
         for (double *b : ctx->d_post)
             if (b) (void)hipFree(b);
         if (ctx->d_u8) (void)hipFree(ctx->d_u8);
+        if (ctx->ev_post) (void)hipEventDestroy(ctx->ev_post);
         if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         if (ctx->ev_u0) (void)hipEventDestroy(ctx->ev_u0);
@@ -413,6 +423,23 @@ static int ensure_post(bs_ctx *ctx, size_t n)
     return BS_OK;
 }
 
+// The blur scratch d_post[0..1] is one pair per context.  *_device calls only enqueue, so two of them on different streams
+// would otherwise share it unordered: a user on another stream than the previous one first waits for that one's event.
+static int acquire_post(bs_ctx *ctx, hipStream_t s)
+{
+    if (!ctx->ev_post) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_post, hipEventDisableTiming));
+    if (ctx->post_busy && ctx->post_stream != s) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_post, 0));
+    return BS_OK;
+}
+
+static int release_post(bs_ctx *ctx, hipStream_t s)
+{
+    HIP_TRY(hipEventRecord(ctx->ev_post, s));
+    ctx->post_busy = true;
+    ctx->post_stream = s;
+    return BS_OK;
+}
+
 int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int height, double strength, int divider, void *hip_stream)
 {
     if (!ctx || !d_in || !d_out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
@@ -422,9 +449,11 @@ int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int h
     size_t n = (size_t)width * height * 3;
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
+    rc = acquire_post(ctx, static_cast<hipStream_t>(hip_stream));
+    if (rc) return rc;
     if (bs::launch_bloom((const double *)d_in, (double *)d_out, ctx->d_post[0], ctx->d_post[1], width, height, strength, divider, ctx->n_cu, hip_stream))
         return fail(BS_EDEVICE, "bloom launch failed");
-    return BS_OK;
+    return release_post(ctx, static_cast<hipStream_t>(hip_stream));
 }
 
 int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider)
@@ -453,7 +482,11 @@ int bs_supersample(bs_ctx *ctx, const double *in, double *out, int width2, int h
     if (rc) return rc;
     StreamDrain drain(ctx);
     HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = acquire_post(ctx, ctx->stream);
+    if (rc) return rc;
     if (bs::launch_supersample(ctx->d_post[2], ctx->d_post[0], width2, height2, ctx->stream)) return fail(BS_EDEVICE, "supersample launch failed");
+    rc = release_post(ctx, ctx->stream);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, ctx->d_post[0], n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
@@ -497,6 +530,8 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     auto t0 = std::chrono::steady_clock::now();
     const size_t n = (size_t)cfg->width * cfg->height * 3;
     if (out_bytes < n) return fail(BS_EINVAL, "output buffer too small");
+    if (bloom_strength != 0 && (bloom_divider <= 0 || cfg->width / bloom_divider == 0))
+        return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
@@ -515,10 +550,13 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
     if (rc) return rc;
     if (bloom_strength != 0) {  // bloom's final img + strength * blurred is fused with the sRGB8 map: the bloomed f64 image is never written
-        if (bloom_divider <= 0 || cfg->width / bloom_divider == 0) return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+        rc = acquire_post(ctx, ctx->stream);
+        if (rc) return rc;
         if (bs::launch_bloom_srgb8(ctx->d_post[2], u8_target, ctx->d_post[0], ctx->d_post[1], cfg->width, cfg->height, bloom_strength, bloom_divider,
                                    ctx->n_cu, ctx->d_srgb_table, ctx->stream))
             return fail(BS_EDEVICE, "bloom launch failed");
+        rc = release_post(ctx, ctx->stream);
+        if (rc) return rc;
     } else {
         rc = bs_srgb8_device(ctx, ctx->d_post[2], u8_target, n, ctx->stream);
         if (rc) return rc;

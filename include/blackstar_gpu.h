@@ -47,12 +47,13 @@ enum {
  * FAST:   the same discrete RK4 map evaluated in the ray's orbital plane with FMA-accumulated stage sums and
  *         r^-5 from v_rsq_f64 + a 2nd-order series correction.  Step counts, fates and disk crossings equal
  *         STRICT's on every ray tested; pixel values agree with STRICT to 3.4e-8 absolute / 3.7e-7 relative
- *         on the BASELINE frames (worst 2.3e-5 relative over a 10 000-scene fuzz: rays grazing the photon
- *         sphere amplify any rounding difference) -- inside the 1e-4 relative bar, not bit-exact.
- *         Two guards keep it there: a ray that orbits the hole (more steps than the longest straight path plus one
- *         photon-sphere circumference; a few per million) is re-traced with STRICT arithmetic inside the same kernel,
- *         and a frame whose stepSize exceeds 0.5 (the RK4 step no longer resolves the field next to the hole) is
- *         traced in STRICT altogether.  The reference's default stepSize is 0.3. */
+ *         on the BASELINE frames and to 6.5e-7 relative at worst over a 10 000-scene fuzz (profiles/r02_fuzz_*)
+ *         -- inside the 1e-4 relative bar, not bit-exact.  Two guards keep it there (without them the fuzz's worst
+ *         case was 2.3e-5: rays grazing the photon sphere amplify any rounding difference): a ray that orbits the
+ *         hole (more steps than the longest straight path plus one photon-sphere circumference; a few per million)
+ *         is re-traced with STRICT arithmetic inside the same kernel, and a frame whose stepSize exceeds 0.5 (the
+ *         RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether.  The reference's
+ *         default stepSize is 0.3. */
 enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
 
 /* Replaces the `Config` argument of render (src/ConfigFile.hs:16-38), AS PARSED: radii un-squared,
@@ -156,6 +157,8 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
 
 /* Replaces: bloom strength divider img (src/ImageFilters.hs:80-86): out = img + strength * boxBlur(w `div` divider, 3 passes).
  * d_in / d_out: device pointers to height*width*3 interleaved RGB f64 (may alias); enqueued on hip_stream, no sync.
+ * The intermediate sweeps live in ONE pair of scratch images per context: a call on another stream than the previous
+ * user of that scratch is ordered behind it with an event (correct, but such calls do not overlap).
  * Returns BS_EINVAL when width `div` divider == 0 (the reference crashes there: foldl1' on an empty window). */
 int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int height, double strength, int divider, void *hip_stream);
 int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider); /* host buffers, blocking */

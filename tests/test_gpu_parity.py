@@ -976,6 +976,48 @@ def test_bloom_device_unaligned_and_aliased_buffers(tree, oracle):
     assert np.array_equal(out.cpu().numpy().reshape(90, 160, 3), ref)
 
 
+def test_bloom_on_different_streams_of_one_context_is_ordered(tree, oracle):
+    """bs_bloom_device only enqueues and the blur scratch is one pair of images per context: calls on different streams, no
+    synchronisation in between, must still each see their own intermediate sweeps (the second waits for the first's event)."""
+    import torch
+    rng = np.random.default_rng(11)
+    imgs = [rng.uniform(0, 1.5, (270, 480, 3)) for _ in range(6)]
+    refs = [oracle.bloom(0.2, 25, im) for im in imgs]
+    L = _lib.lib()
+    ts = [torch.from_numpy(im).to("cuda:0") for im in imgs]
+    outs = [torch.empty_like(t) for t in ts]
+    streams = [torch.cuda.Stream() for _ in ts]
+    torch.cuda.synchronize()
+    for t, o, s in zip(ts, outs, streams):
+        _lib.check(L.bs_bloom_device(tree.handle, t.data_ptr(), o.data_ptr(), 480, 270, 0.2, 25, C.c_void_p(s.cuda_stream)), "bloom on a stream")
+    # a blocking call right behind them uses the same scratch on the context's own stream
+    host = bs.bloom(0.2, 25, imgs[0], tree)
+    torch.cuda.synchronize()
+    assert np.array_equal(host, refs[0])
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert np.array_equal(o.cpu().numpy(), r), f"bloom {i} on its own stream saw another call's scratch"
+
+
+def test_stats_survive_the_reuse_of_their_launch_slot(tree):
+    """bs_stats reports the last bs_render[_device]; batch frames do not update it -- also when they run the ring of launch
+    slots all the way round and take over the slot that render used."""
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 320, 180)
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        bs.render(cfg, tree)
+        want = tree.stats()
+        import torch
+        out = torch.empty((180, 320, 3), dtype=torch.float64, device="cuda:0")
+        bs.render_device(cfg, tree, out.data_ptr(), out.numel(), torch.cuda.current_stream().cuda_stream)  # stats pending, not yet read
+        small = [scenes.with_res(scenes.ani_frame(i * 40, 600), 96, 54) for i in range(12)]                 # 12 quiet frames > 8 slots
+        bs.render_batch(small, [tree])
+        got = tree.stats()
+        for k in ("rays", "steps", "escaped", "horizon", "disk_hits", "star_hits"):
+            assert got[k] == want[k], k
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+
+
 def test_srgb8_is_exact_everywhere(tree, oracle):
     """The threshold-table pixel map against the host libm formula: dense around every one of the 255 byte boundaries, the
     linear/power seam, and the specials."""
