@@ -469,7 +469,8 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
     // sequence (a role switch inside a common loop made the register allocator spill them).
     const int n_int = blocks + 2;
 #ifdef BS_SWEEP_PROBE  // dbg bits: 16 = per-interval timers (they cost a few hundred clocks per interval); 1 = STORE wavefronts idle,
-                       // 2 = loader idle, 4 = chain wavefronts skip their off-interval LDS work (tile writes, operand fetches)
+                       // 2 = loader idle, 4 = chain wavefronts skip their off-interval LDS work (tile writes, operand fetches),
+                       // 128 = STORE wavefronts skip their global stores, 256 = ... their tile reads
     const int dbg = pl.dbg;
     unsigned long long probe_work = 0, probe_start = __builtin_readcyclecounter();
 #define BS_INTERVAL_END()                                                      \
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
                 dst_blk += (size_t)kBlkRows * ostride;
 #pragma unroll
                 for (int q = 0; q < kMaxIt; q++) {
-                    if (q < iters) {
+                    if (q < iters && !BS_DBG(256)) {
                         h.a[q] = *reinterpret_cast<const double *>(tp + (8 * G) * q);
                         h.b[q] = *reinterpret_cast<const double *>(tp + (8 * G) * q + kTileColBytes);
                     }
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
         auto write_block = [&](const Held &h) {  // mul normFactor newRGB (ImageFilters.hs:62-63) -> HBM
 #pragma unroll
             for (int q = 0; q < kMaxIt; q++) {
-                if (q < h.lim) {
+                if (q < h.lim && !BS_DBG(128)) {
                     double *d = h.dst + q * step;
                     if (has2) {
                         Pair pr;
@@ -611,19 +612,29 @@ __global__ __launch_bounds__(kRotThreads) void box_blur_sweep_rot(const double *
                 }
             }
         };
+        // The barrier's own lgkmcnt(0) has retired the reads, but the compiler cannot see that and would wait for them -- AND for
+        // the next block's reads issued in front of the stores -- before the first multiply: passing the registers through an
+        // empty asm makes the (by then free) wait happen here, so the next interval's stores go out while its reads are in flight.
+        auto landed = [&](Held &h) {
+#pragma unroll
+            for (int q = 0; q < kMaxIt; q++) asm volatile("" : "+v"(h.a[q]), "+v"(h.b[q]));
+        };
         int it = 0;
         for (; it + 1 < n_int; it += 2) {
             read_block(hx, it);
             write_block(hy);
             BS_INTERVAL_END();
+            landed(hx);
             read_block(hy, it + 1);
             write_block(hx);
             BS_INTERVAL_END();
+            landed(hy);
         }
         if (it < n_int) {  // odd number of intervals
             read_block(hx, it);
             write_block(hy);
             BS_INTERVAL_END();
+            landed(hx);
             write_block(hx);
         } else {
             write_block(hy);

@@ -36,7 +36,7 @@ int main(int argc, char **argv)
         {   // the rotating three-chain-wavefront kernel (the product path)
             SweepPlan p8;
             if (plan_dma_sweep(a, sw.P, sw.n, r, n_cu, p8, false, kDmaLds - 1024)) {
-                for (int dbg : {0, 1, 2, 4, 5, 7, 16}) {
+                for (int dbg : {0, 1, 128, 256, 2, 4, 5, 7, 16}) {
                     p8.dbg = dbg; p8.clocks = clk;
                     float best = 1e9f;
                     for (int it = 0; it < 6; it++) {
