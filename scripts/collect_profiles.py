@@ -39,3 +39,38 @@ for f in ("bench_default.json", "bench_strict.json", "ubench.json"):
         shutil.copy(os.path.join(G, f), os.path.join(P, f"{R}_{f}"))
 json.dump(summary, open(os.path.join(P, f"{R}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
+
+# ---- render -> bloom -> sRGB8 pipeline (scripts/prof_rgb8.py): kernel stats + FETCH_SIZE / WRITE_SIZE per kernel ----
+src = os.path.join(G, "prof_rgb8", "rgb8_kernel_stats.csv")
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(P, f"{R}_rgb8_kernel_stats.csv"))
+SHORT = (("copyBuffer", "copyBuffer"), ("fillBuffer", "fillBuffer"), ("trace_frame_kernel", "trace_frame_kernel"), ("box_blur_sweep_rot", "box_blur_sweep_rot"),
+         ("box_blur_sweep_lds", "box_blur_sweep_lds"), ("bloom_combine_srgb8", "bloom_combine_srgb8"), ("srgb8_kernel", "srgb8_kernel"))
+rgb8 = collections.OrderedDict()
+for grp, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    fn = os.path.join(G, f"pmc_{grp}_rgb8", f"{grp}_counter_collection.csv")
+    if not os.path.exists(fn):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        if r["Counter_Name"] != counter:
+            continue
+        for key, name in SHORT:
+            if key in r["Kernel_Name"]:
+                agg[name].append(float(r["Counter_Value"]))
+                break
+    for name, v in agg.items():
+        d = rgb8.setdefault(name, {})
+        d[f"{counter}_KiB_per_launch"] = sum(v) / len(v)
+        d[f"{counter}_launches"] = len(v)
+for name, d in rgb8.items():
+    if "FETCH_SIZE_KiB_per_launch" in d and "WRITE_SIZE_KiB_per_launch" in d:
+        d["hbm_bytes_per_launch (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)"] = 1024 * (2 * d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"])
+if rgb8:
+    rgb8["_note"] = ("scripts/prof_rgb8.py under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes); a 1080p sweep reads and "
+                     "writes 49.8 MB each = 99.5 MB algorithmic")
+    json.dump(rgb8, open(os.path.join(P, f"{R}_rgb8_pmc_summary.json"), "w"), indent=1)
+for src, dst in (("bloom_ab_final.txt", "bloom_ab.txt"), ("sweep_probe_final.txt", "sweep_probe.txt"), ("configs_table.jsonl", "configs_table.jsonl"),
+                 ("bench_c5_animation.json", "bench_c5_animation.json")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, f"{R}_{dst}"))
