@@ -191,6 +191,23 @@ def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
     res["bs_render_rgb8"] = entry(med(lambda: bs.render_rgb8(cfg_obj, tree, out=pinned8), 5),
                                   "render + bloom + sRGB8 on the device, 6.2 MB RGB8 written into a page-locked host buffer by the last kernel "
                                   "(doRender up to the PNG encoder), blocking")
+    # Two frames in flight: consecutive frames alternate between two streams (what bs_render_batch does per context), so the end of
+    # one launch -- the ~0.3 ms in which its last tiles drain and the SIMDs empty -- overlaps the start of the next
+    out2 = torch.empty_like(out)
+    s2 = torch.cuda.Stream()
+    lanes = [(out, stream), (out2, s2)]
+    n2 = 20
+    for k in range(4):
+        o, s = lanes[k & 1]
+        bs.render_device(cfg, tree, o.data_ptr(), o.numel(), s.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n2):
+        o, s = lanes[k & 1]
+        bs.render_device(cfg, tree, o.data_ptr(), o.numel(), s.cuda_stream)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) * 1e3 / n2
+    res["two_streams"] = entry(ms2, f"{n2} frames resident in HBM, alternating between two streams (two launches in flight): wall time per frame")
     # STRICT mode of the same frame, image resident in HBM like the headline
     tree.set_mode(_lib.BS_MODE_STRICT)
     try:

@@ -725,6 +725,14 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
     return v;
 }
 
+#ifdef BS_TRACE_PROBE
+// Timeline probe (scripts/trace_timeline.py; never in the product build): per wavefront of the frame kernel, wall-clock stamps
+// (100 MHz, comparable across CUs) at kernel entry, first tile start, start and end of the last tile and at exit, the number of
+// tiles it traced, the iterations of the last one, and where it ran (HW_ID: SIMD, CU, SE; XCC_ID).
+constexpr int kProbeWords = 8, kProbeWaves = 8192;
+__device__ unsigned long long g_trace_probe[kProbeWords * kProbeWaves];
+#endif
+
 // Frame kernel: PERSISTENT wavefronts.  The grid is sized to fill the chip once (P.grid_blocks workgroups of 4
 // wavefronts, <= 4 per CU); every wavefront independently pulls 8x8-pixel tiles of traced rays off a device-wide
 // counter until the frame is done -- no workgroup barrier at all, no per-tile dispatch, one flush of the statistics per
@@ -747,6 +755,11 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     const LaneLds lds(s_lane, s_ints);
 
     const int lane = threadIdx.x & 63;
+#ifdef BS_TRACE_PROBE
+    const unsigned long long probe_t0 = wall_clock64();
+    unsigned long long probe_t1 = 0, probe_t2 = 0, probe_ts = 0;
+    unsigned probe_tiles = 0, probe_last_iters = 0;
+#endif
     int lx, ly;
     if (P.ss) {
         int q = lane >> 2, sub = lane & 3;
@@ -775,6 +788,9 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     // the end is harmless: indices >= n_tiles just end the loop.
     int next_tile = 0;
     if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
+#ifdef BS_TRACE_PROBE
+    probe_t1 = wall_clock64();
+#endif
     for (;;) {
         const int tile = __builtin_amdgcn_readfirstlane(next_tile);
         if (tile >= n_tiles) break;
@@ -785,7 +801,13 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 
         RayResult res;
         unsigned w_iters;
+#ifdef BS_TRACE_PROBE
+        probe_ts = wall_clock64();
+#endif
         trace_ray<FAST>(P, lds, inb, yi, xi, res, w_iters);
+#ifdef BS_TRACE_PROBE
+        probe_last_iters = w_iters;
+#endif
 
         if (P.ss) {
             const int base = lane & ~3;
@@ -813,6 +835,10 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         stat[4 * kBlock] += (unsigned)res.disk_hits;
         stat[5 * kBlock] += (unsigned)res.star_hits;
         a_iters += w_iters;
+#ifdef BS_TRACE_PROBE
+        probe_t2 = wall_clock64();
+        probe_tiles++;
+#endif
     }
     const unsigned s_steps = wave_sum(stat[0 * kBlock]), s_cap = wave_sum(stat[1 * kBlock]), s_hor = wave_sum(stat[2 * kBlock]),
                    s_esc = wave_sum(stat[3 * kBlock]), s_disk = wave_sum(stat[4 * kBlock]), s_star = wave_sum(stat[5 * kBlock]);
@@ -825,6 +851,16 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         if (s_disk) atomicAdd(&P.counters[4], (unsigned long long)s_disk);
         if (s_star) atomicAdd(&P.counters[5], (unsigned long long)s_star);
     }
+#ifdef BS_TRACE_PROBE
+    const unsigned gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (lane == 0 && gw < (unsigned)kProbeWaves) {
+        unsigned long long *q = g_trace_probe + (size_t)gw * kProbeWords;
+        q[0] = probe_t0; q[1] = probe_t1; q[2] = probe_t2; q[3] = wall_clock64(); q[4] = probe_tiles;
+        q[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID, all 32 bits
+        q[6] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) | ((unsigned long long)probe_last_iters << 8);  // XCC_ID[3:0]; iterations of the last tile
+        q[7] = probe_ts;  // start of the last tile
+    }
+#endif
 }
 
 // Test hook: trace an explicit list of traced-resolution pixels, one lane per listed ray.
@@ -925,6 +961,14 @@ int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+#ifdef BS_TRACE_PROBE
+extern "C" int bs_debug_trace_probe(unsigned long long *out, int n_words)
+{
+    const size_t bytes = sizeof(unsigned long long) * (size_t)(n_words < kProbeWords * kProbeWaves ? n_words : kProbeWords * kProbeWaves);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace_probe), bytes) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_trace(const TraceParams &p, int mode, void *stream)
 {
