@@ -34,6 +34,34 @@ def render_batch(cfgs: Sequence, trees: Sequence[StarTree], outs: Sequence[np.nd
     return outs
 
 
+def render_rgb8_batch(cfgs: Sequence[Config], trees: Sequence[StarTree], outs: Sequence[np.ndarray] = None) -> List[np.ndarray]:
+    """doRender for a list of scenes (app/Main.hs:68-77 -> :105-123) with everything up to the PNG encoder on the device
+    (`bs_render_rgb8_batch`): cfgs[i] -- a Config, whose scene carries its own bloomStrength / bloomDivider -- is rendered, bloomed
+    and mapped to RGB8 on trees[i % len(trees)], two frames in flight per tree.  Returns the (h, w, 3) uint8 images in order,
+    byte-identical to render_rgb8 frame by frame; `outs`: buffers to fill (page-locked ones from alloc_image are written in place)."""
+    if not trees:
+        raise ValueError("need at least one StarTree")
+    if any(not isinstance(c, Config) for c in cfgs):
+        raise TypeError("render_rgb8_batch takes Config objects (the scene's bloom parameters are part of the frame)")
+    cs = [_lib.make_config(c.to_bs_config()) for c in cfgs]
+    n = len(cs)
+    if outs is None:
+        outs = [np.empty((c.height, c.width, 3), np.uint8) for c in cs]
+    else:
+        outs = list(outs)
+        if len(outs) != n or any(o.shape != (c.height, c.width, 3) or o.dtype != np.uint8 or not o.flags["C_CONTIGUOUS"] for o, c in zip(outs, cs)):
+            raise ValueError("outs must hold one C-contiguous uint8 (h, w, 3) array per frame")
+    if n == 0:
+        return outs
+    arr = (_lib.BsConfig * n)(*cs)
+    strengths = (C.c_double * n)(*[float(c.scene.bloomStrength) for c in cfgs])
+    dividers = (C.c_int * n)(*[int(c.scene.bloomDivider) for c in cfgs])
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
+    _lib.check(_lib.lib().bs_render_rgb8_batch(ctxs, len(trees), arr, n, strengths, dividers, ptrs), "bs_render_rgb8_batch")
+    return outs
+
+
 def render_split(cfg, trees: Sequence[StarTree], out: np.ndarray = None) -> np.ndarray:
     """ONE frame over several StarTrees (one per GPU): tree k renders the k-th contiguous band of rows (`bs_render_split`).
     Bit-identical to render(cfg, trees[0]).  `out`: the (h, w, 3) float64 buffer to fill; a page-locked one (alloc_image) is

@@ -86,6 +86,8 @@ struct bs_ctx {
     bool post_busy = false;
     unsigned char *d_u8 = nullptr;
     size_t u8_cap = 0;
+    unsigned char *d_u8b = nullptr;  // bs_render_rgb8_batch: staging of the frame on the second stream (pageable outputs only)
+    size_t u8b_cap = 0;
     double *d_srgb_table = nullptr;  // 257 thresholds of the sRGB8 pixel map (bs::srgb8_thresholds)
     hipStream_t stream = nullptr;
     hipEvent_t ev_u0 = nullptr, ev_u1 = nullptr;  // bs_debug_ubench timing
@@ -383,6 +385,7 @@ void bs_destroy(bs_ctx *ctx)
         for (double *b : ctx->d_post)
             if (b) (void)hipFree(b);
         if (ctx->d_u8) (void)hipFree(ctx->d_u8);
+        if (ctx->d_u8b) (void)hipFree(ctx->d_u8b);
         if (ctx->ev_post) (void)hipEventDestroy(ctx->ev_post);
         if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -757,6 +760,94 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
     for (int c = 0; c < n_ctx; c++) {
         th.emplace_back([&, c]() {
             rcs[c] = render_frames_pipelined(ctxs[c], cfgs, outs, c, n_frames, n_ctx);
+            if (rcs[c]) errs[c] = g_err;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n_ctx; c++)
+        if (rcs[c]) return fail(rcs[c], errs[c]);
+    return BS_OK;
+}
+
+// doRender (app/Main.hs:105-123) for frames first, first+step, ... on one context, two frames in flight: frame k runs render ->
+// bloom -> sRGB8 on compute stream k & 1 with its own f64 image, so frame k+1's trace kernel fills the SIMDs frame k's last
+// tiles leave (the fixed ~0.25 ms of a launch) and frame k's bloom runs on the CUs the next trace kernel frees
+// first.  The blur scratch is one pair per context: the bloom of frame k+1 is ordered behind frame k's by acquire/release_post.
+static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, unsigned char *const *outs,
+                                        int first, int n_frames, int step)
+{
+    if (first >= n_frames) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t need = 0;
+    for (int i = first; i < n_frames; i += step) {
+        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
+        const double st = strengths ? strengths[i] : 0.0;
+        if (st != 0 && (!dividers || dividers[i] <= 0 || cfgs[i].width / dividers[i] == 0))
+            return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+        need = std::max(need, (size_t)cfgs[i].width * cfgs[i].height * 3);
+    }
+    auto grow = [&](auto *&buf, size_t &cap, size_t elems) {
+        if (cap >= elems) return true;
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipMalloc((void **)&buf, elems * sizeof(*buf)) != hipSuccess) return false;
+        cap = elems;
+        return true;
+    };
+    if (!grow(ctx->d_img, ctx->img_cap, need) || !grow(ctx->d_img2, ctx->img2_cap, need) || !grow(ctx->d_u8, ctx->u8_cap, need) ||
+        !grow(ctx->d_u8b, ctx->u8b_cap, need))
+        return fail(BS_ENOMEM, "hipMalloc image failed");
+    int rc = ensure_post(ctx, need);
+    if (rc) return rc;
+    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->ev_frame)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double *img[2] = {ctx->d_img, ctx->d_img2};
+    unsigned char *stage[2] = {ctx->d_u8, ctx->d_u8b};
+    hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+    StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
+    int k = 0;
+    for (int i = first; i < n_frames; i += step, k++) {
+        const int b = k & 1;
+        if (k >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
+        const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
+        unsigned char *target = stage[b];
+        if (double *alias = device_alias_of_pinned(ctx, outs[i], n)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
+        rc = enqueue_render(ctx, &cfgs[i], img[b], n, cs[b], 0, -1, true, true, /*quiet=*/true);
+        if (rc) return rc;
+        const double st = strengths ? strengths[i] : 0.0;
+        if (st != 0) {
+            rc = acquire_post(ctx, cs[b]);
+            if (rc) return rc;
+            if (bs::launch_bloom_srgb8(img[b], target, ctx->d_post[0], ctx->d_post[1], cfgs[i].width, cfgs[i].height, st, dividers[i], ctx->n_cu,
+                                       ctx->d_srgb_table, cs[b]))
+                return fail(BS_EDEVICE, "bloom launch failed");
+            rc = release_post(ctx, cs[b]);
+            if (rc) return rc;
+        } else if (bs::launch_srgb8(img[b], target, n, ctx->d_srgb_table, cs[b])) {
+            return fail(BS_EDEVICE, "srgb8 launch failed");
+        }
+        if (target == stage[b]) HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, cs[b]));
+        HIP_TRY(hipEventRecord(ctx->ev_frame[b], cs[b]));
+    }
+    HIP_TRY(hipStreamSynchronize(cs[0]));
+    HIP_TRY(hipStreamSynchronize(cs[1]));
+    return BS_OK;
+}
+
+int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                         unsigned char *const *outs)
+{
+    if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
+    for (int c = 0; c < n_ctx; c++)
+        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+    std::vector<int> rcs(n_ctx, BS_OK);
+    std::vector<std::string> errs(n_ctx);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n_ctx; c++) {
+        th.emplace_back([&, c]() {
+            rcs[c] = render_rgb8_frames_pipelined(ctxs[c], cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx);
             if (rcs[c]) errs[c] = g_err;
         });
     }

@@ -112,7 +112,7 @@ def render_sharded(n_frames: int, render_frame: Callable[[int], "object"], rank:
 def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: Optional[int] = 0, out_dir: Optional[str] = None,
                      basename: str = "frame", dist=None):
     """BASELINE configs[4] end to end: the frames of an Animation (src/Animation.hs generateFrames), frame i on rank
-    i % world, each through the device pipeline of doRender (render -> bloom -> sRGB8, `bs_render_rgb8`), gathered as
+    i % world, each through the device pipeline of doRender (render -> bloom -> sRGB8, `bs_render_rgb8_batch`), gathered as
     RGB8 on `gather_to` (6.2 MB per 1080p frame instead of 49.8 MB of f64).  With out_dir, every rank also PNG-encodes the
     frames it rendered (`<basename>_<zero-padded index>.png`, the naming of app/Animate.hs:55-56 with the padding done
     right -- SURVEY Appendix F.7).  Returns the ordered list of (h, w, 3) uint8 tensors on the root, None elsewhere."""
@@ -121,7 +121,8 @@ def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: 
     import torch
 
     from .animation import generate_frames, validate_keyframes
-    from .raytracer import render_rgb8, write_png
+    from .batch import render_rgb8_batch
+    from .raytracer import write_png
 
     validate_keyframes(animation.keyframes)
     frames = generate_frames(animation)
@@ -129,8 +130,19 @@ def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: 
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
 
+    # This rank's frames go through the device pipeline kPipe at a time (`bs_render_rgb8_batch`: two frames in flight, the next
+    # frame's trace kernel overlaps this frame's tail and bloom); render_sharded then asks for them in order.
+    kPipe = 16
+    mine = shard_frames(len(frames), rank, world)
+    ready = {}
+
     def one(i):
-        rgb8 = render_rgb8(frames[i], tree)
+        if i not in ready:
+            pos = mine.index(i)
+            chunk = mine[pos:pos + kPipe]
+            for j, img in zip(chunk, render_rgb8_batch([frames[j] for j in chunk], [tree])):
+                ready[j] = img
+        rgb8 = ready.pop(i)
         if out_dir:
             write_png(rgb8, os.path.join(out_dir, f"{basename}_{i:0{width}d}.png"))
         return torch.from_numpy(rgb8)

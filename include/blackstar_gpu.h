@@ -177,6 +177,16 @@ int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
  * instead of 49.8 MB at 1080p).  Blocking.  out_rgb8: interleaved RGB8, row-major. */
 int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_rgb8, size_t out_bytes);
 
+/* Batch mode with the whole of doRender on the device (app/Main.hs:68-77 calls doRender, :105-123, for every scene of a directory:
+ * render, bloom with the scene's own bloomStrength / bloomDivider, writeImg): frame i is rendered by ctxs[i % n_ctx] (one host
+ * thread per context) and leaves the GPU as height*width*3 bytes of RGB8 in outs[i].  bloom_strengths[i] == 0 (or a NULL array)
+ * skips the bloom of that frame like the reference does; bloom_dividers is only read where the strength is not 0.  Per context two
+ * frames are in flight on two streams: the next frame's trace kernel takes over the SIMDs this frame's last tiles leave, and this
+ * frame's bloom runs on the first CUs the next trace kernel frees.  Page-locked outs[i] (bs_host_alloc) are written by the last
+ * kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame; bs_stats is not updated. */
+int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
+                         const int *bloom_dividers, unsigned char *const *outs);
+
 /* Test hook: trace the given traced-resolution pixels (y,x pairs) and return per-ray records (host buffers). */
 int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out);
 

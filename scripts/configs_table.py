@@ -62,3 +62,20 @@ bs.render_batch(cfgs, [tree], outs=outs)
 dt = time.perf_counter() - t0
 print(json.dumps({"cfg": "C5 batch: 24 frames (every 25th of 600) through bs_render_batch, page-locked buffers, one GPU", "mode": "fast",
                   "ms_per_frame": round(dt * 1e3 / len(cfgs), 4), "Mpixel_s": round(len(cfgs) * 1920 * 1080 / dt / 1e6, 1)}), flush=True)
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
+anim.nFrames = 600
+frames = bs.generate_frames(anim)[::25]
+outs8 = [bs.alloc_image(tree, 1080, 1920, dtype=np.uint8) for _ in frames]
+bs.render_rgb8_batch(frames[:2], [tree], outs=outs8[:2])
+t0 = time.perf_counter()
+for c, o in zip(frames, outs8):
+    bs.render_rgb8(c, tree, out=o)
+dt1 = time.perf_counter() - t0
+t0 = time.perf_counter()
+bs.render_rgb8_batch(frames, [tree], outs=outs8)
+dt2 = time.perf_counter() - t0
+print(json.dumps({"cfg": "C5 doRender on the device: 24 frames (every 25th of 600), render -> bloom -> sRGB8, RGB8 into page-locked buffers, one GPU", "mode": "fast",
+                  "bs_render_rgb8_frame_by_frame_ms": round(dt1 * 1e3 / len(frames), 4), "bs_render_rgb8_batch_ms_per_frame": round(dt2 * 1e3 / len(frames), 4),
+                  "Mpixel_s_batch": round(len(frames) * 1920 * 1080 / dt2 / 1e6, 1)}), flush=True)

@@ -467,6 +467,42 @@ def test_star_colours_in_all_three_hsi_sectors(oracle):
     t.close()
 
 
+def test_render_rgb8_batch_matches_frame_by_frame(tree, oracle):
+    """bs_render_rgb8_batch (doRender for a directory of scenes, two frames in flight per context): byte-identical to
+    bs_render_rgb8 frame by frame -- frames of different sizes, with and without bloom, into pageable and page-locked buffers --
+    and a bad frame in the middle fails the call with the frames before it delivered and nothing in flight afterwards."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = bs.Config.from_file(os.path.join(root, "scenes", "default-aa.yaml"))
+    anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
+    anim.nFrames = 7
+    cfgs = []
+    for i, c in enumerate(bs.generate_frames(anim)):
+        c = c.with_resolution(*((160, 90), (128, 96), (96, 54))[i % 3])
+        c.scene.bloomStrength = 0.0 if i in (2, 5) else 0.1 + 0.05 * i
+        c.scene.bloomDivider = 25 if i % 2 else 12
+        cfgs.append(c)
+    cfgs.append(base.with_resolution(160, 90))
+    want = [bs.render_rgb8(c, tree) for c in cfgs]
+    got = bs.render_rgb8_batch(cfgs, [tree])
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), f"frame {i}"
+    c0 = cfgs[0]
+    assert np.array_equal(want[0], oracle.srgb8(oracle.bloom(c0.scene.bloomStrength, c0.scene.bloomDivider, bs.render(c0, tree))))
+    outs = [bs.alloc_image(tree, w.shape[0], w.shape[1], dtype=np.uint8) if i % 2 else np.zeros_like(w) for i, w in enumerate(want)]
+    bs.render_rgb8_batch(cfgs, [tree], outs=outs)  # page-locked buffers are written in place by the last kernel
+    for i, (g, w) in enumerate(zip(outs, want)):
+        assert np.array_equal(g, w), f"frame {i} (buffers supplied)"
+    assert bs.render_rgb8_batch([], [tree]) == []
+    import copy
+    bad = copy.deepcopy(cfgs)
+    bad[4].scene.bloomDivider = 100000  # width `div` divider == 0: the reference crashes there (ImageFilters.hs:59)
+    outs = [np.full_like(w, 7) for w in want]
+    with pytest.raises(_lib.BlackstarError, match="bloom radius"):
+        bs.render_rgb8_batch(bad, [tree], outs=outs)
+    assert all((o == 7).all() for o in outs)  # validated up front: nothing was rendered
+    assert np.array_equal(bs.render_rgb8(cfgs[1], tree), want[1])  # the context is still usable
+
+
 def test_render_animation_single_rank(tree, tmp_path, oracle):
     """configs[4] in miniature: 5 interpolated cameras of default-ani.yaml through the device pipeline, world = 1."""
     from blackstar_amd.distributed import render_animation
