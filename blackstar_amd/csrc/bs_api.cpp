@@ -45,6 +45,7 @@ struct bs_ctx {
     int n_cu = 256;
     int blocks_per_cu = 4;       // resident workgroups per CU (VGPR/LDS-limited); env BLACKSTAR_BLOCKS_PER_CU for A/B builds
     int stagger_cycles = 16000;  // first-tile phase offset per SIMD slot (env BLACKSTAR_STAGGER overrides; 0 = off)
+    int stagger_min_tiles = 6;   // ... applied to launches of at least this many tiles per resident wavefront (env BLACKSTAR_STAGGER_MIN_TILES; C2 = 7.9 tiles per wavefront gains 2 %, frames of 3-5 do not)
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;
     bs::StarColor *d_colors = nullptr;
@@ -119,7 +120,7 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 
         const long waves = (long)ctx->n_cu * 4 * ctx->blocks_per_cu;  // resident wavefronts: blocks_per_cu workgroups of 4 per CU
         p.blocks_per_slot = ctx->n_cu;
         p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
-        p.stagger_cycles = tiles >= 8 * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs many tiles
+        p.stagger_cycles = tiles >= (long)ctx->stagger_min_tiles * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs several tiles
     }
     p.n_entries = (int32_t)ctx->n_entries;
     p.nodes = ctx->d_nodes;
@@ -291,6 +292,7 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     ctx->device = device;
     ctx->n_stars = n_stars;
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
+    if (const char *m = std::getenv("BLACKSTAR_STAGGER_MIN_TILES")) ctx->stagger_min_tiles = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
