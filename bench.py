@@ -59,7 +59,11 @@ def cpu_baseline(cfg, star_bytes, budget_s):
     h = max(9, w * cfg["height"] // cfg["width"])
     sample = scenes.with_res(cfg, w, h)
     _, st = c_oracle.render(sample, ix, threads=threads)
-    return {"value": w * h / st["seconds"] / 1e6, "unit": "Mpixel/s", "cores": int(st["threads"]), "kind": "port",
+    # BASELINE configs[0] (the reference's own CPU-runnable case), whole: default.yaml at 640x480, no supersampling, no star map
+    _, st1 = c_oracle.render(scenes.with_res(scenes.DEFAULT, 640, 480), c_oracle.Index(None), threads=threads)
+    c1 = {"value": 640 * 480 / st1["seconds"] / 1e6, "unit": "Mpixel/s", "seconds": st1["seconds"], "rays": int(st1["rays"]),
+          "config": "scenes/default.yaml 640x480, no supersampling, no star map (BASELINE configs[0]), the whole frame"}
+    return {"value": w * h / st["seconds"] / 1e6, "unit": "Mpixel/s", "cores": int(st["threads"]), "kind": "port", "configs0": c1,
             "rays_per_s": st["rays"] / st["seconds"], "seconds": st["seconds"],
             "sample": f"default-aa.yaml camera at {w}x{h} output px (4x supersampled = {st['rays']} rays), same 470k-star catalogue, "
                       f"C restatement of the reference CPU path (oracle/blackstar_oracle.c, -O2, pthreads over rows)"}
