@@ -934,6 +934,20 @@ def test_batch_split_and_stats_on_every_visible_device(catalogue_bytes):
             assert np.array_equal(a, b)
         big = scenes.with_res(scenes.LENSING_DISK, 160, 97)
         assert np.array_equal(bs.render_split(big, trees), bs.render(big, trees[0]))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
+        anim.nFrames = 2 * n + 3
+        anim.scene.resolution = (96, 54)
+        frames = bs.generate_frames(anim)
+        ref8 = [bs.render_rgb8(c, trees[0]) for c in frames]
+        two_on_one = [trees[0], bs.StarTree(stars, device=0)]  # two contexts, two host threads, even on a one-GPU box
+        try:
+            two_on_one[1].set_mode(_lib.BS_MODE_FAST)
+            for group in (trees, two_on_one):
+                for a, b in zip(bs.render_rgb8_batch(frames, group), ref8):
+                    assert np.array_equal(a, b)
+        finally:
+            two_on_one[1].close()
         for d, t in enumerate(trees):  # every device renders and reports on its own
             img = bs.render(cfgs[0], t)
             assert np.array_equal(img, ref[0]) and t.stats()["rays"] == 4 * 96 * 54
