@@ -100,6 +100,10 @@ def parse_args():
     ap.add_argument("--gather", action="store_true",
                     help="N>1: also gather every rank's last frame to rank 0 inside the timed region (off by default: the path "
                          "shards by frame and has no exchange step; frames stay in the HBM of the GPU that rendered them, as at N=1)")
+    ap.add_argument("--streams", type=int, choices=[1, 2], default=None,
+                    help="launches in flight per GPU: consecutive frames alternate between this many streams (and output images). "
+                         "Default 1 for default-aa (per-launch event times, rocprofv3 kernel durations and ms_per_step stay one number), "
+                         "2 for the animation workload (independent frames: the next frame's launch fills the SIMDs this frame's last tiles leave)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bs_render / bs_render_rgb8 / STRICT / ubench legs at N=1")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -234,6 +238,7 @@ def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
 
 
 def result_line(args, world, launcher, value, dt, W, H, frames_cfg, st, kernel_ms, extra_cfg=None, peak_measured=None):
+    overlapped = bool(extra_cfg) and extra_cfg.get("launches_in_flight_per_gpu", 1) > 1
     cfgd = {"workload": WORKLOAD_C3 if frames_cfg is None else WORKLOAD_C5, "mode": args.mode, "frames_per_step_per_gpu": 1,
             "parallelism": f"frame-sharded x{world}", "launcher": launcher,
             "image": "RGB f64 resident in HBM (no D2H in the timed region)"}
@@ -248,7 +253,10 @@ def result_line(args, world, launcher, value, dt, W, H, frames_cfg, st, kernel_m
         "rays_per_s": frames * st["rays"] / dt, "steps_per_ray": st["steps"] / st["rays"],
         "lane_efficiency": st["steps"] / (64.0 * st["wave_iters"]),
         "kernel_ms": kernel_ms, "kernel_ms_last_hipevent": st["kernel_ms"],
-        "roofline": roofline_block(args, st, kernel_ms, W, H, peak_measured),
+        # launches in flight overlap: a launch's own duration then says nothing about the rate; the step time does
+        "roofline": dict(roofline_block(args, st, kernel_ms if not overlapped else dt / args.steps * 1e3, W, H, peak_measured),
+                         time_basis="mean launch duration (HIP events)" if not overlapped else
+                         "ms_per_step (launches overlap: two in flight per GPU; their own durations are about twice this)"),
     }
 
 
@@ -289,14 +297,19 @@ def run_ranks(args):
 
     out = torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream()
-    counter = {"i": 0}
+    n_streams = args.streams or (2 if frames_cfg is not None else 1)
+    lanes = [(out, stream)] + [(torch.empty_like(out), torch.cuda.Stream()) for _ in range(n_streams - 1)]
+    counter = {"i": 0, "k": 0}
 
     def step():
         c = cfg
         if frames_cfg is not None:  # frame i of the animation goes to rank i % world
             c = frames_cfg[(counter["i"] * world + rank) % len(frames_cfg)]
             counter["i"] += 1
-        bs.render_device(c, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
+        o, s = lanes[counter["k"] % n_streams]
+        counter["k"] += 1
+        bs.render_device(c, tree, o.data_ptr(), o.numel(), s.cuda_stream)
+        return s
 
     def fence():
         if world > 1:
@@ -317,9 +330,10 @@ def run_ranks(args):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
-        a.record(stream)
+        s = lanes[counter["k"] % n_streams][1]
+        a.record(s)
         step()
-        b.record(stream)
+        b.record(s)
     t_gather = None
     if world > 1 and args.gather:
         torch.cuda.synchronize()
@@ -349,7 +363,10 @@ def run_ranks(args):
         if world == 1 and not args.no_boundary and frames_cfg is None:
             peak = measure_peak(tree, _lib)
         extra = {"backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else "none (single rank)",
-                 "devices_visible": ndev, "oversubscribed": world > ndev}
+                 "devices_visible": ndev, "oversubscribed": world > ndev, "launches_in_flight_per_gpu": n_streams}
+        if n_streams > 1:
+            extra["launches_in_flight_note"] = ("consecutive frames alternate between two streams and share the GPU, so kernel_ms "
+                                                "(per-launch event time) exceeds ms_per_step")
         res = result_line(args, world, "torchrun-env (one process per GPU)" if world > 1 or "WORLD_SIZE" in os.environ else "single-process",
                           value, dt, W, H, frames_cfg, st, kernel_ms, extra, peak)
         res["per_rank_ms_per_step"] = per_rank_ms
