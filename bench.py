@@ -401,21 +401,29 @@ def run_single_process(args):
     W, H = cfg["width"], cfg["height"]
     star_bytes = synthetic.ppm_catalogue_bytes()
     stars = bs.read_map(star_bytes)
-    trees, outs, streams = [], [], []
+    n_streams = args.streams or (2 if frames_cfg is not None else 1)
+    trees, outs, streams, lanes = [], [], [], []
     for d in devs:
         t = bs.StarTree(stars, device=d)
         t.set_mode(_lib.BS_MODE_FAST if args.mode == "fast" else _lib.BS_MODE_STRICT)
         trees.append(t)
         with torch.cuda.device(d):
-            outs.append(torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{d}"))
-            streams.append(torch.cuda.Stream(device=d))
-    counter = {"i": 0}
+            ln = [(torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{d}"), torch.cuda.Stream(device=d)) for _ in range(n_streams)]
+        lanes.append(ln)
+        outs.append(ln[0][0])
+        streams.append(ln[0][1])
+    counter = {"i": 0, "k": [0] * world}
+
+    def lane(k):  # the (image, stream) device k's NEXT frame goes to
+        return lanes[k][counter["k"][k] % n_streams]
 
     def step(k):
         c = cfg
         if frames_cfg is not None:
             c = frames_cfg[(counter["i"] * world + k) % len(frames_cfg)]
-        bs.render_device(c, trees[k], outs[k].data_ptr(), outs[k].numel(), streams[k].cuda_stream)
+        o, st_ = lane(k)
+        counter["k"][k] += 1
+        bs.render_device(c, trees[k], o.data_ptr(), o.numel(), st_.cuda_stream)
 
     def fence():
         for d in sorted(set(devs)):
@@ -446,9 +454,10 @@ def run_single_process(args):
     for s in range(args.steps):
         for k in range(world):
             with torch.cuda.device(devs[k]):
-                ev[k][s][0].record(streams[k])
+                st_ = lane(k)[1]
+                ev[k][s][0].record(st_)
                 step(k)
-                ev[k][s][1].record(streams[k])
+                ev[k][s][1].record(st_)
         counter["i"] += 1
     t_gather = None
     if args.gather:
@@ -461,11 +470,11 @@ def run_single_process(args):
     dt = time.perf_counter() - t0  # one clock for all devices: this IS the max over "ranks"
     st = trees[0].stats()
     kms = [[a.elapsed_time(b) for a, b in ev[k]] for k in range(world)]
-    per_rank_ms = [ev[k][0][0].elapsed_time(ev[k][-1][1]) / args.steps for k in range(world)]
+    per_rank_ms = [dt / args.steps * 1e3] * world if n_streams > 1 else [ev[k][0][0].elapsed_time(ev[k][-1][1]) / args.steps for k in range(world)]
     kernel_ms = float(np.mean(kms[0]))
     value = args.steps * world * W * H / dt / 1e6
     extra = {"backend": "none (one process, one bs_ctx + stream per device; frames never leave their GPU)",
-             "devices_visible": ndev, "oversubscribed": world > ndev, "devices": devs}
+             "devices_visible": ndev, "oversubscribed": world > ndev, "devices": devs, "launches_in_flight_per_gpu": n_streams}
     res = result_line(args, world, "single-process (N contexts)", value, dt, W, H, frames_cfg, st, kernel_ms, extra)
     res["per_rank_ms_per_step"] = per_rank_ms
     res["per_rank_kernel_ms"] = [float(np.mean(x)) for x in kms]
