@@ -16,7 +16,7 @@ timeout 100 python scripts/bloom_ab.py 2>&1 | grep -v amdgpu > gpurun_out/bloom_
 timeout 60 scripts/probe/sweep_probe > gpurun_out/sweep_probe_final.txt 2>&1
 cd /tmp
 for m in fast strict; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$m -o $m -- python $R/bench.py --steps 10 --warmup 2 --mode $m --cpu-seconds 0 --no-boundary > $R/gpurun_out/prof_$m.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$m -o $m -- python $R/bench.py --mode $m --cpu-seconds 0 --no-boundary > $R/gpurun_out/prof_$m.log 2>&1
 done
 for m in fast strict; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq_$m -o sq -- python $R/scripts/prof_frame.py --mode $m --frames 3 > $R/gpurun_out/pmc_sq_$m.log 2>&1
