@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Soak of the pipelined host paths: many rounds of bs_render_batch / bs_render_rgb8_batch / multi-stream bs_render_device with
+random frame sizes, buffer kinds (pageable / page-locked) and bloom settings, every result compared byte for byte with the
+frame-by-frame blocking calls.  Looks for ordering bugs (streams, events, shared scratch) that a single test run might miss."""
+import copy
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blackstar_amd as bs  # noqa: E402
+from blackstar_amd import _lib, synthetic  # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+stars = bs.read_map(synthetic.ppm_catalogue_bytes())
+trees = [bs.StarTree(stars), bs.StarTree(stars)]
+for t in trees:
+    t.set_mode(_lib.BS_MODE_FAST)
+anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
+anim.nFrames = 600
+frames = bs.generate_frames(anim)
+t_end = time.time() + seconds
+rounds = checked = 0
+while time.time() < t_end:
+    n = int(rng.integers(1, 9))
+    cfgs = []
+    for _ in range(n):
+        c = copy.deepcopy(frames[int(rng.integers(0, 600))])
+        w = int(rng.integers(8, 200)) * 2
+        h = int(rng.integers(8, 120)) * (2 if rng.random() < 0.7 else 1) + int(rng.random() < 0.2)
+        c.scene.resolution = (w, h)
+        c.scene.supersampling = bool(rng.random() < 0.6)
+        c.scene.bloomStrength = 0.0 if rng.random() < 0.25 else float(rng.uniform(0.05, 0.5))
+        c.scene.bloomDivider = int(rng.integers(3, 40))
+        if w // c.scene.bloomDivider == 0:
+            c.scene.bloomDivider = 2
+        cfgs.append(c)
+    use = trees if rng.random() < 0.5 else trees[:1]
+    want8 = [bs.render_rgb8(c, trees[0]) for c in cfgs]
+    want = [bs.render(c.to_bs_config(), trees[0]) for c in cfgs]
+    outs8 = [bs.alloc_image(use[i % len(use)], *w8.shape[:2], dtype=np.uint8) if rng.random() < 0.5 else np.zeros_like(w8) for i, w8 in enumerate(want8)]
+    got8 = bs.render_rgb8_batch(cfgs, use, outs=outs8)
+    outs = [bs.alloc_image(use[i % len(use)], *wf.shape[:2]) if rng.random() < 0.5 else np.zeros_like(wf) for i, wf in enumerate(want)]
+    got = bs.render_batch([c.to_bs_config() for c in cfgs], use, outs=outs)
+    for i in range(n):
+        assert np.array_equal(got8[i], want8[i]), f"round {rounds}: rgb8 batch frame {i} differs ({cfgs[i].scene.resolution})"
+        assert np.array_equal(got[i], want[i]), f"round {rounds}: f64 batch frame {i} differs"
+    # the same frames enqueued on as many streams as frames, no synchronisation in between, plus bloom on each stream
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    dev = [torch.empty(wf.shape, dtype=torch.float64, device="cuda:0") for wf in want]
+    L = _lib.lib()
+    for c, d, s in zip(cfgs, dev, streams):
+        bs.render_device(c.to_bs_config(), trees[0], d.data_ptr(), d.numel(), s.cuda_stream)
+        if c.scene.bloomStrength != 0:
+            hh, ww = d.shape[:2]
+            _lib.check(L.bs_bloom_device(trees[0].handle, d.data_ptr(), d.data_ptr(), ww, hh, float(c.scene.bloomStrength), int(c.scene.bloomDivider),
+                                         C.c_void_p(s.cuda_stream)), "bloom on a stream")
+    torch.cuda.synchronize()
+    for i, (c, d) in enumerate(zip(cfgs, dev)):
+        ref = want[i] if c.scene.bloomStrength == 0 else bs.bloom(float(c.scene.bloomStrength), int(c.scene.bloomDivider), want[i], trees[0])
+        assert np.array_equal(d.cpu().numpy(), ref), f"round {rounds}: multi-stream frame {i} differs"
+    rounds += 1
+    checked += 3 * n
+print(f"soak: {rounds} rounds, {checked} frames compared, all identical, {seconds:.0f} s")
