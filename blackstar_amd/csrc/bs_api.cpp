@@ -749,11 +749,21 @@ static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *c
     return BS_OK;
 }
 
+// every context of a batch / split call is driven by its own host thread: the same context twice would be driven by two
+static int distinct_contexts(bs_ctx *const *ctxs, int n_ctx)
+{
+    for (int c = 0; c < n_ctx; c++) {
+        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+        for (int d = 0; d < c; d++)
+            if (ctxs[d] == ctxs[c]) return fail(BS_EINVAL, "the same context appears twice (one context per device, each named once)");
+    }
+    return BS_OK;
+}
+
 int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs)
 {
     if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
-    for (int c = 0; c < n_ctx; c++)
-        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     // One host thread per context (= per device); frame i goes to context i % n_ctx.  No data-path
     // collective: frames are independent (app/Main.hs:72-77 renders them one after another).
     std::vector<int> rcs(n_ctx, BS_OK);
@@ -842,8 +852,7 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
                          unsigned char *const *outs)
 {
     if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
-    for (int c = 0; c < n_ctx; c++)
-        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
     std::vector<std::thread> th;
@@ -862,8 +871,7 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
 int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
 {
     if (!ctxs || n_ctx <= 0 || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
-    for (int c = 0; c < n_ctx; c++)
-        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
     if (out_doubles < (size_t)cfg->width * cfg->height * 3) return fail(BS_EINVAL, "output buffer too small");
     // Context c renders the c-th of n contiguous row bands (sizes differ by at most one row; contexts beyond the number

@@ -150,7 +150,8 @@ int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double
  * frame i is rendered by ctxs[i % n_ctx] (one context per device, frames sharded round-robin, one host thread per
  * context); outs[i] is a host buffer of cfgs[i].height*width*3 doubles.  Per context two frames are in flight (two device
  * images, two compute streams, one copy stream): frame k's device-to-host copy and its end-of-frame tail overlap frame
- * k+1's kernel.  bs_stats is not updated by batch frames. */
+ * k+1's kernel.  bs_stats is not updated by batch frames.  The contexts must be distinct (BS_EINVAL otherwise: each is driven by
+ * its own host thread); the same holds for bs_render_split and bs_render_rgb8_batch. */
 int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs);
 
 /* ---- "next" rows: the two steps after render in app/Main.hs:113-123, kept on the device ---- */

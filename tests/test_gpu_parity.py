@@ -493,6 +493,10 @@ def test_render_rgb8_batch_matches_frame_by_frame(tree, oracle):
     for i, (g, w) in enumerate(zip(outs, want)):
         assert np.array_equal(g, w), f"frame {i} (buffers supplied)"
     assert bs.render_rgb8_batch([], [tree]) == []
+    with pytest.raises(_lib.BlackstarError, match="appears twice"):  # one host thread per context: the same one twice is refused
+        bs.render_rgb8_batch(cfgs, [tree, tree])
+    with pytest.raises(_lib.BlackstarError, match="appears twice"):
+        bs.render_batch([c.to_bs_config() for c in cfgs], [tree, tree])
     import copy
     bad = copy.deepcopy(cfgs)
     bad[4].scene.bloomDivider = 100000  # width `div` divider == 0: the reference crashes there (ImageFilters.hs:59)
