@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BLACKSTAR_LIB") or os.path.join(_HERE, "libblackstar_gpu.so")  # BLACKSTAR_LIB: A/B builds of the same ABI
 
 BS_MODE_STRICT, BS_MODE_FAST = 0, 1
+BS_ABI_VERSION = 2  # include/blackstar_gpu.h
 
 
 class BsConfig(C.Structure):
@@ -27,7 +28,7 @@ class BsConfig(C.Structure):
 class BsStats(C.Structure):
     """struct bs_stats_t."""
     _fields_ = [(k, C.c_uint64) for k in ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits", "wave_iters")] + \
-               [("kernel_ms", C.c_double), ("wall_ms", C.c_double)]
+               [("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("effective_mode", C.c_int32), ("zero_copy", C.c_int32)]
 
 
 # struct bs_star / struct bs_ray_record as numpy structured dtypes (same layout as the C structs)
@@ -39,7 +40,7 @@ RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4
 SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
            "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
            "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots",
-           "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch")
+           "bs_effective_mode", "bs_validate_config", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch")
 
 _lib = None
 
@@ -81,6 +82,10 @@ def lib() -> C.CDLL:
                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     _share_hip_runtime_with_torch()
     L = C.CDLL(SO_PATH)
+    L.bs_abi_version.restype = C.c_int
+    if L.bs_abi_version() != BS_ABI_VERSION:  # a stale build of the same name: fail here, not at some later symbol lookup or struct read
+        raise BlackstarError(f"{SO_PATH} has ABI version {L.bs_abi_version()}, this binding was written against {BS_ABI_VERSION}: rebuild it "
+                             "(python -c 'import __graft_entry__ as g; g.build()')")
     vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
     L.bs_create.restype = vp
     L.bs_create.argtypes = [C.c_int, vp, sz]
@@ -107,6 +112,8 @@ def lib() -> C.CDLL:
     L.bs_star_lookup.argtypes = [vp, dp, dp, vp, sz, vp, vp]
     L.bs_set_mode.argtypes = [vp, C.c_int]
     L.bs_get_mode.argtypes = [vp]
+    L.bs_effective_mode.argtypes = [vp, C.POINTER(BsConfig)]
+    L.bs_validate_config.argtypes = [C.POINTER(BsConfig)]
     L.bs_set_max_steps.argtypes = [vp, C.c_int]
     L.bs_stats.argtypes = [vp, C.POINTER(BsStats)]
     L.bs_last_error.restype = C.c_char_p

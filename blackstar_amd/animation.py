@@ -11,7 +11,7 @@ from typing import Any, List
 
 import yaml
 
-from .config_file import Camera, Config, ConfigError, Scene
+from .config_file import Camera, Config, ConfigError, Scene, load_yaml
 
 
 @dataclass
@@ -55,7 +55,7 @@ class Animation:
     def from_file(path: str) -> "Animation":
         try:
             with open(path, "r", encoding="utf-8") as f:
-                return Animation.decode(yaml.safe_load(f.read()))
+                return Animation.decode(load_yaml(f.read()))
         except (OSError, yaml.YAMLError) as e:
             raise ConfigError(str(e)) from e
 

@@ -12,6 +12,7 @@ exactly like Raytracer.render (src/Raytracer.hs:57-64).
 from __future__ import annotations
 
 import copy
+import math
 from dataclasses import dataclass, field
 from typing import Any, Tuple
 
@@ -25,38 +26,31 @@ class ConfigError(ValueError):
 Vec3 = Tuple[float, float, float]
 
 
-_YAML12_FLOAT = None
+class _Loader(yaml.SafeLoader):
+    """PyYAML resolves plain scalars by YAML 1.1, where a float needs a dot: `1e-1` or `5E3` stay strings.  The reference's
+    decoder (Data.Yaml = libyaml + aeson's number parser) reads them as numbers.  The 1.2-style float form is therefore added as an
+    IMPLICIT resolver -- it applies to plain scalars only, so an explicitly quoted scalar (`fov: "1.5"`) stays a string and is
+    rejected, like aeson rejects a String where a number is expected."""
 
 
-def _yaml12_number(v: str):
-    """PyYAML resolves scalars by YAML 1.1: a float without a dot (`1e-1`, `5E3`) stays a str.  The reference's decoder
-    (Data.Yaml = libyaml + aeson's number parser) accepts them, so numeric-looking strings are read the YAML 1.2 way."""
-    global _YAML12_FLOAT
-    if _YAML12_FLOAT is None:
-        import re
-        _YAML12_FLOAT = re.compile(r"[-+]?(\.[0-9]+|[0-9]+(\.[0-9]*)?)([eE][-+]?[0-9]+)?")
-    if _YAML12_FLOAT.fullmatch(v.strip()):
-        return float(v)
-    return None
+import re as _re  # noqa: E402
+
+_Loader.add_implicit_resolver("tag:yaml.org,2002:float", _re.compile(r"^[-+]?(\.[0-9]+|[0-9]+(\.[0-9]*)?)[eE][-+]?[0-9]+$"), list("-+0123456789."))
+
+
+def load_yaml(text: str) -> Any:
+    return yaml.load(text, Loader=_Loader)  # noqa: S506 -- a SafeLoader subclass
 
 
 def _num(v: Any, what: str) -> float:
-    if isinstance(v, str):
-        f = _yaml12_number(v)
-        if f is not None:
-            return f
     if isinstance(v, bool) or not isinstance(v, (int, float)):
         raise ConfigError(f"{what}: expected a number, got {v!r}")
     return float(v)
 
 
 def _int(v: Any, what: str) -> int:
-    """An aeson `Int` field: any JSON number with an integral value (25, 25.0, 2.5e1) decodes; 25.5 does not."""
-    if isinstance(v, str):
-        f = _yaml12_number(v)
-        if f is not None:
-            v = f
-    if isinstance(v, bool) or not isinstance(v, (int, float)) or float(v) != int(v):
+    """An aeson `Int` field: any JSON number with an integral value (25, 25.0, 2.5e1) decodes; 25.5, .inf and 1e999 do not."""
+    if isinstance(v, bool) or not isinstance(v, (int, float)) or not math.isfinite(v) or float(v) != int(v):
         raise ConfigError(f"{what}: expected an Int, got {v!r}")
     return int(v)
 
@@ -156,7 +150,7 @@ class Config:
     @staticmethod
     def from_yaml(text: str) -> "Config":
         try:
-            obj = yaml.safe_load(text)
+            obj = load_yaml(text)
         except yaml.YAMLError as e:
             raise ConfigError(str(e)) from e
         return Config.decode(obj)

@@ -62,6 +62,7 @@ struct bs_ctx {
         hipEvent_t ev_done = nullptr;              // everything of the render (incl. the counter read-back) has been enqueued before it
         bool used = false;
         uint64_t rays = 0;
+        int mode = BS_MODE_FAST;                   // the arithmetic this render was traced with (effective_mode)
     };
     static constexpr int kSlots = 8;
     LaunchSlot slots[kSlots];
@@ -97,6 +98,7 @@ struct bs_ctx {
     hipEvent_t ev_band[kMaxHostBands] = {};
     bool pending = false;  // a render has been enqueued whose stats were not read back yet
     double last_wall_ms = 0;
+    int last_zero_copy = 0;  // the last blocking render wrote the caller's page-locked buffer itself (no device image, no copy)
     bs_stats_t stats{};
 };
 
@@ -166,17 +168,25 @@ struct StreamDrain {
 double *device_alias_of_pinned(const bs_ctx *ctx, const void *host, size_t bytes)
 {
     if (!ctx->zero_copy || !host || bytes == 0) return nullptr;
-    hipPointerAttribute_t a, b;
+    hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, host) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer) {
         (void)hipGetLastError();  // pageable memory is reported as an error: not one of ours
         return nullptr;
     }
-    if (hipPointerGetAttributes(&b, static_cast<const char *>(host) + bytes - 1) != hipSuccess || b.type != hipMemoryTypeHost) {
-        (void)hipGetLastError();  // the buffer runs past the page-locked range
-        return nullptr;
-    }
     // page-locked for ANOTHER device only (hipHostMalloc / hipHostRegister there without the Portable flag): not ours to write
     if (a.device != ctx->device && !(a.allocationFlags & hipHostMallocPortable)) return nullptr;
+    // [host, host + bytes) must lie inside the ONE page-locked range `host` belongs to.  Probing the two ends is not enough: a
+    // buffer that starts in one hipHostRegister range and ends in another, with pageable memory (or a differently mapped range)
+    // in between, passes that test, and the kernel's stores through base alias + offset then fault on the GPU -- which ends the
+    // process instead of returning an error.  Anything that is not provably one range takes the staged path.
+    void *base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, a.devicePointer) != hipSuccess || !base) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const char *dp = static_cast<const char *>(a.devicePointer);
+    if (dp < static_cast<const char *>(base) || bytes > size || static_cast<size_t>(dp - static_cast<const char *>(base)) > size - bytes) return nullptr;
     return static_cast<double *>(a.devicePointer);
 }
 
@@ -211,6 +221,7 @@ int resolve_stats(bs_ctx *ctx)
     st.wave_iters = sl.h_counters[6];
     st.kernel_ms = ms;
     st.wall_ms = ctx->last_wall_ms;
+    st.effective_mode = sl.mode;
     ctx->pending = false;
     return BS_OK;
 }
@@ -247,7 +258,8 @@ int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_
     bs_ctx::LaunchSlot &sl = ctx->slots[ctx->cur_slot];
     if (!first) HIP_TRY(hipMemsetAsync(sl.d_counters + (bs::kCounters - 1), 0, sizeof(unsigned long long), s));  // tile queue head
     p.counters = sl.d_counters;
-    if (bs::launch_trace(p, effective_mode(ctx, cfg), s)) return fail(BS_EDEVICE, "kernel launch failed");
+    sl.mode = effective_mode(ctx, cfg);
+    if (bs::launch_trace(p, sl.mode, s)) return fail(BS_EDEVICE, "kernel launch failed");
     sl.rays += (uint64_t)p.wt * (uint64_t)(p.band_t1 - p.band_t0);
     if (last) {
         if (!quiet) {
@@ -406,6 +418,22 @@ int bs_set_mode(bs_ctx *ctx, int mode)
 }
 
 int bs_get_mode(const bs_ctx *ctx) { return ctx ? ctx->mode : BS_EINVAL; }
+
+int bs_validate_config(const bs_config *cfg)
+{
+    if (!cfg) return fail(BS_EINVAL, "null argument");
+    bs::TraceParams p;
+    std::memset(&p, 0, sizeof p);
+    std::string err;
+    if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
+    return BS_OK;
+}
+
+int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg)
+{
+    if (!ctx || !cfg) return fail(BS_EINVAL, "null argument");
+    return effective_mode(ctx, cfg);
+}
 
 int bs_set_max_steps(bs_ctx *ctx, int max_steps)
 {
@@ -568,6 +596,7 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     }
     if (u8_target == ctx->d_u8) HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->last_zero_copy = u8_target != ctx->d_u8;
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BS_OK;
 }
@@ -627,8 +656,10 @@ int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->last_zero_copy = 1;
         return BS_OK;
     }
+    ctx->last_zero_copy = 0;
     if (ctx->img_cap < need) {
         if (ctx->d_img) (void)hipFree(ctx->d_img);
         ctx->d_img = nullptr;
@@ -921,6 +952,7 @@ int bs_stats(bs_ctx *ctx, bs_stats_t *out)
     int rc = resolve_stats(ctx);
     if (rc) return rc;
     ctx->stats.wall_ms = ctx->last_wall_ms;
+    ctx->stats.zero_copy = ctx->last_zero_copy;
     *out = ctx->stats;
     return BS_OK;
 }

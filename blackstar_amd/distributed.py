@@ -73,7 +73,7 @@ def render_sharded(n_frames: int, render_frame: Callable[[int], "object"], rank:
     import torch
     if dist is None:
         import torch.distributed as dist  # noqa: PLC0415
-    if gather_to is not None and world > 1 and world > n_frames:
+    if gather_to is not None and world > 1 and 0 < n_frames < world:  # (no frames at all: no rounds, [] on the root)
         # checked identically on every rank BEFORE anything is rendered or any collective is entered: a rank without a single
         # frame has no tensor shape to contribute to the gather, and failing there alone would leave the other ranks hanging
         raise ValueError(f"{world} ranks for {n_frames} frames: use world <= n_frames (or gather_to=None)")

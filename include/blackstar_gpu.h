@@ -30,11 +30,16 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 1
+/* 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
+ * non-finite fields, stepSize <= 0, negative radii, lookAt == position).  1: rounds 1-2.  A binding should compare
+ * bs_abi_version() with the BS_ABI_VERSION it was written against before anything else. */
+#define BS_ABI_VERSION 2
 
 enum {
     BS_OK = 0,
-    BS_EINVAL = -1,  /* bad argument (null pointer, non-positive resolution, buffer too small, bad hue) */
+    BS_EINVAL = -1,  /* bad argument: null pointer, non-positive resolution, buffer too small, bad hue; or a configuration on which the
+                      * reference's colorize never terminates (src/Raytracer.hs:80-86 has no iteration cap): a non-finite value anywhere
+                      * in bs_config, stepSize <= 0, a negative disk radius, lookAt == position.  Returned before any GPU work. */
     BS_EDEVICE = -2, /* no such HIP device / HIP runtime error */
     BS_ENOMEM = -3,  /* host or device allocation failed */
     BS_ECAPPED = -4, /* never returned: rays stopped by the step cap are reported through bs_stats_t.capped only */
@@ -47,13 +52,16 @@ enum {
  * FAST:   the same discrete RK4 map evaluated in the ray's orbital plane with FMA-accumulated stage sums and
  *         r^-5 from v_rsq_f64 + a 2nd-order series correction.  Step counts, fates and disk crossings equal
  *         STRICT's on every ray tested; pixel values agree with STRICT to 3.4e-8 absolute / 3.7e-7 relative
- *         on the BASELINE frames and to 6.5e-7 relative at worst over a 10 000-scene fuzz (profiles/r02_fuzz_*)
+ *         on the BASELINE frames and to 6.5e-7 relative at worst over the committed fuzz runs (profiles/r02_fuzz_modes_10000.json:
+ *         10 000 scenes, 267 M values, worst 6.5e-7; r02_fuzz_modes_20000.json: 20 000 other scenes on the final library, 536 M values, worst 2.8e-7)
  *         -- inside the 1e-4 relative bar, not bit-exact.  Two guards keep it there (without them the fuzz's worst
  *         case was 2.3e-5: rays grazing the photon sphere amplify any rounding difference): a ray that orbits the
  *         hole (more steps than the longest straight path plus one photon-sphere circumference; a few per million)
  *         is re-traced with STRICT arithmetic inside the same kernel, and a frame whose stepSize exceeds 0.5 (the
- *         RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether.  The reference's
- *         default stepSize is 0.3. */
+ *         RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether -- at STRICT's cost,
+ *         2.4x FAST's per step (C3 frame: 10.4 vs 4.4 ms at stepSize 0.3).  bs_effective_mode(ctx, cfg) tells which arithmetic
+ *         a frame will get and bs_stats_t.effective_mode which one the last render got.  The reference's default stepSize
+ *         is 0.3 and every scene file it ships uses that. */
 enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
 
 /* Replaces the `Config` argument of render (src/ConfigFile.hs:16-38), AS PARSED: radii un-squared,
@@ -88,6 +96,10 @@ typedef struct bs_stats_t {
     uint64_t wave_iters; /* sum over wavefronts of the iterations of their slowest lane: lane efficiency = steps / (64 * wave_iters) */
     double kernel_ms;   /* hipEvent time of the kernels of the last render */
     double wall_ms;     /* host wall time of the last bs_render call (H2D params + kernels + D2H image) */
+    int32_t effective_mode; /* BS_MODE_* the last render was actually traced with (FAST frames with stepSize > 0.5 run in STRICT) */
+    int32_t zero_copy;      /* 1: the last blocking bs_render / bs_render_rows / bs_render_rgb8 wrote the caller's page-locked buffer
+                             * from the kernel itself; 0: it went through a device image and a copy (pageable memory, a buffer that is
+                             * not provably inside ONE page-locked range, BLACKSTAR_ZERO_COPY=0) */
 } bs_stats_t;
 
 /* Test hook: per-ray terminal state (not part of the reference interface). */
@@ -213,6 +225,10 @@ int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms
 
 int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST (env BLACKSTAR_MODE=strict|fast overrides at bs_create) */
 int bs_get_mode(const bs_ctx *ctx);
+/* The arithmetic a render of `cfg` on this context would be traced with: bs_get_mode(), except that a FAST context traces frames
+ * with stepSize > 0.5 in STRICT (see BS_MODE_FAST above).  Returns BS_MODE_* or BS_EINVAL.  For batch frames (whose statistics
+ * are not kept) this is the only way to know; perf numbers and A/B comparisons should record it. */
+int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg);
 int bs_set_max_steps(bs_ctx *ctx, int max_steps); /* safety cap; the reference has none (src/Raytracer.hs:80-86). default 100000 */
 int bs_stats(bs_ctx *ctx, bs_stats_t *out);       /* synchronises the context's last render first */
 const char *bs_last_error(void);
@@ -234,6 +250,11 @@ long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_sta
  * bs_render_rgb8 compare against on the device: table[k], k = 1..255, is the smallest double whose byte is >= k (found by
  * bisection with the host libm's pow, once per process); table[0] = -inf, table[256] = +inf. */
 int bs_debug_srgb8_table(double table[257]);
+
+/* Host-only: the checks every bs_render* entry point applies to its bs_config before any GPU work (see BS_EINVAL): BS_OK, or
+ * BS_EINVAL with the reason in bs_last_error().  No reference counterpart: `render` is total in the types and simply never
+ * returns on such inputs (src/Raytracer.hs:80-86). */
+int bs_validate_config(const bs_config *cfg);
 
 /* Replaces: toPixelRGB on PixelHSI (massiv-io Graphics.ColorSpace; call sites src/Raytracer.hs:65,
  * src/StarMap.hs:114).  Host-only; returns BS_EINVAL if the hue is outside [0,1). */

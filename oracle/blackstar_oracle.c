@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -259,7 +260,27 @@ static int sum_hits(const orc_star *stars, uint32_t *hits, int nh, double intens
     return nh;
 }
 
-#define MAX_HITS 4096
+/* The reference folds over however many stars inRadius returns (StarMap.hs:104,115): the hit list grows on demand and is
+ * NEVER truncated (round 2 capped it silently at 4096).  Running out of memory ends the process with a message: a checker
+ * that quietly drops stars would be worse than none. */
+typedef struct { uint32_t *v; int n, cap; uint32_t small[64]; } hitlist;
+
+static void hits_init(hitlist *h) { h->v = h->small; h->n = 0; h->cap = (int)(sizeof h->small / sizeof h->small[0]); }
+
+static void hits_push(hitlist *h, uint32_t id)
+{
+    if (h->n == h->cap) {
+        int cap = h->cap * 2;
+        uint32_t *nv = (uint32_t *)malloc((size_t)cap * sizeof(uint32_t));
+        if (!nv) { fprintf(stderr, "blackstar_oracle: out of memory growing a star hit list to %d entries\n", cap); abort(); }
+        memcpy(nv, h->v, (size_t)h->n * sizeof(uint32_t));
+        if (h->v != h->small) free(h->v);
+        h->v = nv; h->cap = cap;
+    }
+    h->v[h->n++] = id;
+}
+
+static void hits_free(hitlist *h) { if (h->v != h->small) free(h->v); }
 
 int orc_star_lookup(const orc_index *ix, double intensity, double saturation, const double vel[3], double rgb[3])
 {
@@ -268,8 +289,8 @@ int orc_star_lookup(const orc_index *ix, double intensity, double saturation, co
     const double r2 = radius * radius; /* kdt inRadius: distSqr p q <= radius*radius */
     double nvel[3];
     normalize3(vel, nvel); /* :103 */
-    uint32_t hits[MAX_HITS];
-    int nh = 0;
+    hitlist hits;
+    hits_init(&hits);
     if (ix && ix->n) {
         int lo[3], hi[3];
         for (int a = 0; a < 3; a++) { lo[a] = cell_of(nvel[a] - radius * 1.01); hi[a] = cell_of(nvel[a] + radius * 1.01); }
@@ -280,11 +301,13 @@ int orc_star_lookup(const orc_index *ix, double intensity, double saturation, co
                     for (uint32_t k = ix->cell_start[c]; k < ix->cell_start[c + 1]; k++) {
                         const orc_star *st = &ix->stars[ix->order[k]];
                         double dv[3] = {st->x - nvel[0], st->y - nvel[1], st->z - nvel[2]};
-                        if (quadrance3(dv) <= r2 && nh < MAX_HITS) hits[nh++] = ix->order[k];
+                        if (quadrance3(dv) <= r2) hits_push(&hits, ix->order[k]);
                     }
                 }
     }
-    return sum_hits(ix ? ix->stars : NULL, hits, nh, intensity, saturation, nvel, rgb);
+    int nh = sum_hits(ix ? ix->stars : NULL, hits.v, hits.n, intensity, saturation, nvel, rgb);
+    hits_free(&hits);
+    return nh;
 }
 
 int orc_star_lookup_brute(const orc_star *stars, size_t n, double intensity, double saturation, const double vel[3], double rgb[3])
@@ -292,13 +315,15 @@ int orc_star_lookup_brute(const orc_star *stars, size_t n, double intensity, dou
     const double radius = 3 * 0.0005, r2 = radius * radius;
     double nvel[3];
     normalize3(vel, nvel);
-    uint32_t hits[MAX_HITS];
-    int nh = 0;
+    hitlist hits;
+    hits_init(&hits);
     for (size_t i = 0; i < n; i++) {
         double dv[3] = {stars[i].x - nvel[0], stars[i].y - nvel[1], stars[i].z - nvel[2]};
-        if (quadrance3(dv) <= r2 && nh < MAX_HITS) hits[nh++] = (uint32_t)i;
+        if (quadrance3(dv) <= r2) hits_push(&hits, (uint32_t)i);
     }
-    return sum_hits(stars, hits, nh, intensity, saturation, nvel, rgb);
+    int nh = sum_hits(stars, hits.v, hits.n, intensity, saturation, nvel, rgb);
+    hits_free(&hits);
+    return nh;
 }
 
 /* ---------------------------------------------------------------- colorize / findColor / blend */

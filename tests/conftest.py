@@ -40,6 +40,14 @@ def catalogue_bytes():
 
 
 @pytest.fixture(scope="session")
+def clustered_bytes():
+    """The NON-uniform test sky (tests/golden/make_golden.py --clustered): the 2,000 stars + 48 clusters of 5..40 stars inside
+    0.001 rad (at directions in which rays of the 96x54 default-aa frame leave the scene) + a band at 10x the mean density."""
+    with open(os.path.join(GOLDEN, "catalogue_clustered.ppm"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import c_oracle
     c_oracle.build()
@@ -54,6 +62,11 @@ def oracle_stars(oracle, catalogue_bytes):
 @pytest.fixture(scope="session")
 def oracle_index(oracle, oracle_stars):
     return oracle.Index(oracle_stars)
+
+
+@pytest.fixture(scope="session")
+def oracle_index_clustered(oracle, clustered_bytes):
+    return oracle.Index(oracle.read_ppm(clustered_bytes))
 
 
 @pytest.fixture(scope="session")

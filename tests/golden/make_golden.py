@@ -97,7 +97,7 @@ def main():
         print(name, len(ys), rec["steps"].mean(), np.bincount(rec["fate"]))
 
 
-if __name__ == "__main__" and "--c1" not in sys.argv and "--extra" not in sys.argv:
+if __name__ == "__main__" and not {"--c1", "--extra", "--clustered"} & set(sys.argv):
     main()
 
 
@@ -155,3 +155,80 @@ def c1_summary():
 
 if __name__ == "__main__" and "--c1" in sys.argv:
     c1_summary()
+
+
+def _ppm_records(xyz, mag, sp):
+    xyz = xyz / np.linalg.norm(xyz, axis=1, keepdims=True)
+    rec = np.zeros(len(xyz), np.dtype([("ra", ">f8"), ("dec", ">f8"), ("sp", "u1"), ("skip", "u1"), ("mag", ">i2"), ("pad", "u1", 8)]))
+    rec["ra"] = np.mod(np.arctan2(xyz[:, 1], xyz[:, 0]), 2 * np.pi)
+    rec["dec"] = np.arcsin(np.clip(xyz[:, 2], -1, 1))
+    rec["sp"], rec["mag"] = sp, mag
+    return rec.tobytes()
+
+
+def clustered():
+    """A NON-uniform sky (round 3): the 2,000-star catalogue + 48 clusters of 5..40 stars, each inside 0.001 rad of the direction
+    in which one ray of the default-aa camera at 96x54 leaves the scene (so the rendered frame itself holds pixels whose
+    starLookup sums 6, 7, 12, ... 40 stars) + a band at 10x the mean density.  starLookup folds over every star inRadius returns
+    (src/StarMap.hs:104,115); the fixtures pin lookups with up to 40+ hits.  Written: catalogue_clustered.ppm, the image golden,
+    the per-ray golden of the cluster rays and their neighbours, and a batch of plain starLookup queries."""
+    rng = np.random.default_rng(20260929)
+    base = open(os.path.join(HERE, "catalogue_2000.ppm"), "rb").read()
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 96, 54)
+    sc = no.derive(cfg)
+    ys, xs = np.mgrid[0:sc["ht"], 0:sc["wt"]]
+    ys, xs = ys.ravel(), xs.ravel()
+    rec0 = no.trace(cfg, None, ys, xs)
+    esc = np.nonzero(rec0["fate"] == 1)[0]
+    pick = np.sort(rng.choice(esc, 48, replace=False))
+    centres = no.normalize(rec0["vel"][pick])
+    sizes = np.concatenate([[5, 6, 7, 12, 40, 40, 33, 21], rng.integers(6, 41, 40)])
+    c = np.repeat(centres, sizes, axis=0)
+    ref = np.where(np.abs(c[:, 2:3]) < 0.9, [[0.0, 0.0, 1.0]], [[1.0, 0.0, 0.0]])
+    e1 = np.cross(c, ref); e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.cross(c, e1)
+    rho, phi = 0.001 * np.sqrt(rng.random((len(c), 1))), 2 * np.pi * rng.random((len(c), 1))
+    members = c + rho * (np.cos(phi) * e1 + np.sin(phi) * e2)
+    cl = _ppm_records(members, rng.integers(1150, 1450, len(c)).astype(np.int16), np.frombuffer(b"OBAFGKM?", np.uint8)[rng.integers(0, 8, len(c))])
+    # band: +-0.035 rad about the great circle whose pole is (0.3, -0.5, 0.81), filled to 10x the mean density of the 2,000 stars
+    pole = np.array([0.3, -0.5, 0.81]); pole /= np.linalg.norm(pole)
+    b1 = np.cross(pole, [0, 0, 1.0]); b1 /= np.linalg.norm(b1); b2 = np.cross(pole, b1)
+    nb = int(round(9 * 2000 / (4 * np.pi) * 2 * np.pi * 2 * np.sin(0.035)))
+    sb, lam = np.sin(0.035) * (2 * rng.random((nb, 1)) - 1), 2 * np.pi * rng.random((nb, 1))
+    band = np.sqrt(1 - sb * sb) * (np.cos(lam) * b1 + np.sin(lam) * b2) + sb * pole
+    bd = _ppm_records(band, (1200 - np.floor(700 * rng.random(nb) ** 3)).astype(np.int16), np.frombuffer(b"OBAFGKM?", np.uint8)[rng.integers(0, 8, nb)])
+    cat = base + cl + bd
+    with open(os.path.join(HERE, "catalogue_clustered.ppm"), "wb") as f:
+        f.write(cat)
+    stars = parse_catalogue(cat)
+    print("clustered catalogue:", len(stars), "stars,", len(c), "in clusters,", nb, "in the band")
+
+    img, rec = no.render(cfg, stars)
+    np.savez_compressed(os.path.join(HERE, "image_clustered_default_aa_96x54.npz"), cfg=json.dumps(cfg), img=img,
+                        total_steps=np.int64(rec["steps"].sum()), fate_counts=np.bincount(rec["fate"], minlength=3),
+                        disk_hits=np.int64(rec["disk_hits"].sum()), star_hits=np.int64(rec["star_hits"].sum()),
+                        max_star_hits=np.int64(rec["star_hits"].max()), star_hits_hist=np.bincount(rec["star_hits"], minlength=64))
+    print("image", img.shape, "star hits/ray histogram:", np.bincount(rec["star_hits"]))
+    assert rec["star_hits"].max() >= 40 and (rec["star_hits"] == 6).any() and (rec["star_hits"] == 5).any()
+
+    # per-ray golden: the 48 cluster rays, their right-hand neighbours, and 96 random rays
+    sel = np.unique(np.concatenate([pick, np.minimum(pick + 1, len(ys) - 1), rng.choice(len(ys), 96, replace=False)]))
+    v0, p0 = no.generate_rays(sc, ys[sel], xs[sel])
+    np.savez_compressed(os.path.join(HERE, "trace_clustered.npz"), cfg=json.dumps(cfg), ys=ys[sel].astype(np.int32), xs=xs[sel].astype(np.int32),
+                        vel0=v0, h2=rec["h2"][sel], vel=rec["vel"][sel], pos=rec["pos"][sel], rgba=rec["rgba"][sel], steps=rec["steps"][sel],
+                        fate=rec["fate"][sel], disk_hits=rec["disk_hits"][sel], star_hits=rec["star_hits"][sel])
+
+    # plain starLookup queries: cluster centres (all members in reach), members (part of the cluster in reach), points 0.0005..0.003
+    # away from centres (clusters partly / just out of reach), band directions, random directions; un-normalised like `vel` is
+    q = [centres * rng.uniform(0.5, 3, (48, 1)), members[rng.choice(len(members), 400, replace=False)],
+         c[rng.choice(len(c), 400)] + rng.normal(scale=0.0012, size=(400, 3)), band[rng.choice(nb, 300)] + rng.normal(scale=4e-4, size=(300, 3)),
+         rng.normal(size=(352, 3))]
+    dirs = np.concatenate(q)
+    rgb, hits = no.star_lookup(stars, 0.4, 1.5, dirs)
+    np.savez_compressed(os.path.join(HERE, "lookup_clustered.npz"), dirs=dirs, rgb=rgb, hits=hits, intensity=0.4, saturation=1.5)
+    print("lookup golden:", len(dirs), "queries, hits histogram:", np.bincount(hits))
+    assert hits.max() >= 40 and (hits >= 6).sum() > 300
+
+
+if __name__ == "__main__" and "--clustered" in sys.argv:
+    clustered()

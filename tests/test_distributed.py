@@ -34,6 +34,17 @@ def test_more_ranks_than_frames_fails_on_every_rank_before_any_collective():
     assert render_sharded(2, lambda i: i, 2, 3, gather_to=None, dist=NoCollectives()) == []
 
 
+def test_no_frames_at_all_is_an_empty_result_not_an_error():
+    """n_frames == 0 (an empty directory in app/Main.hs:68-77's batch loop): no rounds, no collective; [] on the root, None elsewhere."""
+    from blackstar_amd.distributed import render_sharded
+
+    def never(i):
+        raise AssertionError("no frame to render")
+    assert render_sharded(0, never, 0, 4, gather_to=0) == []
+    assert render_sharded(0, never, 3, 4, gather_to=0) is None
+    assert render_sharded(0, never, 1, 4, gather_to=None) == []
+
+
 def _worker(rank, world, port, n_frames, q):
     import torch
     import torch.distributed as dist

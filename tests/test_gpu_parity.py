@@ -1237,3 +1237,197 @@ def test_bloom_randomised_shapes_bit_exact(tree, oracle):
         got = bs.bloom(0.4, div, img, tree)
         ref = oracle.bloom(0.4, div, img)
         assert np.array_equal(got, ref), f"{w}x{h} divider {div} (r = {w // div}): {(got != ref).sum()} values differ, max {np.abs(got - ref).max():.3e}"
+
+
+# ---- a NON-uniform sky (round 3): lookups that sum 6 .. 40+ stars -----------------------------------------------------------
+# The kernel's star_lookup queues the first 5 hits of a lane in LDS and shades any further hit in place (trace_kernel.hip, `hits <
+# kHitSlots`): on the uniform catalogues above (0.26 hits per lookup) that second branch never ran.  The reference folds over every star
+# inRadius returns (src/StarMap.hs:104,115), and a real catalogue has clusters and a dense galactic plane.
+
+@pytest.fixture(scope="module")
+def tree_clustered(clustered_bytes):
+    t = bs.StarTree(bs.read_map(clustered_bytes), device=0)
+    t.set_mode(_lib.BS_MODE_STRICT)
+    yield t
+    t.close()
+
+
+def test_clustered_sky_star_lookup_vs_golden_and_brute_force(tree_clustered, oracle, oracle_index_clustered):
+    g = load_golden("lookup_clustered")
+    rgb, hits = bs.star_lookup(tree_clustered, float(g["intensity"]), float(g["saturation"]), g["dirs"], return_hits=True)
+    assert hits.max() >= 40 and (hits >= 12).sum() > 200 and (hits == 5).any() and (hits == 6).any()  # both sides of the 5 LDS slots
+    assert np.array_equal(hits, g["hits"]), "hit SETS differ from the numpy restatement"
+    np.testing.assert_allclose(rgb, g["rgb"], rtol=1e-12, atol=1e-15)
+    for k in range(0, len(hits), 3):
+        ref, nref = oracle.star_lookup(oracle_index_clustered, float(g["intensity"]), float(g["saturation"]), g["dirs"][k], brute=True)
+        assert hits[k] == nref
+        np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_clustered_sky_frame_and_rays(mode, tree_clustered, oracle, oracle_index_clustered):
+    g = load_golden("image_clustered_default_aa_96x54")
+    gt = load_golden("trace_clustered")
+    fast = mode == "fast"
+    tree_clustered.set_mode(_lib.BS_MODE_FAST if fast else _lib.BS_MODE_STRICT)
+    try:
+        img = bs.render(g["cfg"], tree_clustered)
+        st = tree_clustered.stats()
+        rec = bs.trace_rays(gt["cfg"], tree_clustered, gt["ys"], gt["xs"])
+    finally:
+        tree_clustered.set_mode(_lib.BS_MODE_STRICT)
+    rtol, atol = (RTOL_FAST, ATOL_FAST) if fast else (RTOL_STRICT, ATOL_STRICT)
+    ref, ost = oracle.render(g["cfg"], oracle_index_clustered, threads=0)
+    for want in (g["img"], ref):
+        bad = np.abs(img - want) > atol + rtol * np.abs(want)
+        assert bad.sum() == 0, f"{bad.sum()} channel values outside tolerance, max abs err {np.abs(img - want).max()}"
+    assert st["star_hits"] == int(g["star_hits"]) == ost["star_hits"] and st["steps"] == int(g["total_steps"])
+    # the per-ray records: the in-place branch runs for every ray with more than 5 hits (up to 40 here)
+    assert np.array_equal(rec["star_hits"], gt["star_hits"]) and rec["star_hits"].max() >= 40 and (rec["star_hits"] >= 12).sum() >= 20
+    assert np.array_equal(rec["steps"], gt["steps"]) and np.array_equal(rec["fate"], gt["fate"])
+    if not fast:
+        assert np.array_equal(rec["vel"], gt["vel"])
+    np.testing.assert_allclose(rec["rgba"], gt["rgba"], rtol=rtol, atol=atol)
+
+
+def test_clustered_full_size_catalogue_lookup_and_frame(oracle):
+    """bench.py --catalogue clustered: 470,000 uniform stars + 3,000 clusters + a band at 10x the mean density (686 k stars; grid cells
+    hold from 0 to ~100 entries).  Lookups aimed at clusters, at the band and anywhere vs the oracle's index, and a 480x270 supersampled
+    C3 frame in both modes vs the oracle's render."""
+    data = synthetic.clustered_catalogue_bytes()
+    stars = bs.read_map(data)
+    t = bs.StarTree(stars)
+    ix = oracle.Index(oracle.read_ppm(data))
+    rng = np.random.default_rng(31)
+    n0 = synthetic.N_FULL
+    members = stars[rng.integers(n0, len(stars), 12000)]
+    dirs = np.concatenate([np.stack([members["x"], members["y"], members["z"]], axis=1) * rng.uniform(0.5, 3, (12000, 1)) + rng.normal(scale=3e-4, size=(12000, 3)),
+                           rng.normal(size=(8000, 3))])
+    rgb, hits = bs.star_lookup(t, 0.4, 1.5, dirs, return_hits=True)
+    assert hits.max() >= 30 and (hits >= 6).sum() > 1500
+    for k in range(0, len(dirs), 5):
+        ref, nref = oracle.star_lookup(ix, 0.4, 1.5, dirs[k])
+        assert hits[k] == nref, k
+        np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 480, 270)
+    ref, ost = oracle.render(cfg, ix, threads=0)
+    for mode, rtol, atol in ((_lib.BS_MODE_STRICT, RTOL_STRICT, ATOL_STRICT), (_lib.BS_MODE_FAST, RTOL_FAST, ATOL_FAST)):
+        t.set_mode(mode)
+        img = bs.render(cfg, t)
+        st = t.stats()
+        bad = np.abs(img - ref) > atol + rtol * np.abs(ref)
+        assert bad.sum() == 0, (mode, int(bad.sum()), np.abs(img - ref).max())
+        assert st["star_hits"] == ost["star_hits"] and st["steps"] == ost["steps"]
+    assert ost["star_hits"] / ost["escaped"] > 0.3  # denser than the uniform sky's 0.26 hits per lookup
+    t.close()
+
+
+# ---- inputs the reference never returns from (round 3) -----------------------------------------------------------------------
+
+def test_bad_configs_return_einval_fast_and_leave_the_context_usable(tree):
+    """colorize has no iteration cap (src/Raytracer.hs:80-86): NaN state, stepSize <= 0 or lookAt == position never terminate there.
+    Behind the C ABI each must come back as BS_EINVAL before any GPU work (round 2 traced them to max_steps: seconds to a minute
+    inside one kernel), from every render entry point, and the context must render normally afterwards."""
+    import time
+    from test_host import BAD_CONFIGS
+    L = _lib.lib()
+    good = scenes.with_res(scenes.DEFAULT_AA, 1920, 1080)  # full size: a config that slipped through would take seconds
+    out = bs.alloc_image(tree, 1080, 1920)
+    out8 = np.zeros((1080, 1920, 3), np.uint8)
+    rec = np.zeros(4, _lib.RECORD_DTYPE)
+    yx = np.zeros((4, 2), np.int32)
+    small = scenes.with_res(scenes.DEFAULT_AA, 64, 36)
+    ref = bs.render(small, tree)
+    for what, (over, msg) in sorted(BAD_CONFIGS.items()):
+        c = _lib.make_config(dict(good, **over))
+        calls = {"bs_render": lambda: L.bs_render(tree.handle, C.byref(c), out.ctypes.data, out.size),
+                 "bs_render_rows": lambda: L.bs_render_rows(tree.handle, C.byref(c), 0, 1, out.ctypes.data, out.size),
+                 "bs_render_rgb8": lambda: L.bs_render_rgb8(tree.handle, C.byref(c), C.c_double(0.15), 25, out8.ctypes.data, out8.size),
+                 "bs_trace_rays": lambda: L.bs_trace_rays(tree.handle, C.byref(c), yx.ctypes.data, 4, rec.ctypes.data)}
+        if what != "zero width":
+            arr = (_lib.BsConfig * 1)(c)
+            ptrs = (C.c_void_p * 1)(out.ctypes.data)
+            ctxs = (C.c_void_p * 1)(tree.handle)
+            calls["bs_render_batch"] = lambda: L.bs_render_batch(ctxs, 1, arr, 1, ptrs)
+        for name, f in calls.items():
+            t0 = time.perf_counter()
+            rc = f()
+            dt = (time.perf_counter() - t0) * 1e3
+            assert rc == -1, (what, name, rc)
+            assert msg.encode() in L.bs_last_error(), (what, name, L.bs_last_error())
+            assert dt < 50, f"{name} took {dt:.1f} ms to refuse '{what}'"
+        assert np.array_equal(bs.render(small, tree), ref), f"context unusable after '{what}'"
+
+
+def test_effective_mode_is_reported(tree):
+    """A FAST context traces frames with stepSize > 0.5 in STRICT (2.4x the cost): bs_effective_mode says so up front, bs_stats
+    afterwards; bs_get_mode keeps reporting what was asked for."""
+    L = _lib.lib()
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 64, 36)
+    coarse = dict(cfg, step_size=0.75)
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        assert L.bs_get_mode(tree.handle) == _lib.BS_MODE_FAST
+        assert L.bs_effective_mode(tree.handle, C.byref(_lib.make_config(cfg))) == _lib.BS_MODE_FAST
+        assert L.bs_effective_mode(tree.handle, C.byref(_lib.make_config(coarse))) == _lib.BS_MODE_STRICT
+        fast_img = bs.render(cfg, tree)
+        assert tree.stats()["effective_mode"] == _lib.BS_MODE_FAST
+        coarse_fast = bs.render(coarse, tree)
+        assert tree.stats()["effective_mode"] == _lib.BS_MODE_STRICT and L.bs_get_mode(tree.handle) == _lib.BS_MODE_FAST
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    assert L.bs_effective_mode(tree.handle, C.byref(_lib.make_config(cfg))) == _lib.BS_MODE_STRICT
+    assert np.array_equal(bs.render(coarse, tree), coarse_fast)  # it WAS the STRICT arithmetic, bit for bit
+    assert tree.stats()["effective_mode"] == _lib.BS_MODE_STRICT
+    assert not np.array_equal(bs.render(cfg, tree), fast_img)
+
+
+def test_zero_copy_only_inside_one_page_locked_range(tree):
+    """bs_stats_t.zero_copy tells which delivery path a blocking render took.  Page-locked buffers (bs_host_alloc, torch's pinned
+    allocator, hipHostRegister) are written by the kernel itself; a buffer that starts in one hipHostRegister range and ends in
+    another with PAGEABLE memory between them must NOT be (round 2 probed only its two ends and would have faulted on the GPU,
+    which ends the process): it takes the staged path and still delivers the right pixels."""
+    import torch
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 320, 181)
+    n = 181 * 320 * 3
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        ref = bs.render(cfg, tree)
+        assert tree.stats()["zero_copy"] == 0  # pageable
+        pinned = bs.alloc_image(tree, 2 * 181, 320)
+        bs.render(cfg, tree, out=pinned[:181])
+        assert tree.stats()["zero_copy"] == 1 and np.array_equal(pinned[:181], ref)
+        bs.render(cfg, tree, out=pinned[181:])  # interior pointer, runs to the very end of the allocation
+        assert tree.stats()["zero_copy"] == 1 and np.array_equal(pinned[181:], ref)
+        tp = torch.empty(n, dtype=torch.float64).pin_memory().numpy().reshape(181, 320, 3)  # another allocator's page-locked memory
+        bs.render(cfg, tree, out=tp)
+        assert np.array_equal(tp, ref)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        hip.hipHostUnregister.argtypes = [C.c_void_p]
+        page = 4096
+        raw = np.zeros(4 * (1 << 20) + page, np.uint8)
+        base = (raw.ctypes.data + page - 1) // page * page
+        a0, a1, b0, b1 = 0, 512 << 10, 1 << 20, 3 << 20          # [a0,a1) and [b0,b1) page-locked, [a1,b0) left pageable
+        assert hip.hipHostRegister(base + a0, a1 - a0, 0) == 0 and hip.hipHostRegister(base + b0, b1 - b0, 0) == 0
+        try:
+            def view(off):
+                return np.frombuffer((C.c_ubyte * (n * 8)).from_address(base + off), np.float64).reshape(181, 320, 3)
+            inside = view(b0 + 4096)                                 # wholly inside the second range
+            inside[:] = -1
+            bs.render(cfg, tree, out=inside)
+            assert tree.stats()["zero_copy"] == 1 and np.array_equal(inside, ref)
+            spanning = view(256 << 10)                               # first range -> pageable hole -> second range
+            assert (256 << 10) + n * 8 > b0 and (256 << 10) + n * 8 < b1
+            spanning[:] = -1
+            bs.render(cfg, tree, out=spanning)
+            assert tree.stats()["zero_copy"] == 0, "a buffer spanning two page-locked ranges was handed to the kernel"
+            assert np.array_equal(spanning, ref)
+            tail = view(b1 - n * 8 + 4096)                           # ends one page past the second range
+            bs.render(cfg, tree, out=tail)
+            assert tree.stats()["zero_copy"] == 0 and np.array_equal(tail, ref)
+        finally:
+            hip.hipHostUnregister(base + a0)
+            hip.hipHostUnregister(base + b0)
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)

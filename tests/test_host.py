@@ -21,13 +21,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L, sym), f"{sym} declared in include/blackstar_gpu.h but not exported"
     assert set(_lib.SYMBOLS) <= declared
-    assert L.bs_abi_version() == 1
+    assert L.bs_abi_version() == _lib.BS_ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.BsConfig) == 19 * 8 + 4 * 4
     assert _lib.STAR_DTYPE.itemsize == 48 and _lib.RECORD_DTYPE.itemsize == 96
-    assert ctypes.sizeof(_lib.BsStats) == 10 * 8
+    assert ctypes.sizeof(_lib.BsStats) == 11 * 8
 
 
 def test_no_cpu_backend():
@@ -62,13 +62,20 @@ def test_config_defaults_and_errors():
     c3 = bs.Config.from_yaml("camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1e0}\n"
                              "scene: {stepSize: 1e-1, resolution: [1920.0, 1.08e3], bloomDivider: 2.5e1, diskOuter: 12}\n")
     assert c3.scene.stepSize == 0.1 and c3.scene.resolution == (1920, 1080) and c3.scene.bloomDivider == 25 and c3.camera.fov == 1.0
-    for bad in ("scene: {resolution: [1920.5, 1080]}", "scene: {stepSize: abc}", "scene: {bloomDivider: 2.5}"):
+    # ... and what it refuses: non-integral Ints, non-numbers, QUOTED numbers (aeson yields String for them), infinite Ints
+    for bad in ("scene: {resolution: [1920.5, 1080]}", "scene: {stepSize: abc}", "scene: {bloomDivider: 2.5}", 'scene: {stepSize: "0.3"}',
+                "scene: {resolution: ['1920', 1080]}", 'scene: {stepSize: "1e-1"}', "scene: {resolution: [1e999, 5]}", "scene: {bloomDivider: .inf}"):
         with pytest.raises(bs.ConfigError):
             bs.Config.from_yaml("camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: 1}\n" + bad + "\n")
     c2 = bs.Config.from_yaml(c.to_yaml())  # ToJSON round trip (hue * 360 and back)
     assert c2.to_bs_config() == pytest.approx(c.to_bs_config())
     p = bs.prepare_scene(bs.Config.from_file(os.path.join(ROOT, "scenes", "default.yaml")), True)  # app/Main.hs:93-103
     assert p.scene.resolution == (300, 168) and p.scene.supersampling is False and p.scene.bloomStrength == 0
+
+
+def test_quoted_fov_is_rejected_like_aeson_does():
+    with pytest.raises(bs.ConfigError):
+        bs.Config.from_yaml('camera: {position: [1,2,3], lookAt: [0,0,0], upVec: [0,1,0], fov: "1.5"}\nscene: {}\n')
 
 
 def test_animation_frames_match_independent_restatement():
@@ -165,6 +172,62 @@ def test_header_is_c99_and_layouts_match_the_shim(tmp_path):
                            "-lblackstar_gpu", "-Wl,-rpath," + os.path.join(ROOT, "blackstar_amd")])
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+BAD_CONFIGS = {  # what -> (override, substring of the message).  src/Raytracer.hs:80-86 never terminates on any of these.
+    "NaN camera position": (dict(cam_pos=(0.0, float("nan"), -20.0)), "camera.position"),
+    "infinite lookAt": (dict(cam_lookat=(float("inf"), 0.0, 0.0)), "camera.lookAt"),
+    "NaN up vector": (dict(cam_up=(0.0, 1.0, float("nan"))), "camera.upVec"),
+    "NaN fov": (dict(fov=float("nan")), "camera.fov"),
+    "zero stepSize": (dict(step_size=0.0), "stepSize"),
+    "negative stepSize": (dict(step_size=-0.3), "stepSize"),
+    "NaN stepSize": (dict(step_size=float("nan")), "stepSize"),
+    "infinite stepSize": (dict(step_size=float("inf")), "stepSize"),
+    "negative diskInner": (dict(disk_inner=-1.0), "diskInner"),
+    "negative diskOuter": (dict(disk_outer=-13.0), "diskOuter"),
+    "NaN diskOpacity": (dict(disk_opacity=float("nan")), "diskOpacity"),
+    "NaN starIntensity": (dict(star_intensity=float("nan")), "starIntensity"),
+    "lookAt == position": (dict(cam_lookat=(0.0, 1.0, -20.0)), "lookAt equals"),
+    "bad hue": (dict(disk_hsi=(1.0, 0.1, 1.0)), "not properly scaled"),
+    "zero width": (dict(width=0), "resolution"),
+}
+
+
+@pytest.mark.parametrize("what", sorted(BAD_CONFIGS))
+def test_validate_config_rejects_what_the_reference_never_returns_from(what):
+    """bs_validate_config is host-only: the checks every render entry point applies before any GPU work."""
+    import ctypes as C
+    L = _lib.lib()
+    assert L.bs_validate_config(C.byref(_lib.make_config(scenes.with_res(scenes.DEFAULT, 8, 8)))) == 0
+    over, msg = BAD_CONFIGS[what]
+    assert L.bs_validate_config(C.byref(_lib.make_config(dict(scenes.with_res(scenes.DEFAULT, 8, 8), **over)))) == -1
+    assert msg.encode() in L.bs_last_error(), L.bs_last_error()
+    assert L.bs_validate_config(None) == -1
+
+
+def test_every_shipped_scene_and_animation_frame_validates():
+    import ctypes as C
+    L = _lib.lib()
+    for name in scenes.REFERENCE_SCENES:
+        c = bs.Config.from_file(os.path.join(ROOT, "scenes", name + ".yaml"))
+        assert L.bs_validate_config(C.byref(_lib.make_config(c.to_bs_config()))) == 0, name
+    anim = bs.Animation.from_file(os.path.join(ROOT, "animations", "default-ani.yaml"))
+    for c in bs.generate_frames(anim)[::25]:
+        assert L.bs_validate_config(C.byref(_lib.make_config(c.to_bs_config()))) == 0
+
+
+def test_stale_library_is_refused_by_its_abi_version(tmp_path):
+    """A libblackstar_gpu.so of another ABI version under the same name fails at load with a message that says so (not at a later
+    symbol lookup or, worse, a struct read)."""
+    import subprocess
+    import sys
+    src = tmp_path / "stale.c"
+    src.write_text("int bs_abi_version(void) { return 1; }\n")
+    so = tmp_path / "libblackstar_gpu.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    code = "import blackstar_amd as bs\ntry:\n    bs._lib.lib()\n    print('LOADED')\nexcept bs._lib.BlackstarError as e:\n    print('refused', 'ABI version 1' in str(e))\n"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, BLACKSTAR_LIB=str(so)))
+    assert r.returncode == 0 and r.stdout.strip() == "refused True", (r.stdout, r.stderr)
 
 
 def test_missing_native_library_fails_loudly():

@@ -155,6 +155,60 @@ def test_star_lookup_grid_vs_brute_force(oracle, oracle_stars, oracle_index):
         np.testing.assert_allclose(a, rgb[k], rtol=1e-14, atol=1e-16)
 
 
+def test_clustered_sky_goldens(oracle, oracle_index_clustered):
+    """starLookup folds over EVERY star inRadius returns (src/StarMap.hs:104,115).  The clustered-sky fixtures come from the numpy
+    restatement; the C restatement must reproduce them: lookups summing up to 40+ stars, the frame that contains such pixels,
+    and the per-ray records of the rays that end inside the clusters."""
+    g = load_golden("lookup_clustered")
+    assert g["hits"].max() >= 40 and (g["hits"] >= 6).sum() > 300
+    for k in range(len(g["dirs"])):
+        rgb, n = oracle.star_lookup(oracle_index_clustered, float(g["intensity"]), float(g["saturation"]), g["dirs"][k], brute=(k % 7 == 0))
+        assert n == g["hits"][k], k
+        np.testing.assert_allclose(rgb, g["rgb"][k], rtol=1e-13, atol=1e-16)
+    gi = load_golden("image_clustered_default_aa_96x54")
+    img, st = oracle.render(gi["cfg"], oracle_index_clustered, threads=2)
+    assert st["steps"] == int(gi["total_steps"]) and st["star_hits"] == int(gi["star_hits"]) and st["disk_hits"] == int(gi["disk_hits"])
+    np.testing.assert_allclose(img, gi["img"], rtol=1e-13, atol=1e-15)
+    gt = load_golden("trace_clustered")
+    rec = oracle.trace_rays(gt["cfg"], oracle_index_clustered, gt["ys"], gt["xs"])
+    assert np.array_equal(rec["star_hits"], gt["star_hits"]) and rec["star_hits"].max() >= 40
+    assert sorted(set(rec["star_hits"].tolist()) & {5, 6, 7, 12}) == [5, 6, 7, 12]  # either side of the kernel's 5 LDS hit slots
+    assert np.array_equal(rec["vel"], gt["vel"]) and np.array_equal(rec["steps"], gt["steps"])
+    np.testing.assert_allclose(rec["rgba"], gt["rgba"], rtol=1e-13, atol=1e-15)
+
+
+def test_oracle_hit_list_is_never_truncated(oracle):
+    """Round 2's oracle capped a lookup at 4096 stars silently; the reference has no cap.  6,000 coincident faint stars: all are hits,
+    through the index and by brute force, and the colour is the full sum."""
+    n = 6000
+    stars = np.zeros(n, oracle.STAR_DTYPE)
+    stars["x"], stars["mag"], stars["hue"], stars["sat"] = 1.0, 950 + 50 * 14, 0.094, 0.29  # val = intensity * 2^-14 each
+    ix = oracle.Index(stars)
+    for brute in (False, True):
+        rgb, hits = oracle.star_lookup(ix, 1.0, 0.0, np.array([2.0, 0.0, 0.0]), brute=brute)
+        assert hits == n
+        np.testing.assert_allclose(rgb, [n * 2.0 ** -14] * 3, rtol=1e-12)
+
+
+def test_clustered_synthetic_catalogue_recipe():
+    """bench.py --catalogue clustered: the uniform BASELINE sky + clusters + a dense band, in the PPM on-disk layout."""
+    from blackstar_amd import synthetic
+    small = synthetic.clustered_catalogue_bytes(n_uniform=5000, n_clusters=40)
+    assert small[:28 + 5000 * 28] == synthetic.ppm_catalogue_bytes(5000)  # the uniform part is the BASELINE recipe, unchanged
+    from oracle import c_oracle
+    st = c_oracle.read_ppm(small)
+    xyz = np.stack([st["x"], st["y"], st["z"]], axis=1)
+    np.testing.assert_allclose(np.linalg.norm(xyz, axis=1), 1.0, rtol=1e-15)
+    ix = c_oracle.Index(st)
+    hits = [c_oracle.star_lookup(ix, 0.4, 1.5, xyz[k])[1] for k in range(5000, 5000 + 6 * 40, 3)]
+    assert min(hits) >= 2 and max(hits) >= 20  # queries at cluster members see (most of) their cluster
+    pole = np.array(synthetic.BAND_POLE) / np.linalg.norm(synthetic.BAND_POLE)
+    lat = np.arcsin(xyz @ pole)
+    in_band = np.abs(lat) < synthetic.BAND_HALF_WIDTH
+    area = 2 * np.pi * 2 * np.sin(synthetic.BAND_HALF_WIDTH)
+    assert 7 < in_band.sum() / area / (5000 / (4 * np.pi)) < 13  # ~10x the mean density
+
+
 def test_supersample_order(oracle):
     rng = np.random.default_rng(3)
     img = rng.uniform(0, 2, (10, 14, 3))
