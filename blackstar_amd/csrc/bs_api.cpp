@@ -99,6 +99,9 @@ struct bs_ctx {
     bool pending = false;  // a render has been enqueued whose stats were not read back yet
     double last_wall_ms = 0;
     int last_zero_copy = 0;  // the last blocking render wrote the caller's page-locked buffer itself (no device image, no copy)
+    struct VerifiedRange { const void *host = nullptr; size_t bytes = 0; };
+    VerifiedRange verified[8];  // host buffers device_alias_of_pinned has walked page by page (registered memory without a queryable range)
+    int verified_next = 0;
     bs_stats_t stats{};
 };
 
@@ -165,30 +168,80 @@ struct StreamDrain {
 // bs_render of the C3 frame 5.45 -> 4.57 ms (kernel 4.38), C2 2.14 -> 1.49 ms (49.8 MB in 1.47 ms = 34 GB/s while tracing), C4
 // 21.6 -> 18.7 ms; the kernel time itself does not change (11 GB/s average is far below what PCIe takes in 96-B segments).
 // Returns the device alias of `host`, or nullptr for pageable memory (which takes the staged path).  BLACKSTAR_ZERO_COPY=0: off.
-double *device_alias_of_pinned(const bs_ctx *ctx, const void *host, size_t bytes)
+// *straddles (optional): set when `host` STARTS in page-locked memory but [host, host + bytes) is not contained in it -- a buffer
+// no path can deliver into: the kernel's stores would fault, and the runtime's own hipMemcpyAsync refuses it ("invalid argument":
+// it finds the registered range the pointer starts in and the size does not fit).  Callers turn that into BS_EINVAL.
+double *device_alias_of_pinned(bs_ctx *ctx, const void *host, size_t bytes, bool *straddles = nullptr)
 {
-    if (!ctx->zero_copy || !host || bytes == 0) return nullptr;
+    if (straddles) *straddles = false;
+    if (!host || bytes == 0) return nullptr;
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, host) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer) {
         (void)hipGetLastError();  // pageable memory is reported as an error: not one of ours
         return nullptr;
     }
-    // page-locked for ANOTHER device only (hipHostMalloc / hipHostRegister there without the Portable flag): not ours to write
-    if (a.device != ctx->device && !(a.allocationFlags & hipHostMallocPortable)) return nullptr;
-    // [host, host + bytes) must lie inside the ONE page-locked range `host` belongs to.  Probing the two ends is not enough: a
-    // buffer that starts in one hipHostRegister range and ends in another, with pageable memory (or a differently mapped range)
-    // in between, passes that test, and the kernel's stores through base alias + offset then fault on the GPU -- which ends the
-    // process instead of returning an error.  Anything that is not provably one range takes the staged path.
+    // [host, host + bytes) must lie inside page-locked memory from end to end.  Probing the two ends is not enough: a buffer that
+    // starts in one hipHostRegister range and ends in another, with pageable memory in between, passes that test, and the kernel's
+    // stores through base alias + offset then fault on the GPU -- which ends the process instead of returning an error.
+    const char *hp = static_cast<const char *>(host);
+    bool covered = false, known = false;
     void *base = nullptr;
     size_t size = 0;
-    if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, a.devicePointer) != hipSuccess || !base) {
+    // (1) the range the pointer belongs to, as the driver-style attributes report it: exact for hipHostMalloc (bs_host_alloc,
+    //     torch's pinned allocator) AND for hipHostRegister'ed memory -- for which hipMemGetAddressRange on ROCm 7.2 returns the
+    //     size but a NULL base (scripts/pinned_probe.py -> profiles/r03_pinned_probe.txt)
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, const_cast<void *>(host)) == hipSuccess && base &&
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, const_cast<void *>(host)) == hipSuccess && size) {
+        const char *hb = static_cast<const char *>(base);
+        known = true;
+        covered = hp >= hb && bytes <= size && static_cast<size_t>(hp - hb) <= size - bytes;
+    } else {
         (void)hipGetLastError();
+        base = nullptr;
+        size = 0;
+        if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, a.devicePointer) == hipSuccess && base) {
+            const char *db = static_cast<const char *>(base), *dp = static_cast<const char *>(a.devicePointer);
+            known = true;
+            covered = dp >= db && bytes <= size && static_cast<size_t>(dp - db) <= size - bytes;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (!known) {
+        // (2) no range to be had: walk the buffer page by page (every page page-locked, the device alias contiguous) -- once per
+        //     buffer: the last few verified (pointer, size) pairs are remembered, callers reuse their frame buffers
+        for (const auto &v : ctx->verified)
+            if (v.host == host && v.bytes == bytes) covered = true;
+        if (!covered) {
+            const char *dp = static_cast<const char *>(a.devicePointer);
+            const uintptr_t page = 4096;
+            covered = true;
+            for (uintptr_t q = (reinterpret_cast<uintptr_t>(hp) & ~(page - 1)) + page; covered && q < reinterpret_cast<uintptr_t>(hp) + bytes; q += page) {
+                hipPointerAttribute_t b;
+                if (hipPointerGetAttributes(&b, reinterpret_cast<const void *>(q)) != hipSuccess || b.type != hipMemoryTypeHost ||
+                    static_cast<const char *>(b.devicePointer) - reinterpret_cast<const char *>(q) != dp - hp) {
+                    (void)hipGetLastError();
+                    covered = false;
+                }
+            }
+            if (covered) {
+                ctx->verified[ctx->verified_next] = {host, bytes};
+                ctx->verified_next = (ctx->verified_next + 1) % (int)(sizeof ctx->verified / sizeof ctx->verified[0]);
+            }
+        }
+    }
+    if (!covered) {
+        if (straddles) *straddles = true;
         return nullptr;
     }
-    const char *dp = static_cast<const char *>(a.devicePointer);
-    if (dp < static_cast<const char *>(base) || bytes > size || static_cast<size_t>(dp - static_cast<const char *>(base)) > size - bytes) return nullptr;
+    if (!ctx->zero_copy) return nullptr;  // BLACKSTAR_ZERO_COPY=0: stage + copy (the runtime copies into page-locked memory directly)
+    // page-locked for ANOTHER device only (hipHostMalloc / hipHostRegister there without the Portable flag): not ours to write
+    if (a.device != ctx->device && !(a.allocationFlags & hipHostMallocPortable)) return nullptr;
     return static_cast<double *>(a.devicePointer);
 }
+
+const char *kStraddleMsg = "output buffer starts in page-locked memory but is not contained in it (it runs past the end of its hipHostMalloc / "
+                           "hipHostRegister range, e.g. into pageable memory between two registered ranges): neither the kernel nor the runtime's copy can deliver into it";
 
 int ensure_scratch(bs_ctx *ctx, size_t bytes)
 {
@@ -577,7 +630,9 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     }
     // a page-locked out_rgb8 is written by the sRGB8 kernel itself (zero copy), otherwise staged through d_u8
     unsigned char *u8_target = ctx->d_u8;
-    if (double *alias = device_alias_of_pinned(ctx, out_rgb8, n)) u8_target = reinterpret_cast<unsigned char *>(alias);
+    bool straddles = false;
+    if (double *alias = device_alias_of_pinned(ctx, out_rgb8, n, &straddles)) u8_target = reinterpret_cast<unsigned char *>(alias);
+    if (straddles) return fail(BS_EINVAL, kStraddleMsg);
     StreamDrain drain(ctx);
     // doRender (app/Main.hs:105-123): render -> bloom if bloomStrength /= 0 -> writeImg's sRGB + toWord8, all in HBM
     rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
@@ -650,7 +705,10 @@ int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double
     size_t need = (size_t)cfg->width * (size_t)(row1 - row0) * 3;
     if (out_doubles < need) return fail(BS_EINVAL, "output buffer too small");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (double *alias = device_alias_of_pinned(ctx, out_rgb, need * sizeof(double))) {  // page-locked buffer: the kernel writes it
+    bool straddles = false;
+    double *alias = device_alias_of_pinned(ctx, out_rgb, need * sizeof(double), &straddles);
+    if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+    if (alias) {  // page-locked buffer: the kernel writes it
         StreamDrain drain(ctx);
         int rc = enqueue_render(ctx, cfg, alias, need, ctx->stream, row0, row1);
         if (rc) return rc;
@@ -718,9 +776,11 @@ static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *c
     {   // every frame's buffer page-locked: the kernels write them directly, two frames in flight on two streams, no copies
         std::vector<double *> alias;
         bool all = true;
-        for (int i = first; i < n_frames && all; i += step) {
-            double *a = device_alias_of_pinned(ctx, outs[i], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double));
-            all = a != nullptr;
+        for (int i = first; i < n_frames; i += step) {  // (every buffer is looked at: one that straddles fails the call before any launch)
+            bool straddles = false;
+            double *a = device_alias_of_pinned(ctx, outs[i], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double), &straddles);
+            if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+            all = all && a != nullptr;
             alias.push_back(a);
         }
         if (all) {
@@ -856,7 +916,9 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
         if (k >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
         unsigned char *target = stage[b];
-        if (double *alias = device_alias_of_pinned(ctx, outs[i], n)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
+        bool straddles = false;
+        if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
+        if (straddles) return fail(BS_EINVAL, kStraddleMsg);
         rc = enqueue_render(ctx, &cfgs[i], img[b], n, cs[b], 0, -1, true, true, /*quiet=*/true);
         if (rc) return rc;
         const double st = strengths ? strengths[i] : 0.0;

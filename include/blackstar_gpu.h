@@ -129,7 +129,10 @@ int bs_device_count(void);
  * directly over PCIe -- no device image and no copy: the call costs the kernel time (C3 frame: 4.6 ms).  Into pageable memory the
  * frame is traced as two consecutive launches of half the rows each, so that the first half's copy to the host overlaps the
  * second half's kernel (5.4 ms into a buffer that has been touched before, 9 ms into a fresh one: first-touch page faults).
- * Pixels and bs_stats are those of the whole frame either way. */
+ * Pixels and bs_stats are those of the whole frame either way (bs_stats_t.zero_copy says which way it went).
+ * A buffer that STARTS in page-locked memory must be contained in that one page-locked range: one that runs past its end (into
+ * pageable memory, or across a gap between two hipHostRegister ranges) is refused with BS_EINVAL -- the kernel's stores would fault
+ * there, and the runtime's own copy refuses such a destination too.  The same holds for every host-output entry point. */
 int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles);
 
 /* Same, but the image stays in HBM: d_out_rgb is a device pointer on the context's device, the work is

@@ -1382,11 +1382,19 @@ def test_effective_mode_is_reported(tree):
     assert not np.array_equal(bs.render(cfg, tree), fast_img)
 
 
+def _cfg_obj(cfg):
+    """A Config object (the form render_rgb8 takes) for a bs_config dict."""
+    c = bs.Config.from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "default-aa.yaml"))
+    c = c.with_resolution(cfg["width"], cfg["height"])
+    assert c.to_bs_config() == cfg
+    return c
+
+
 def test_zero_copy_only_inside_one_page_locked_range(tree):
     """bs_stats_t.zero_copy tells which delivery path a blocking render took.  Page-locked buffers (bs_host_alloc, torch's pinned
     allocator, hipHostRegister) are written by the kernel itself; a buffer that starts in one hipHostRegister range and ends in
     another with PAGEABLE memory between them must NOT be (round 2 probed only its two ends and would have faulted on the GPU,
-    which ends the process): it takes the staged path and still delivers the right pixels."""
+    which ends the process): such a buffer is refused with BS_EINVAL."""
     import torch
     cfg = scenes.with_res(scenes.DEFAULT_AA, 320, 181)
     n = 181 * 320 * 3
@@ -1417,17 +1425,41 @@ def test_zero_copy_only_inside_one_page_locked_range(tree):
             inside[:] = -1
             bs.render(cfg, tree, out=inside)
             assert tree.stats()["zero_copy"] == 1 and np.array_equal(inside, ref)
-            spanning = view(256 << 10)                               # first range -> pageable hole -> second range
-            assert (256 << 10) + n * 8 > b0 and (256 << 10) + n * 8 < b1
-            spanning[:] = -1
-            bs.render(cfg, tree, out=spanning)
-            assert tree.stats()["zero_copy"] == 0, "a buffer spanning two page-locked ranges was handed to the kernel"
-            assert np.array_equal(spanning, ref)
-            tail = view(b1 - n * 8 + 4096)                           # ends one page past the second range
-            bs.render(cfg, tree, out=tail)
-            assert tree.stats()["zero_copy"] == 0 and np.array_equal(tail, ref)
+            # first range -> pageable hole -> second range; and a buffer that ends one page past its range.  Nothing can deliver
+            # into these (the runtime's own hipMemcpyAsync refuses them too): BS_EINVAL, the buffer untouched, the context usable.
+            for off in (256 << 10, b1 - n * 8 + 4096):
+                bad = view(off)
+                bad[:] = -1
+                with pytest.raises(bs._lib.BlackstarError, match="not contained"):
+                    bs.render(cfg, tree, out=bad)
+                assert (bad == -1).all()
+                rgb8 = np.frombuffer((C.c_ubyte * n).from_address(base + (b1 - n + 4096)), np.uint8).reshape(181, 320, 3)
+                with pytest.raises(bs._lib.BlackstarError, match="not contained"):
+                    bs.render_rgb8(_cfg_obj(cfg), tree, out=rgb8)
+                bs.render(cfg, tree, out=inside)
+                assert tree.stats()["zero_copy"] == 1 and np.array_equal(inside, ref)
         finally:
             hip.hipHostUnregister(base + a0)
             hip.hipHostUnregister(base + b0)
     finally:
         tree.set_mode(_lib.BS_MODE_STRICT)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("which", ["uniform", "clustered"])
+def test_gpu_against_the_reference_itself(which, mode):
+    """The HIP path against the REFERENCE's own outputs (tools/ghc_pin): render in both modes, starLookup, bloom (bit-exact) and
+    writeImg's bytes.  Skips until a GHC-made dump exists under tests/golden/ghc/ -- see tests/ghc_pin.py."""
+    import ghc_pin
+    if not ghc_pin.available(which):
+        pytest.skip(ghc_pin.SKIP_REASON.format(set=which))
+    d = ghc_pin.Dump(which)
+    t = bs.StarTree(bs.read_map(d.catalogue_bytes()), device=0)
+    t.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+    try:
+        rtol, atol = (RTOL_FAST, ATOL_FAST) if mode == "fast" else (RTOL_STRICT, ATOL_STRICT)
+        rep = ghc_pin.compare(d, render=lambda cfg: bs.render(cfg, t), star_lookup=lambda i, s, dirs: bs.star_lookup(t, i, s, dirs),
+                              bloom=lambda st, dv, img: bs.bloom(st, dv, img, t), srgb8=lambda img: bs.srgb8(img, t), rtol=rtol, atol=atol)
+        print(f"{which}/{mode}: {rep['values']} values vs GHC, {rep['bit_equal'] / rep['values']:.2%} bit-equal, worst rel {rep['worst_rel']:.2e}")
+    finally:
+        t.close()

@@ -2,6 +2,7 @@
 C restatement vs golden vectors from the independent numpy restatement, vs 50-digit mpmath, vs physics and
 colour known-answers."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -364,3 +365,85 @@ def _edge_locus_accepted(edge):
     """The bar of the disk-edge pin: onsets matched at >= 120 of the 180 angles, reference - render between -0.5 and +2.2 px on
     average (the older revision's intensity law delays its threshold crossing by 1-2 px), scatter below 2 px."""
     return len(edge) >= 120 and -0.5 < edge[:, 2].mean() < 2.2 and edge[:, 2].std() < 2.0
+
+
+# ---- the reference itself as the pin (tools/ghc_pin) --------------------------------------------------------------------------
+
+def _oracle_callables(oracle, d):
+    ix = oracle.Index(oracle.read_ppm(d.catalogue_bytes()))
+    return dict(render=lambda cfg: oracle.render(cfg, ix, threads=0)[0],
+                star_lookup=lambda i, s, dirs: np.stack([oracle.star_lookup(ix, i, s, v)[0] for v in dirs]),
+                bloom=oracle.bloom, srgb8=oracle.srgb8)
+
+
+@pytest.mark.parametrize("which", ["uniform", "clustered"])
+def test_oracle_against_the_reference_itself(which, oracle):
+    """The C restatement against the output of the REFERENCE's own render / bloom / writeImg / starLookup on this repository's
+    fixed inputs (tools/ghc_pin/Dump.hs).  This is the test that would turn 'parity unpinned' into 'pinned'; it needs a dump made with
+    GHC, which this image cannot produce -- so it skips, loudly, until tests/golden/ghc/ exists."""
+    import ghc_pin
+    if not ghc_pin.available(which):
+        pytest.skip(ghc_pin.SKIP_REASON.format(set=which))
+    d = ghc_pin.Dump(which)
+    rep = ghc_pin.compare(d, rtol=1e-12, atol=1e-15, **_oracle_callables(oracle, d))
+    print(f"{which}: {rep['scenes']} scenes, {rep['values']} values vs GHC ({' '.join(d.meta.get('compiler', []))}): "
+          f"{rep['bit_equal'] / rep['values']:.2%} bit-equal, worst rel {rep['worst_rel']:.2e}")
+    # SURVEY Appendix B, recalled semantics this settles: linear.normalize's shortcut, kdt inRadius '<=', massiv-io HSI->RGB, toWord8
+    stars = oracle.read_ppm(d.catalogue_bytes())
+    mine = sorted(map(tuple, np.stack([stars["x"], stars["y"], stars["z"], stars["mag"].astype(float), stars["hue"], stars["sat"]], axis=1).tolist()))
+    assert sorted(map(tuple, d.assocs().tolist())) == mine, "KdMap.assocs (readMap + starColor') differs from the restated catalogue reader"
+    from blackstar_amd import kdt_file  # row f4: the recalled cereal layout of stars.kdt against a real file
+    back = kdt_file.read_kdt(d.kdt_bytes())
+    got = np.stack([back["x"], back["y"], back["z"], back["mag"].astype(float), back["hue"], back["sat"]], axis=1)
+    assert np.array_equal(got, d.assocs()), "stars.kdt decodes to other stars (or another order) than KdMap.assocs"
+
+
+def test_ghc_pin_harness_on_a_stand_in_dump(tmp_path, oracle):
+    """Self-test of the comparison harness ONLY -- not a pin.  A directory in the dump's format is written from the numpy restatement
+    (never into tests/golden/ghc), the C oracle is compared against it through the very code path a real dump takes, and a
+    corrupted copy must be caught.  Proves the reader, the PNG decoder and the comparisons work before a real dump exists."""
+    import shutil
+    import ghc_pin
+    import blackstar_amd as bs
+    from blackstar_amd import kdt_file
+    from blackstar_amd.raytracer import write_png
+    which = "clustered"
+    out = tmp_path / "dumps" / which
+    out.mkdir(parents=True)
+    inp = os.path.join(ghc_pin.INPUTS, which)
+    cat = open(os.path.join(inp, "catalogue.ppm"), "rb").read()
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import parse_catalogue
+    stars6 = parse_catalogue(cat)
+    name = "clustered_default_aa_96x54"
+    cfg = bs.Config.from_file(os.path.join(inp, "scenes", name + ".yaml"))
+    img, _ = np_oracle.render(cfg.to_bs_config(), stars6)
+    img.astype("<f8").tofile(out / f"{name}.render.f64")
+    bl = np_oracle.bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img)
+    bl.astype("<f8").tofile(out / f"{name}.bloom.f64")
+    write_png(np_oracle.srgb8(bl), str(out / f"{name}.png"))
+    dirs = np.fromfile(os.path.join(inp, "dirs.f64"), "<f8").reshape(-1, 3)
+    i, s = map(float, open(os.path.join(inp, "lookup.txt")).read().split())
+    np_oracle.star_lookup(stars6, i, s, dirs)[0].astype("<f8").tofile(out / "starlookup.f64")
+    rec = np.frombuffer(cat, np.dtype([("ra", ">f8"), ("dec", ">f8"), ("sp", "u1"), ("skip", "u1"), ("mag", ">i2"), ("pad", "u1", 8)]), offset=28)
+    kdt = kdt_file.write_kdt(stars6[:, :3], rec["mag"], "".join(chr(c) for c in rec["sp"]))
+    (out / "stars.kdt").write_bytes(kdt)
+    back = kdt_file.read_kdt(kdt)
+    np.stack([back["x"], back["y"], back["z"], back["mag"].astype(float), back["hue"], back["sat"]], axis=1).astype("<f8").tofile(out / "assocs.f64")
+    (out / "manifest.txt").write_text(f"compiler STAND-IN numpy-restatement\nstars {len(stars6)} dirs {len(dirs)}\nscene {name} 96 54 bloom\n")
+    assert ghc_pin.available(which, root=str(tmp_path / "dumps"))
+    d = ghc_pin.Dump(which, root=str(tmp_path / "dumps"))
+    assert np.array_equal(d.png(name), np_oracle.srgb8(bl))  # own PNG decoder reads back what the encoder wrote
+    rep = ghc_pin.compare(d, rtol=1e-12, atol=1e-15, **_oracle_callables(oracle, d))
+    assert rep["scenes"] == 1 and rep["values"] == 96 * 54 * 3 + 3 * len(dirs) and rep["bit_equal"] > 0.9 * rep["values"]
+    # a single wrong value anywhere must fail the comparison
+    for victim, offset in ((f"{name}.render.f64", 8 * 1234), ("starlookup.f64", 0), (f"{name}.bloom.f64", 8 * 77)):
+        bad_root = tmp_path / ("bad_" + victim)
+        shutil.copytree(tmp_path / "dumps", bad_root)
+        raw = bytearray((bad_root / which / victim).read_bytes())
+        v = np.frombuffer(bytes(raw[offset:offset + 8]), "<f8")[0]
+        raw[offset:offset + 8] = np.array([v * (1 + 1e-9) + 1e-9], "<f8").tobytes()
+        (bad_root / which / victim).write_bytes(bytes(raw))
+        with pytest.raises(AssertionError):
+            ghc_pin.compare(ghc_pin.Dump(which, root=str(bad_root)), rtol=1e-12, atol=1e-15, **_oracle_callables(oracle, d))

@@ -1,0 +1,115 @@
+{-# LANGUAGE ScopedTypeVariables #-}
+-- ghc-pin-dump: runs the REFERENCE's own exported functions on fixed inputs and writes their raw outputs, so that the
+-- restatements in blackstar_amd's repository (oracle/, and through them the HIP kernels) can be pinned by the reference
+-- itself instead of by a recollection of it.
+--
+-- This program contains no algorithm of its own.  It links against the `blackstar` LIBRARY stanza of the reference
+-- (blackstar.cabal:16-24 exposes Raytracer, StarMap, ConfigFile, ImageFilters) and calls:
+--     StarMap.readMapFromFile / buildStarTree / treeToByteString / readTreeFromFile / starLookup
+--     Raytracer.render / Raytracer.writeImg
+--     ImageFilters.bloom
+--     Data.Yaml.decodeFileEither  (the way app/Main.hs:85 decodes a scene file)
+--     Data.KdMap.Static.assocs    (kdt: the order and content of the tree the reference builds)
+--
+-- It could NOT be compiled where it was written (no GHC in that image): expect to fix an import or two.  Written against
+-- resolver lts-13.16 (stack.yaml:1): GHC 8.6.4, massiv 0.2.x (`size` returns an Ix2), massiv-io 0.1.x, kdt 0.2.4, cereal 0.5.8.
+-- See README.md next to this file for the cabal stanza and the output layout.
+--
+-- usage: ghc-pin-dump INPUT_DIR OUTPUT_DIR
+--   INPUT_DIR/catalogue.ppm     PPM catalogue bytes (28-byte header + 28-byte records, src/StarMap.hs:45-58)
+--   INPUT_DIR/dirs.f64          n x 3 little-endian doubles: un-normalised directions for starLookup
+--   INPUT_DIR/lookup.txt        one line: "<starIntensity> <starSaturation>" used for dirs.f64
+--   INPUT_DIR/scenes/*.yaml     scene files in the reference's own format (scenes/default.yaml)
+module Main (main) where
+
+import           Control.Monad            (forM_, unless)
+import qualified Data.ByteString          as B
+import qualified Data.ByteString.Builder  as BB
+import qualified Data.ByteString.Lazy     as BL
+import qualified Data.KdMap.Static        as K
+import           Data.List                (sort)
+import qualified Data.Massiv.Array        as A
+import           Data.Massiv.Array        (Ix2 (..))
+import           Data.Massiv.Array.IO     (Image)
+import           Data.Serialize.Get       (getFloat64le, runGet)
+import           Data.Version             (showVersion)
+import qualified Data.Yaml                as Y
+import           Graphics.ColorSpace
+import           Linear                   (V3 (..))
+import           System.Directory         (createDirectoryIfMissing, listDirectory)
+import           System.Environment       (getArgs)
+import           System.Exit              (die)
+import           System.FilePath          (takeBaseName, takeExtension, (<.>), (</>))
+import           System.Info              (arch, compilerName, compilerVersion, os)
+import           System.IO                (IOMode (WriteMode), hPutStrLn, withFile)
+
+import           ConfigFile
+import           ImageFilters             (bloom)
+import           Raytracer                (render, writeImg)
+import           StarMap
+
+-- h*w*3 little-endian doubles, row-major, interleaved RGB: the layout of bs_render's out_rgb
+imageBytes :: Image A.U RGB Double -> BL.ByteString
+imageBytes img = BB.toLazyByteString . mconcat $
+    [ BB.doubleLE r <> BB.doubleLE g <> BB.doubleLE b | PixelRGB r g b <- A.toList img ]
+
+doubles :: B.ByteString -> [Double]
+doubles bs
+    | B.null bs = []
+    | otherwise = case runGet getFloat64le (B.take 8 bs) of
+        Right d -> d : doubles (B.drop 8 bs)
+        Left e  -> error e
+
+triples :: [Double] -> [V3 Double]
+triples (x : y : z : rest) = V3 x y z : triples rest
+triples _                  = []
+
+main :: IO ()
+main = do
+    args <- getArgs
+    (inDir, outDir) <- case args of
+        [i, o] -> return (i, o)
+        _      -> die "usage: ghc-pin-dump INPUT_DIR OUTPUT_DIR"
+    createDirectoryIfMissing True outDir
+
+    -- generate-tree's path (app/GenerateTree.hs:18-26) followed by blackstar's (app/Main.hs:46): the catalogue goes through
+    -- readMap, kdt's build, cereal's encoder AND decoder, and starColor' before anything is rendered
+    estars <- readMapFromFile (inDir </> "catalogue.ppm")
+    stored <- either die return estars
+    let storedTree = buildStarTree stored
+    B.writeFile (outDir </> "stars.kdt") (treeToByteString storedTree)
+    etree <- readTreeFromFile (outDir </> "stars.kdt")
+    tree <- either die return etree
+
+    -- KdMap.assocs after starColor': n x 6 doubles (x, y, z, mag*100, hue, sat) in the tree's own order
+    BL.writeFile (outDir </> "assocs.f64") . BB.toLazyByteString . mconcat $
+        [ mconcat (map BB.doubleLE [x, y, z, fromIntegral mag, hue, sat]) | (V3 x y z, (mag, hue, sat)) <- K.assocs tree ]
+
+    -- starLookup on fixed directions: n x 3 doubles
+    [inten, satur] <- map read . words <$> readFile (inDir </> "lookup.txt")
+    dirs <- triples . doubles <$> B.readFile (inDir </> "dirs.f64")
+    BL.writeFile (outDir </> "starlookup.f64") . BB.toLazyByteString . mconcat $
+        [ BB.doubleLE r <> BB.doubleLE g <> BB.doubleLE b | d <- dirs, let PixelRGB r g b = starLookup tree inten satur d ]
+
+    -- every scene: render, bloom with the scene's own parameters (app/Main.hs:113-118), writeImg (:121-123)
+    names <- sort . filter ((== ".yaml") . takeExtension) <$> listDirectory (inDir </> "scenes")
+    withFile (outDir </> "manifest.txt") WriteMode $ \hdl -> do
+        hPutStrLn hdl $ unwords ["compiler", compilerName, showVersion compilerVersion, os, arch]
+        hPutStrLn hdl $ unwords ["stars", show (length stored), "dirs", show (length dirs)]
+        forM_ names $ \fn -> do
+            ecfg <- Y.decodeFileEither (inDir </> "scenes" </> fn)
+            cfg :: Config <- either (die . Y.prettyPrintParseException) return ecfg
+            let name = takeBaseName fn
+                scn = scene cfg
+                img = render cfg tree
+                h :. w = A.size img
+            BL.writeFile (outDir </> name <.> "render.f64") (imageBytes img)
+            final <- if bloomStrength scn /= 0
+                then do
+                    bloomed <- bloom (bloomStrength scn) (bloomDivider scn) img
+                    BL.writeFile (outDir </> name <.> "bloom.f64") (imageBytes bloomed)
+                    return bloomed
+                else return img
+            writeImg final (outDir </> name <.> "png")
+            hPutStrLn hdl $ unwords ["scene", name, show w, show h, if bloomStrength scn /= 0 then "bloom" else "nobloom"]
+    unless (null names) $ putStrLn ("wrote " ++ show (length names) ++ " scenes to " ++ outDir)

@@ -1,0 +1,93 @@
+"""Writes tools/ghc_pin/inputs/: everything ghc-pin-dump (Dump.hs) needs, derived from this repository's committed fixtures.
+
+    python tools/ghc_pin/make_inputs.py
+
+  inputs/uniform/    catalogue.ppm = tests/golden/catalogue_2000.ppm; scenes/*.yaml = the configurations of the eleven image goldens
+                     (tests/conftest.py IMAGE_GOLDENS) in the reference's own scene-file format; dirs.f64 = 10 000 starLookup directions
+  inputs/clustered/  catalogue.ppm = tests/golden/catalogue_clustered.ppm (clusters of 5..40 stars inside one lookup radius);
+                     the clustered frame; dirs.f64 = the 1 500 directions of tests/golden/lookup_clustered.npz
+
+kdt cannot build an empty tree (Data.KdMap.Static.build errors on []), so the reference has no "no star map" run: the C2 scene is
+written with starIntensity 0 instead (every star then contributes exactly 0).
+"""
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import GOLDEN, IMAGE_GOLDENS, load_golden  # noqa: E402
+from oracle import scenes  # noqa: E402
+
+DEFAULT_DISK = (0.16, 0.1, 0.95)  # src/ConfigFile.hs:74: left out of the file so the reference's own default is used, bit for bit
+ANI_BLOOM = (0.7, 25)             # animations/default-ani.yaml:9-10
+
+
+def bloom_of(cfg):
+    """bloomStrength / bloomDivider of the scene file a golden's configuration comes from (not an input of render)."""
+    for name, ref in scenes.REFERENCE_SCENES.items():
+        if all(k in ("width", "height") or (tuple(cfg[k]) if isinstance(cfg[k], (list, tuple)) else cfg[k]) == ref[k] for k in ref):
+            return scenes.REFERENCE_BLOOM[name]
+    return ANI_BLOOM
+
+
+def scene_yaml(cfg, bloom):
+    def vec(v):
+        return "[" + ", ".join(repr(float(x)) for x in v) + "]"
+    lines = ["camera:", f"  position: {vec(cfg['cam_pos'])}", f"  lookAt: {vec(cfg['cam_lookat'])}", f"  upVec: {vec(cfg['cam_up'])}",
+             f"  fov: {float(cfg['fov'])!r}", "scene:", f"  stepSize: {float(cfg['step_size'])!r}", f"  bloomStrength: {float(bloom[0])!r}",
+             f"  bloomDivider: {int(bloom[1])}", f"  starIntensity: {float(cfg['star_intensity'])!r}", f"  starSaturation: {float(cfg['star_saturation'])!r}"]
+    if tuple(cfg["disk_hsi"]) != DEFAULT_DISK:
+        deg = cfg["disk_hsi"][0] * 360
+        assert deg / 360 == cfg["disk_hsi"][0], "hue does not survive ConfigFile.hs:51's x / 360"
+        lines.append(f"  diskColor: [{deg!r}, {float(cfg['disk_hsi'][1])!r}, {float(cfg['disk_hsi'][2])!r}]")
+    lines += [f"  diskOpacity: {float(cfg['disk_opacity'])!r}", f"  diskInner: {float(cfg['disk_inner'])!r}", f"  diskOuter: {float(cfg['disk_outer'])!r}",
+              f"  resolution: [{int(cfg['width'])}, {int(cfg['height'])}]", f"  supersampling: {'true' if cfg['supersampling'] else 'false'}"]
+    return "\n".join(lines) + "\n"
+
+
+def write_set(name, catalogue, cfgs, dirs, intensity, saturation):
+    import blackstar_amd as bs
+    d = os.path.join(HERE, "inputs", name)
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(os.path.join(d, "scenes"))
+    shutil.copyfile(os.path.join(GOLDEN, catalogue), os.path.join(d, "catalogue.ppm"))
+    np.ascontiguousarray(dirs, "<f8").tofile(os.path.join(d, "dirs.f64"))
+    with open(os.path.join(d, "lookup.txt"), "w") as f:
+        f.write(f"{intensity!r} {saturation!r}\n")
+    for key, (cfg, bloom) in cfgs.items():
+        path = os.path.join(d, "scenes", key + ".yaml")
+        with open(path, "w") as f:
+            f.write(scene_yaml(cfg, bloom))
+        back = bs.Config.from_file(path)  # the product's own decoder must read the file back to the very same numbers
+        assert back.to_bs_config() == {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()}, key
+        assert (back.scene.bloomStrength, back.scene.bloomDivider) == tuple(bloom), key
+    print(name, len(cfgs), "scenes,", len(dirs), "directions")
+
+
+def main():
+    cfgs = {}
+    for g in IMAGE_GOLDENS:
+        cfg = load_golden("image_" + g)["cfg"]
+        key, bloom = g, bloom_of(cfg)
+        if "nostars" in g:
+            cfg = dict(cfg, star_intensity=0.0)
+            key = g.replace("nostars", "starintensity0")
+        cfgs[key] = (cfg, bloom)
+    rng = np.random.default_rng(20260930)
+    stars = np.load(os.path.join(GOLDEN, "catalogue_2000_parsed.npz"))["stars"]
+    near = stars[rng.integers(0, len(stars), 6000), :3]
+    dirs = np.concatenate([near * rng.uniform(0.5, 3, (6000, 1)) + rng.normal(scale=5e-4, size=(6000, 3)), rng.normal(size=(4000, 3))])
+    write_set("uniform", "catalogue_2000.ppm", cfgs, dirs, 0.4, 1.5)
+    gc = load_golden("image_clustered_default_aa_96x54")["cfg"]
+    lk = load_golden("lookup_clustered")
+    write_set("clustered", "catalogue_clustered.ppm", {"clustered_default_aa_96x54": (gc, bloom_of(gc))}, lk["dirs"], float(lk["intensity"]), float(lk["saturation"]))
+
+
+if __name__ == "__main__":
+    main()
