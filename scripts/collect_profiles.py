@@ -9,10 +9,10 @@ import sys
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+G, P = os.path.join(ROOT, "gpurun_out", *sys.argv[2:3]), os.path.join(ROOT, "profiles")  # optional 2nd argument: sub-directory of gpurun_out
 os.makedirs(P, exist_ok=True)
 summary = {}
-for m in ("fast", "strict"):
+for m in ("fast", "strict", "clustered"):  # "clustered": FAST mode on the non-uniform sky (bench.py --catalogue clustered)
     src = os.path.join(G, f"prof_{m}", f"{m}_kernel_stats.csv")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{R}_{m}_kernel_stats.csv"))
@@ -33,7 +33,8 @@ for m in ("fast", "strict"):
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt)) if "trace_frame" in r["Kernel_Name"]]
             if d:
                 pmc[f"kernel_ns_in_{grp}_pass"] = sum(d) / len(d)
-    summary[m] = pmc
+    if pmc or m != "clustered":
+        summary[m] = pmc
 for f in ("bench_default.json", "bench_strict.json", "ubench.json"):
     if os.path.exists(os.path.join(G, f)):
         shutil.copy(os.path.join(G, f), os.path.join(P, f"{R}_{f}"))

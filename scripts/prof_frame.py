@@ -15,13 +15,13 @@ ap.add_argument("--mode", default="fast")
 ap.add_argument("--frames", type=int, default=3)
 ap.add_argument("--scene", default="default-aa.yaml")
 ap.add_argument("--res", default="")
-ap.add_argument("--stars", default="synthetic", help="synthetic | none")
+ap.add_argument("--stars", default="synthetic", help="synthetic | clustered | none | PATH of a PPM catalogue file")
 a = ap.parse_args()
 cfg = bs.Config.from_file(os.path.join(ROOT, "scenes", a.scene))
 if a.res:
     w, h = a.res.split("x")
     cfg = cfg.with_resolution(int(w), int(h))
-tree = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes()) if a.stars == "synthetic" else None)
+tree = bs.StarTree(None if a.stars == "none" else bs.read_map(synthetic.catalogue_bytes(a.stars)))
 tree.set_mode(_lib.BS_MODE_FAST if a.mode == "fast" else _lib.BS_MODE_STRICT)
 for _ in range(a.frames):
     img = bs.render(cfg, tree)
