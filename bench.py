@@ -620,9 +620,14 @@ def run_ranks(args):
                                           [local_rank], n_sus)
         fence()
         ms_all = all_ranks(per_dev[0]["ms_per_frame"])
+        devices = smp.summary()
+        if world > 1:  # every rank sampled its own device: collect them in rank order
+            objs = [None] * world
+            dist.all_gather_object(objs, devices)
+            devices = [d for o in objs for d in (o or [None])]
         sustained = dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / max(ms_all) / 1e3, per_rank_ms_per_frame=ms_all,
-                         device=smp.summary(), note="back-to-back launches of the same frame on one stream per GPU, all ranks at once; "
-                                                    "Mpixel_s from the slowest rank")
+                         device=devices, note="back-to-back launches of the same frame on one stream per GPU, all ranks at once; "
+                                              "Mpixel_s from the slowest rank; device = sampled sclk / power, one entry per rank")
 
     if rank == 0:
         frames = args.steps * world
