@@ -114,9 +114,13 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
                 if (!std::isfinite(f.v[i])) { err = std::string(f.name) + " is not finite (the reference's colorize would never terminate: src/Raytracer.hs:80-86)"; return false; }
         if (!(c.step_size > 0)) { err = "scene.stepSize must be positive (the reference's colorize would never terminate: src/Raytracer.hs:80-86)"; return false; }
         if (c.disk_inner < 0 || c.disk_outer < 0) { err = "scene.diskInner / scene.diskOuter must not be negative"; return false; }
-        if (c.cam_lookat[0] == c.cam_pos[0] && c.cam_lookat[1] == c.cam_pos[1] && c.cam_lookat[2] == c.cam_pos[2]) {
-            err = "camera.lookAt equals camera.position: no viewing direction (every ray would have velocity 0 and never terminate)";
-            return false;
+        {   // linear's normalize leaves a vector with |v|^2 <= 1e-12 as it is: a view direction that short makes every ray's velocity
+            // that short too (generateRay never gets a unit vector to work with), and the rays crawl: >= 1e8 steps to leave the scene
+            const double dv[3] = {c.cam_lookat[0] - c.cam_pos[0], c.cam_lookat[1] - c.cam_pos[1], c.cam_lookat[2] - c.cam_pos[2]};
+            if (quadrance(dv) <= 1e-12) {
+                err = "camera.lookAt equals camera.position (to within 1e-6): no viewing direction -- every ray would have velocity ~0 and never terminate";
+                return false;
+            }
         }
     }
     std::memcpy(p.cam, c.cam_pos, sizeof p.cam);

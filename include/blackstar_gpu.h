@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
- * non-finite fields, stepSize <= 0, negative radii, lookAt == position).  1: rounds 1-2.  A binding should compare
+ * non-finite fields, stepSize <= 0, negative radii, lookAt within 1e-6 of position).  1: rounds 1-2.  A binding should compare
  * bs_abi_version() with the BS_ABI_VERSION it was written against before anything else. */
 #define BS_ABI_VERSION 2
 
@@ -39,7 +39,7 @@ enum {
     BS_OK = 0,
     BS_EINVAL = -1,  /* bad argument: null pointer, non-positive resolution, buffer too small, bad hue; or a configuration on which the
                       * reference's colorize never terminates (src/Raytracer.hs:80-86 has no iteration cap): a non-finite value anywhere
-                      * in bs_config, stepSize <= 0, a negative disk radius, lookAt == position.  Returned before any GPU work. */
+                      * in bs_config, stepSize <= 0, a negative disk radius, lookAt within 1e-6 of position.  Returned before any GPU work. */
     BS_EDEVICE = -2, /* no such HIP device / HIP runtime error */
     BS_ENOMEM = -3,  /* host or device allocation failed */
     BS_ECAPPED = -4, /* never returned: rays stopped by the step cap are reported through bs_stats_t.capped only */

@@ -188,6 +188,7 @@ BAD_CONFIGS = {  # what -> (override, substring of the message).  src/Raytracer.
     "NaN diskOpacity": (dict(disk_opacity=float("nan")), "diskOpacity"),
     "NaN starIntensity": (dict(star_intensity=float("nan")), "starIntensity"),
     "lookAt == position": (dict(cam_lookat=(0.0, 1.0, -20.0)), "lookAt equals"),
+    "lookAt 1e-7 from position": (dict(cam_lookat=(1e-7, 1.0, -20.0)), "lookAt equals"),
     "bad hue": (dict(disk_hsi=(1.0, 0.1, 1.0)), "not properly scaled"),
     "zero width": (dict(width=0), "resolution"),
 }
