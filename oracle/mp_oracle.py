@@ -40,3 +40,38 @@ def trace(vel, pos, h, safe, max_steps=100000):
         v = [a + (b + 2 * c + 2 * d + e) * h / 6 for a, b, c, d, e in zip(v, k1v, k2v, k3v, k4v)]
         p = [a + (b + 2 * c + 2 * d + e) * h / 6 for a, b, c, d, e in zip(p, k1p, k2p, k3p, k4p)]
     return steps, 2, v, p
+
+
+def star_lookup(stars, intensity, saturation, vel):
+    """starLookup (src/StarMap.hs:93-115) in 50-digit arithmetic for ONE direction: stars is an (n, 6) float array x, y, z, hue, sat,
+    mag (binary64 values taken as exact).  Returns (rgb as mpf, number of stars within the radius, smallest |d^2 - r^2| / r^2 over
+    all stars = how close the hit SET is to flipping).  Pins the colour arithmetic of lookups that sum many stars independently
+    of libm, of FMA contraction and of the summation order (which only matters at the 1e-16 level this evaluation sits far below)."""
+    w = mp.mpf("0.0005")
+    r2 = (3 * w) ** 2
+    v = [mp.mpf(float(x)) for x in vel]
+    l = v[0] ** 2 + v[1] ** 2 + v[2] ** 2
+    n = v if (abs(l) <= mp.mpf("1e-12") or abs(1 - l) <= mp.mpf("1e-12")) else [x / mp.sqrt(l) for x in v]
+    a = mp.log(2) / 50
+    acc = [mp.mpf(0)] * 3
+    hits, margin = 0, mp.inf
+    pi = mp.pi
+    for x, y, z, hue, sat, mag in stars:
+        d2 = (mp.mpf(float(x)) - n[0]) ** 2 + (mp.mpf(float(y)) - n[1]) ** 2 + (mp.mpf(float(z)) - n[2]) ** 2
+        margin = min(margin, abs(d2 - r2) / r2)
+        if d2 > r2:
+            continue
+        hits += 1
+        val = mp.mpf(float(intensity)) * min(mp.mpf(1), mp.exp(a * (950 - mp.mpf(float(mag))) - d2 / (2 * w ** 2)))
+        s = mp.mpf(float(saturation)) * mp.mpf(float(sat))
+        h = mp.mpf(float(hue)) * 2 * pi
+        is_ = val * s
+        second = val - is_
+        if h < 2 * pi / 3:
+            r = val + is_ * mp.cos(h) / mp.cos(pi / 3 - h); b = second; g = val + 2 * is_ + b - r
+        elif h < 4 * pi / 3:
+            g = val + is_ * mp.cos(h - 2 * pi / 3) / mp.cos(h + pi); r = second; b = val + 2 * is_ + r - g
+        else:
+            b = val + is_ * mp.cos(h - 4 * pi / 3) / mp.cos(2 * pi - pi / 3 - h); g = second; r = val + 2 * is_ + g - b
+        acc = [acc[0] + r, acc[1] + g, acc[2] + b]
+    return [min(mp.mpf(1), c) for c in acc], hits, margin

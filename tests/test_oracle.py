@@ -178,6 +178,28 @@ def test_clustered_sky_goldens(oracle, oracle_index_clustered):
     np.testing.assert_allclose(rec["rgba"], gt["rgba"], rtol=1e-13, atol=1e-15)
 
 
+def test_mpmath_pins_many_star_lookups(oracle, oracle_index_clustered):
+    """Lookups that sum 5 .. 40+ stars, evaluated in 50-digit arithmetic from the same binary64 inputs: the hit SETS agree (no star
+    within 1e-9 of the radius in these queries) and the FP64 sums -- whatever their order -- sit within 1e-13 of the exact ones."""
+    from oracle import mp_oracle
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import parse_catalogue
+    g = load_golden("lookup_clustered")
+    stars6 = parse_catalogue(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "catalogue_clustered.ppm"), "rb").read())
+    pick = [int(k) for k in np.argsort(-g["hits"])[:6]] + [int(np.nonzero(g["hits"] == h)[0][0]) for h in (5, 6, 7, 12)]
+    for k in pick:
+        d = g["dirs"][k]
+        nd = d / np.linalg.norm(d)
+        near = stars6[np.sum((stars6[:, :3] - nd) ** 2, axis=1) < 0.003 ** 2]  # a superset of the stars in reach (radius 0.0015)
+        rgb, hits, margin = mp_oracle.star_lookup(near, float(g["intensity"]), float(g["saturation"]), d)
+        assert margin > 1e-9 and hits == int(g["hits"][k])
+        c, n = oracle.star_lookup(oracle_index_clustered, float(g["intensity"]), float(g["saturation"]), d)
+        assert n == hits
+        for a, b, q in zip(rgb, c, g["rgb"][k]):
+            assert abs(float(a) - b) <= 1e-13 * max(1.0, abs(b)) and abs(float(a) - q) <= 1e-13 * max(1.0, abs(q))
+
+
 def test_oracle_hit_list_is_never_truncated(oracle):
     """Round 2's oracle capped a lookup at 4096 stars silently; the reference has no cap.  6,000 coincident faint stars: all are hits,
     through the index and by brute force, and the colour is the full sum."""
