@@ -31,7 +31,7 @@ import           Data.List                (sort)
 import qualified Data.Massiv.Array        as A
 import           Data.Massiv.Array        (Ix2 (..))
 import           Data.Massiv.Array.IO     (Image)
-import           Data.Serialize.Get       (getFloat64le, runGet)
+import           Data.Serialize           (getFloat64le, runGet)   -- cereal: Data.Serialize re-exports Get and IEEE754, as src/StarMap.hs uses it
 import           Data.Version             (showVersion)
 import qualified Data.Yaml                as Y
 import           Graphics.ColorSpace
