@@ -177,7 +177,7 @@ def pmc_traffic(mode):
     return None, None
 
 
-def pmc_traffic_live(mode, catalogue, timeout_s=120):
+def pmc_traffic_live(mode, catalogue, timeout_s=60):
     """HBM bytes per launch of the trace kernel MEASURED NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- separate
     runs, as MI355X_MICROARCH.md's HBM section prescribes) over scripts/prof_frame.py, which renders the same frame three times
     through the C ABI in a child process.  Counters cannot be read from inside an un-profiled process, hence the children; timing is

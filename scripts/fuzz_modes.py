@@ -44,7 +44,7 @@ def scene(i):
 
 
 out = dict(scenes=0, values=0, outside_tolerance=0, fate_mismatch_scenes=0, step_mismatch_scenes=0, disk_hit_mismatch_scenes=0,
-           star_hit_mismatch_scenes=0, star_hits=0, escaped=0, worst_abs=0.0, worst_rel=0.0, nonfinite_scenes=0, bad=[], sky=SKY, stars=len(tree))
+           star_hit_mismatch_scenes=0, star_hits=0, escaped=0, fast_scenes_traced_in_strict=0, worst_abs=0.0, worst_rel=0.0, nonfinite_scenes=0, bad=[], sky=SKY, stars=len(tree))
 for i in range(N):
     cfg = scene(i)
     tree.set_mode(_lib.BS_MODE_STRICT); a = bs.render(cfg, tree); sa = tree.stats()
@@ -64,6 +64,7 @@ for i in range(N):
     out["disk_hit_mismatch_scenes"] += int(sa["disk_hits"] != sb["disk_hits"])
     out["star_hit_mismatch_scenes"] += int(sa["star_hits"] != sb["star_hits"])  # a star on the very edge of the radius may flip: reported, not a failure
     out["star_hits"] += int(sa["star_hits"]); out["escaped"] += int(sa["escaped"])
+    out["fast_scenes_traced_in_strict"] += int(sb["effective_mode"] == _lib.BS_MODE_STRICT)  # stepSize > 0.5: FAST mode falls back (bs_effective_mode)
     if (bad or f) and len(out["bad"]) < 5:
         out["bad"].append(dict(index=i, cfg=cfg, outside=bad, strict=(sa["horizon"], sa["escaped"], sa["capped"], sa["steps"]),
                                fast=(sb["horizon"], sb["escaped"], sb["capped"], sb["steps"])))
