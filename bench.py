@@ -546,9 +546,12 @@ def run_ranks(args):
         return s
 
     def fence():
+        # every rank's GPU work has finished BEFORE any rank passes the barrier (a rank that is still executing must not overlap a
+        # neighbour's timed region when ranks share a device in the smoke modes), and RCCL's own barrier kernel has finished after it
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def all_ranks(x):  # every rank's value of a float, in rank order
         if world == 1:
