@@ -644,8 +644,6 @@ def run_ranks(args):
             extra["launches_in_flight_note"] = ("consecutive frames alternate between two streams and share the GPU, so kernel_ms "
                                                 "(per-launch event time) exceeds ms_per_step")
         launcher = "torchrun-env (one process per GPU)" if world > 1 or "WORLD_SIZE" in os.environ else "single-process"
-        if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and frames_cfg is None:
-            args.traffic_live = pmc_traffic_live(args.mode, args.catalogue)
         if resident:
             value = frames * W * H / dt / 1e6
         else:  # the named d2h form is the result
@@ -669,6 +667,12 @@ def run_ranks(args):
             res["boundary"], res["strict"] = boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream)
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(cfg, star_bytes, args.cpu_seconds)
+        if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and frames_cfg is None:
+            # LAST: the profiler's child processes run after every timed leg of this process (a PMC session may leave the device in
+            # another clock state for a while), and only the counter values are taken from them
+            args.traffic_live = pmc_traffic_live(args.mode, args.catalogue)
+            fresh = roofline_block(args, st, kernel_ms, W, H)
+            res["roofline"].update({k: fresh[k] for k in ("traffic", "traffic_kind", "traffic_source")})
         print(json.dumps(res), flush=True)
     tree.close()
     if world > 1:
