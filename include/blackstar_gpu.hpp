@@ -92,10 +92,16 @@ inline std::vector<Star> readMapFromFile(const std::string &path)
 // The StarTree argument of render: the star set resident on one GPU (built once, reused for every scene).
 class StarTree {
 public:
-    explicit StarTree(const std::vector<Star> &stars, int device = 0) : ctx_(bs_create(device, stars.data(), stars.size()))
+    explicit StarTree(const std::vector<Star> &stars, int device = 0) : ctx_(nullptr)
     {
+        if (bs_abi_version() != BS_ABI_VERSION)  // a stale libblackstar_gpu.so under the same name: struct layouts may differ
+            throw std::runtime_error("libblackstar_gpu has ABI version " + std::to_string(bs_abi_version()) + ", this header is version " +
+                                     std::to_string(BS_ABI_VERSION));
+        ctx_ = bs_create(device, stars.data(), stars.size());
         if (!ctx_) throw std::runtime_error(std::string("bs_create: ") + bs_last_error());
     }
+    // The arithmetic a render of cfg would be traced with (FAST contexts trace stepSize > 0.5 in STRICT): bs_effective_mode
+    int effectiveMode(const bs_config &c) const { return bs_effective_mode(ctx_, &c); }
     StarTree(const StarTree &) = delete;
     StarTree &operator=(const StarTree &) = delete;
     ~StarTree() { bs_destroy(ctx_); }
