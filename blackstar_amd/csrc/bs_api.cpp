@@ -99,6 +99,23 @@ struct bs_ctx {
     bool pending = false;  // a render has been enqueued whose stats were not read back yet
     double last_wall_ms = 0;
     int last_zero_copy = 0;  // the last blocking render wrote the caller's page-locked buffer itself (no device image, no copy)
+    // bs_render_rgb8_batch with a PARTITIONED chip: the trace kernels run on streams whose CU mask leaves M CUs out (M / 8 in every
+    // XCD), and bloom + sRGB8 run on a stream that owns exactly those -- see render_rgb8_frames_partitioned / choose_post_cus
+    int post_cus_req = -1;       // env BLACKSTAR_POST_CUS: -1 = choose per batch (default), 0 = never partition, 8..32 = always that many
+    int post_plan_cus = 0;       // CUs the blur sweeps are PLANNED for on the post stream (env BLACKSTAR_POST_PLAN_CUS; 0 = the partition's)
+    int launch_cus = 0;          // CUs the next trace launches may use (0 = n_cu): sizes the persistent grid
+    int bloom_plan_cus = 0;      // probe only (env BLACKSTAR_BLOOM_PLAN_CUS): CU count bs_bloom_device plans its sweeps for (0 = n_cu)
+    struct Partition {
+        hipStream_t trace[2] = {nullptr, nullptr};  // CU mask: every CU but the post stage's
+        hipStream_t post = nullptr;                 // CU mask: the post stage's CUs
+    };
+    static constexpr int kPartitions = 4;           // post stage on 8, 16, 24 or 32 CUs
+    Partition parts[kPartitions];
+    hipEvent_t ev_traced[3] = {nullptr, nullptr, nullptr}, ev_posted[3] = {nullptr, nullptr, nullptr};
+    double *d_img3 = nullptr;
+    size_t img3_cap = 0;
+    unsigned char *d_u8c = nullptr;
+    size_t u8c_cap = 0;
     struct VerifiedRange { const void *host = nullptr; size_t bytes = 0; };
     VerifiedRange verified[8];  // host buffers device_alias_of_pinned has walked page by page (registered memory without a queryable range)
     int verified_next = 0;
@@ -122,8 +139,9 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, bs::TraceParams &p, int row0 
     p.disk_slots = ctx->disk_slots;
     {
         const long tiles = (long)((p.wt + 7) / 8) * ((p.band_t1 - p.band_t0 + 7) / 8);
-        const long waves = (long)ctx->n_cu * 4 * ctx->blocks_per_cu;  // resident wavefronts: blocks_per_cu workgroups of 4 per CU
-        p.blocks_per_slot = ctx->n_cu;
+        const int cus = ctx->launch_cus > 0 ? ctx->launch_cus : ctx->n_cu;  // (a CU-masked stream offers fewer)
+        const long waves = (long)cus * 4 * ctx->blocks_per_cu;  // resident wavefronts: blocks_per_cu workgroups of 4 per CU
+        p.blocks_per_slot = cus;
         p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
         p.stagger_cycles = tiles >= (long)ctx->stagger_min_tiles * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs several tiles
     }
@@ -159,6 +177,9 @@ struct StreamDrain {
         if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
         for (hipStream_t s : {ctx->stream, ctx->stream2, ctx->copy_stream})
             if (s) (void)hipStreamSynchronize(s);
+        for (const bs_ctx::Partition &pt : ctx->parts)
+            for (hipStream_t s : {pt.trace[0], pt.trace[1], pt.post})
+                if (s) (void)hipStreamSynchronize(s);
     }
 };
 
@@ -362,6 +383,9 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));
+    if (const char *m = std::getenv("BLACKSTAR_POST_CUS")) ctx->post_cus_req = std::strcmp(m, "auto") ? std::max(0, std::min(32, std::atoi(m))) / 8 * 8 : -1;
+    if (const char *m = std::getenv("BLACKSTAR_POST_PLAN_CUS")) ctx->post_plan_cus = std::max(0, std::atoi(m));
+    if (const char *m = std::getenv("BLACKSTAR_BLOOM_PLAN_CUS")) ctx->bloom_plan_cus = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_MODE")) {
         if (!std::strcmp(m, "fast")) ctx->mode = BS_MODE_FAST;
         else if (!std::strcmp(m, "strict")) ctx->mode = BS_MODE_STRICT;
@@ -453,6 +477,15 @@ void bs_destroy(bs_ctx *ctx)
             if (b) (void)hipFree(b);
         if (ctx->d_u8) (void)hipFree(ctx->d_u8);
         if (ctx->d_u8b) (void)hipFree(ctx->d_u8b);
+        if (ctx->d_u8c) (void)hipFree(ctx->d_u8c);
+        if (ctx->d_img3) (void)hipFree(ctx->d_img3);
+        for (bs_ctx::Partition &pt : ctx->parts)
+            for (hipStream_t st : {pt.trace[0], pt.trace[1], pt.post})
+                if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : ctx->ev_traced)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->ev_posted)
+            if (e) (void)hipEventDestroy(e);
         if (ctx->ev_post) (void)hipEventDestroy(ctx->ev_post);
         if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -537,7 +570,8 @@ int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int h
     if (rc) return rc;
     rc = acquire_post(ctx, static_cast<hipStream_t>(hip_stream));
     if (rc) return rc;
-    if (bs::launch_bloom((const double *)d_in, (double *)d_out, ctx->d_post[0], ctx->d_post[1], width, height, strength, divider, ctx->n_cu, hip_stream))
+    if (bs::launch_bloom((const double *)d_in, (double *)d_out, ctx->d_post[0], ctx->d_post[1], width, height, strength, divider,
+                         ctx->bloom_plan_cus > 0 ? ctx->bloom_plan_cus : ctx->n_cu, hip_stream))
         return fail(BS_EDEVICE, "bloom launch failed");
     return release_post(ctx, static_cast<hipStream_t>(hip_stream));
 }
@@ -941,6 +975,145 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
     return BS_OK;
 }
 
+// How many CUs the post stage of a batch should own (0: none -- the shared-chip pipeline above).  With the chip partitioned a frame
+// costs about trace x n_cu / (n_cu - M) (+3 %), provided the post stage confined to M CUs keeps up; on the shared chip it costs trace +
+// post + ~0.33 ms of hand-over stalls (a blur workgroup only ever gets a CU in the drain of a later trace kernel).  Measured
+// (scripts/post_partition_ab.py, profiles/r03_post_partition_ab.txt): C3 1080p 4.38 against 4.67 ms with M = 8; 720p 2.00 against 2.25
+// with M = 16 (M = 8: the post stage becomes the bottleneck, 2.26); bloomDivider 10 (r = 192) 4.47 against 4.72 with M = 16 (M = 8: 7.1);
+// but 3840x2160 20.7-21.1 against 20.2 on the shared chip (the stall is a constant, the partition's price is proportional), and frames
+// without supersampling are too cheap to trace per pixel for any M.  Both sides are ESTIMATED per frame -- trace: rays x straight-path
+// steps / the measured FAST rate of 4.5e11 ray-steps per second and chip (STRICT: / 2.4); post: bs::estimate_post_us -- and the smallest
+// M of {8, 16} is taken for which, on EVERY frame of the share, (a) the post stage on M CUs needs at most 92 % of the trace time on the
+// rest and (b) the partitioned frame time undercuts the shared one by 2 %.  BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
+static int post_cus_for_frame(const bs_config &cfg, double strength, int divider, int n_cu, bool fast, int m)
+{
+    bs::TraceParams p;
+    std::memset(&p, 0, sizeof p);
+    std::string err;
+    if (strength == 0 || !bs::derive_params(cfg, p, err)) return 0;
+    const double post_m = bs::estimate_post_us(cfg.width, cfg.height, divider, m);
+    const double post_all = bs::estimate_post_us(cfg.width, cfg.height, divider, n_cu);
+    const double steps = (p.rcam + std::sqrt(p.safe)) / p.h;  // the longest straight path through the scene, in steps
+    const double rate = 4.5e11 * n_cu / 256.0 / (fast ? 1.0 : 2.4);
+    const double trace_all = (double)p.wt * p.ht * steps / rate * 1e6;
+    const double trace_m = trace_all * n_cu / (n_cu - m);
+    if (trace_all < 1500.0) return 0;  // small frames (below ~720p supersampled): launch overheads dominate both stages; not measured, not partitioned
+    return post_m > 0 && post_all > 0 && post_m <= 0.92 * trace_m && 1.03 * trace_m < 0.98 * (trace_all + post_all + 330.0) ? m : 0;
+}
+
+static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, int first, int n_frames, int step)
+{
+    if (ctx->post_cus_req == 0 || ctx->n_cu < 128 || ctx->n_cu % 8 != 0) return 0;
+    if (ctx->post_cus_req > 0) return ctx->post_cus_req;
+    for (int m : {8, 16}) {
+        bool ok = dividers != nullptr;
+        for (int i = first; ok && i < n_frames; i += step)
+            ok = post_cus_for_frame(cfgs[i], strengths ? strengths[i] : 0.0, dividers[i], ctx->n_cu, effective_mode(ctx, &cfgs[i]) == BS_MODE_FAST, m) == m;
+        if (ok) return m;
+    }
+    return 0;
+}
+
+// The same with the chip PARTITIONED between the two stages (ctx->post_cus > 0).  A blur workgroup needs a whole CU (152 KiB of LDS,
+// 8 wavefronts of 202 VGPRs) and the trace kernels' persistent workgroups hold every CU until their tile queue runs dry, so on shared
+// streams the post stage of frame k only ever runs in the drain of a later trace kernel, and delays the one behind it (4.67 against
+// 4.13 ms per frame without the post stage).  Here the trace kernels run on streams whose CU mask leaves post_cus CUs out and the post
+// stage on a stream that owns exactly those: frame k's bloom + sRGB8 run WHILE frames k+1, k+2 are traced, at the price of post_cus /
+// n_cu of the trace rate.  Mask bit i is CU i / 8 of XCD i % 8 (scripts/cumask_probe.py, profiles/r03_cumask_probe.txt: an XCD
+// without a single bit gets ALL its CUs), so bits [0, post_cus) are post_cus / 8 CUs in every XCD.  Three images in flight.
+static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_config *cfgs, const double *strengths, const int *dividers,
+                                          unsigned char *const *outs, int first, int n_frames, int step)
+{
+    if (first >= n_frames) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t need = 0;
+    for (int i = first; i < n_frames; i += step) {
+        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
+        const double st = strengths ? strengths[i] : 0.0;
+        if (st != 0 && (!dividers || dividers[i] <= 0 || cfgs[i].width / dividers[i] == 0))
+            return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+        need = std::max(need, (size_t)cfgs[i].width * cfgs[i].height * 3);
+    }
+    auto grow = [&](auto *&buf, size_t &cap, size_t elems) {
+        if (cap >= elems) return true;
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipMalloc((void **)&buf, elems * sizeof(*buf)) != hipSuccess) return false;
+        cap = elems;
+        return true;
+    };
+    if (!grow(ctx->d_img, ctx->img_cap, need) || !grow(ctx->d_img2, ctx->img2_cap, need) || !grow(ctx->d_img3, ctx->img3_cap, need) ||
+        !grow(ctx->d_u8, ctx->u8_cap, need) || !grow(ctx->d_u8b, ctx->u8b_cap, need) || !grow(ctx->d_u8c, ctx->u8c_cap, need))
+        return fail(BS_ENOMEM, "hipMalloc image failed");
+    int rc = ensure_post(ctx, need);
+    if (rc) return rc;
+    bs_ctx::Partition &pt = ctx->parts[post_cus / 8 - 1];
+    if (!pt.post) {
+        const int words = (ctx->n_cu + 31) / 32;
+        std::vector<uint32_t> post(words, 0u), trace(words, 0u);
+        for (int b = 0; b < ctx->n_cu; b++) (b < post_cus ? post : trace)[b / 32] |= 1u << (b % 32);
+        HIP_TRY(hipExtStreamCreateWithCUMask(&pt.post, (uint32_t)words, post.data()));
+        for (hipStream_t &t : pt.trace) HIP_TRY(hipExtStreamCreateWithCUMask(&t, (uint32_t)words, trace.data()));
+    }
+    for (hipEvent_t &e : ctx->ev_traced)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t &e : ctx->ev_posted)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double *img[3] = {ctx->d_img, ctx->d_img2, ctx->d_img3};
+    unsigned char *stage[3] = {ctx->d_u8, ctx->d_u8b, ctx->d_u8c};
+    const int plan_cus = ctx->post_plan_cus > 0 ? ctx->post_plan_cus : post_cus;
+    struct LaunchCus {  // the trace launches of this call size their persistent grids for the CUs their streams may use
+        bs_ctx *c;
+        LaunchCus(bs_ctx *c_, int n) : c(c_) { c->launch_cus = n; }
+        ~LaunchCus() { c->launch_cus = 0; }
+    } cus(ctx, ctx->n_cu - post_cus);
+    StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
+    int k = 0;
+    for (int i = first; i < n_frames; i += step, k++) {
+        const int b = k % 3;
+        hipStream_t ts = pt.trace[k & 1];
+        if (k >= 3) HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));  // frame k-3 (same image, same staging) has left the device
+        const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
+        unsigned char *target = stage[b];
+        bool straddles = false;
+        if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);
+        if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        rc = enqueue_render(ctx, &cfgs[i], img[b], n, ts, 0, -1, true, true, /*quiet=*/true);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev_traced[b], ts));
+        HIP_TRY(hipStreamWaitEvent(pt.post, ctx->ev_traced[b], 0));
+        const double st = strengths ? strengths[i] : 0.0;
+        if (st != 0) {
+            rc = acquire_post(ctx, pt.post);
+            if (rc) return rc;
+            if (bs::launch_bloom_srgb8(img[b], target, ctx->d_post[0], ctx->d_post[1], cfgs[i].width, cfgs[i].height, st, dividers[i], plan_cus,
+                                       ctx->d_srgb_table, pt.post))
+                return fail(BS_EDEVICE, "bloom launch failed");
+            rc = release_post(ctx, pt.post);
+            if (rc) return rc;
+        } else if (bs::launch_srgb8(img[b], target, n, ctx->d_srgb_table, pt.post)) {
+            return fail(BS_EDEVICE, "srgb8 launch failed");
+        }
+        if (target == stage[b]) HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, pt.post));
+        HIP_TRY(hipEventRecord(ctx->ev_posted[b], pt.post));
+    }
+    HIP_TRY(hipStreamSynchronize(pt.trace[0]));
+    HIP_TRY(hipStreamSynchronize(pt.trace[1]));
+    HIP_TRY(hipStreamSynchronize(pt.post));
+    return BS_OK;
+}
+
+int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_divider, int n_cu, int mode)
+{
+    if (!cfg || n_cu < 1) return fail(BS_EINVAL, "bad argument");
+    if (n_cu < 128 || n_cu % 8 != 0) return 0;
+    const bool fast = mode == BS_MODE_FAST && cfg->step_size <= 0.5;
+    for (int m : {8, 16})
+        if (post_cus_for_frame(*cfg, bloom_strength, bloom_divider, n_cu, fast, m) == m) return m;
+    return 0;
+}
+
 int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
                          unsigned char *const *outs)
 {
@@ -951,7 +1124,10 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
     std::vector<std::thread> th;
     for (int c = 0; c < n_ctx; c++) {
         th.emplace_back([&, c]() {
-            rcs[c] = render_rgb8_frames_pipelined(ctxs[c], cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx);
+            bs_ctx *x = ctxs[c];
+            const int post_cus = choose_post_cus(x, cfgs, bloom_strengths, bloom_dividers, c, n_frames, n_ctx);
+            rcs[c] = post_cus ? render_rgb8_frames_partitioned(x, post_cus, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx)
+                              : render_rgb8_frames_pipelined(x, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx);
             if (rcs[c]) errs[c] = g_err;
         });
     }

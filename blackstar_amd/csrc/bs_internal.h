@@ -109,6 +109,8 @@ int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, in
 // bloom + writeImg's pixel map in one go: only RGB8 is written (d_table: the 257 sRGB8 thresholds, srgb8_thresholds)
 int launch_bloom_srgb8(const double *d_in, unsigned char *d_out_u8, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu,
                        const double *d_table, void *stream);
+// microseconds bloom + sRGB8 of a w x h frame would take on `cus` CUs of the chip (model; < 0: no estimate) -- see post_kernels.hip
+double estimate_post_us(int w, int h, int divider, int cus);
 int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *stream);
 int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, const double *d_table, void *stream);
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);

@@ -1463,3 +1463,68 @@ def test_gpu_against_the_reference_itself(which, mode):
         print(f"{which}/{mode}: {rep['values']} values vs GHC, {rep['bit_equal'] / rep['values']:.2%} bit-equal, worst rel {rep['worst_rel']:.2e}")
     finally:
         t.close()
+
+
+# ---- bs_render_rgb8_batch with the chip partitioned between the trace kernels and the post stage (round 3) ---------------------
+
+@pytest.mark.parametrize("post", ["auto", "8", "16", "0"])
+def test_rgb8_batch_on_a_partitioned_chip_is_byte_identical(post, catalogue_bytes, monkeypatch):
+    """BLACKSTAR_POST_CUS: bloom + sRGB8 of frame k on a stream that owns 8 / 16 CUs while frames k+1, k+2 are traced on the rest
+    (auto: chosen per batch; these frames are small, so auto means the shared chip).  Whatever the pipeline: the bytes of
+    bs_render_rgb8 frame by frame -- frames of different cameras, a frame without bloom, page-locked and pageable outputs mixed,
+    more frames than images in flight -- and a failing frame in the middle leaves nothing in flight and the context usable."""
+    monkeypatch.setenv("BLACKSTAR_POST_CUS", post)
+    t = bs.StarTree(bs.read_map(catalogue_bytes), device=0)
+    try:
+        anim = bs.Animation.from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "animations", "default-ani.yaml"))
+        frames = bs.generate_frames(anim)
+        cfgs = [frames[i].with_resolution(320, 180) for i in (0, 40, 90, 150, 200, 260, 310, 374)]
+        cfgs[3].scene.bloomStrength = 0.0        # writeImg without bloom in the middle of the batch
+        cfgs[5] = cfgs[5].with_resolution(200, 112)
+        cfgs[6].scene.bloomDivider = 9           # r = 35
+        refs = [bs.render_rgb8(c, t).copy() for c in cfgs]
+        assert len({r.tobytes() for r in refs}) == len(refs)
+        outs = [bs.alloc_image(t, c.scene.resolution[1], c.scene.resolution[0], dtype=np.uint8) if i % 3 else
+                np.zeros((c.scene.resolution[1], c.scene.resolution[0], 3), np.uint8) for i, c in enumerate(cfgs)]
+        for rep in range(2):
+            for o in outs:
+                o[:] = 7
+            got = bs.render_rgb8_batch(cfgs, [t], outs=outs)
+            for k, (g, r) in enumerate(zip(got, refs)):
+                assert np.array_equal(g, r), (post, rep, k)
+        bad = [c for c in cfgs]
+        bad[4] = bad[4].with_resolution(320, 180)
+        bad[4].scene.diskColor = (1.5, 0.1, 1.0)  # hue 540 deg: the reference raises an error
+        with pytest.raises(bs._lib.BlackstarError, match="not properly scaled"):
+            bs.render_rgb8_batch(bad, [t], outs=outs)
+        assert np.array_equal(bs.render_rgb8(cfgs[0], t), refs[0])
+        for g, r in zip(bs.render_rgb8_batch(cfgs, [t]), refs):
+            assert np.array_equal(g, r)
+    finally:
+        t.close()
+
+
+def test_rgb8_batch_partition_at_full_size():
+    """The C3 frame itself, where the partition is chosen automatically (8 CUs for the post stage): bytes of bs_render_rgb8, and
+    not slower than the shared chip."""
+    import time
+    cfg = bs.Config.from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "default-aa.yaml"))
+    assert _lib.lib().bs_debug_post_cus(C.byref(_lib.make_config(cfg.to_bs_config())), cfg.scene.bloomStrength, cfg.scene.bloomDivider, 256, _lib.BS_MODE_FAST) == 8
+    times = {}
+    for post in ("0", "auto"):
+        os.environ["BLACKSTAR_POST_CUS"] = post
+        try:
+            t = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes()), device=0)
+        finally:
+            del os.environ["BLACKSTAR_POST_CUS"]
+        ring = [bs.alloc_image(t, 1080, 1920, dtype=np.uint8) for _ in range(4)]
+        outs = [ring[i % 4] for i in range(16)]
+        ref = bs.render_rgb8(cfg, t).copy()
+        bs.render_rgb8_batch([cfg] * 16, [t], outs=outs)
+        assert all(np.array_equal(o, ref) for o in ring)
+        t0 = time.perf_counter()
+        bs.render_rgb8_batch([cfg] * 16, [t], outs=outs)
+        times[post] = (time.perf_counter() - t0) / 16 * 1e3
+        t.close()
+    print(f"bs_render_rgb8_batch, C3: shared chip {times['0']:.3f} ms per frame, partitioned {times['auto']:.3f}")
+    assert times["auto"] < times["0"] * 1.01

@@ -217,6 +217,28 @@ def test_every_shipped_scene_and_animation_frame_validates():
         assert L.bs_validate_config(C.byref(_lib.make_config(c.to_bs_config()))) == 0
 
 
+def test_post_stage_partition_heuristic():
+    """bs_render_rgb8_batch sets CUs aside for bloom + sRGB8 only where both estimates say it pays (host-only hook).  The expectations
+    are the measured winners of scripts/post_partition_ab.py (profiles/r03_post_partition_ab.txt)."""
+    import ctypes as C
+    L = _lib.lib()
+
+    def m(cfg, st=0.15, div=25, n_cu=256, mode=_lib.BS_MODE_FAST):
+        return L.bs_debug_post_cus(C.byref(_lib.make_config(cfg)), st, div, n_cu, mode)
+    assert m(scenes.DEFAULT_AA) == 8                                  # C3: 4.38 against 4.67 ms
+    assert m(scenes.ani_frame(300, 600), st=0.7) == 8                 # C5 frames
+    assert m(scenes.LENSING_DISK) == 8                                # 1280x800 supersampled: 2.55 against 2.74 ms
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 1280, 720)) == 16     # 720p: on 8 CUs the post stage would be the bottleneck (2.26 vs 2.00)
+    assert m(scenes.DEFAULT_AA, div=10) == 16                         # r = 192: 4.47 against 4.72 (7.1 on 8 CUs)
+    assert m(scenes.DEFAULT) == 0 and m(scenes.CLOSEUP, st=0.7) == 0  # no supersampling: too cheap to trace per pixel
+    assert m(scenes.with_res(scenes.LENSING_DISK, 3840, 2160)) == 0   # 4K: the shared chip's stall is a constant, the partition's price is not
+    assert m(scenes.DEFAULT_AA, st=0.0) == 0                          # no bloom, no post stage worth a partition
+    assert m(scenes.DEFAULT_AA, mode=_lib.BS_MODE_STRICT) == 0       # STRICT: 3 % of a 10 ms frame is more than the stall
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 96, 54)) == 0 and m(scenes.with_res(scenes.DEFAULT_AA, 640, 360)) == 0  # small frames
+    assert m(scenes.DEFAULT_AA, n_cu=64) == 0 and m(scenes.DEFAULT_AA, n_cu=100) == 0      # a partitioned device / odd CU counts
+    assert L.bs_debug_post_cus(None, 0.1, 25, 256, 1) == -1
+
+
 def test_stale_library_is_refused_by_its_abi_version(tmp_path):
     """A libblackstar_gpu.so of another ABI version under the same name fails at load with a message that says so (not at a later
     symbol lookup or, worse, a struct read)."""
