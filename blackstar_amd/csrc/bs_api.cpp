@@ -983,8 +983,9 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 // but 3840x2160 20.7-21.1 against 20.2 on the shared chip (the stall is a constant, the partition's price is proportional), and frames
 // without supersampling are too cheap to trace per pixel for any M.  Both sides are ESTIMATED per frame -- trace: rays x straight-path
 // steps / the measured FAST rate of 4.5e11 ray-steps per second and chip (STRICT: / 2.4); post: bs::estimate_post_us -- and the smallest
-// M of {8, 16} is taken for which, on EVERY frame of the share, (a) the post stage on M CUs needs at most 92 % of the trace time on the
-// rest and (b) the partitioned frame time undercuts the shared one by 2 %.  BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
+// M of {8, 16} is taken for which, on EVERY frame of the share, (a) the post stage ALONE on M CUs needs at most 86 % of the trace time on the
+// rest (next to the trace kernels it runs ~20 % slower than alone: 720p on 8 CUs 1.80 ms alone, 2.25 in the pipeline) and (b) the
+// partitioned frame time undercuts the shared one by 2 %.  BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
 static int post_cus_for_frame(const bs_config &cfg, double strength, int divider, int n_cu, bool fast, int m)
 {
     bs::TraceParams p;
@@ -998,7 +999,7 @@ static int post_cus_for_frame(const bs_config &cfg, double strength, int divider
     const double trace_all = (double)p.wt * p.ht * steps / rate * 1e6;
     const double trace_m = trace_all * n_cu / (n_cu - m);
     if (trace_all < 1500.0) return 0;  // small frames (below ~720p supersampled): launch overheads dominate both stages; not measured, not partitioned
-    return post_m > 0 && post_all > 0 && post_m <= 0.92 * trace_m && 1.03 * trace_m < 0.98 * (trace_all + post_all + 330.0) ? m : 0;
+    return post_m > 0 && post_all > 0 && post_m <= 0.86 * trace_m && 1.03 * trace_m < 0.98 * (trace_all + post_all + 330.0) ? m : 0;
 }
 
 static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, int first, int n_frames, int step)

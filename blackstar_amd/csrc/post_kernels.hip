@@ -767,8 +767,11 @@ static bool plan_dma_sweep(const void *in, int P, int n, int r, int n_cu, SweepP
     for (int d : {3, 2, 1}) {  // the px that covers the chip with one round of workgroups, as deep a prefetch as the LDS allows
         if ((long)px0 * (stride_of(d) + tile_bytes) <= lds_budget) { px = px0; dp = d; break; }
     }
-    if (!px && !single_round) {  // fewer pixels per workgroup: more workgroups than CUs
-        for (int d : {2, 1}) {
+    if (!px && !single_round) {  // fewer pixels per workgroup: more workgroups than CUs, i.e. several ROUNDS of workgroups per CU -- then what
+        // counts is the CU-time of a sweep, not a workgroup's latency: the most chain-pixels the LDS takes (prefetch depth 1) first.  Measured
+        // (profiles/r03_post_partition_ab.txt, "fat"): r = 192 on 8 CUs 5.0 against 5.9 ms, 1080p on 16 CUs 1.91 against 2.01, 4K on all 256 CUs
+        // 0.80-0.87 either way.
+        for (int d : {1, 2}) {
             const int fit = (int)(lds_budget / (stride_of(d) + tile_bytes));
             if (fit >= 1) { px = std::min(px0, fit); dp = d; break; }
         }
@@ -834,10 +837,10 @@ static void blur_passes(const double *src, double *d_a, double *d_b, int w, int 
 
 // Estimated duration (microseconds) of bloom + sRGB8 of a w x h frame on a stream that owns `cus` CUs, the sweeps planned for that many
 // (bs_render_rgb8_batch's partitioned pipeline decides with it how many CUs the post stage gets).  Model fitted to
-// scripts/post_cost_probe.py (profiles/r03_post_cost_probe.txt): a sweep is ceil(groups / cus) rounds of workgroups, a workgroup takes
-// 4 us + 19 ns per row (chains of `n` rows; 10 chain-pixels per workgroup pace it by the STORE wavefronts), the combine streams
-// 2.1 x the image at ~50 GB/s per CU.  Within ~10 % of the measured 3.8 / 17.7 / 5.9 / 1.8 ms (1080p, 4K, r = 192, 720p on 8 CUs;
-// the model gives 4.1 / 19.4 / 6.0 / 1.9).
+// scripts/post_cost_probe.py (profiles/r03_post_partition_ab.txt): a sweep is ceil(groups / cus) rounds of workgroups, a workgroup takes
+// 4 us + (12.5 + 0.9 px) ns per row (chains of `n` rows; the more chain-pixels px a workgroup carries, the longer its STORE wavefronts
+// need per block: 17 ns per row at px = 5, 23 at px = 12), the combine streams 2.1 x the image at ~50 GB/s per CU.  Within ~10 % of the
+// measured 3.77 / 17.4 / 5.0 / 1.80 ms (1080p, 4K, r = 192, 720p on 8 CUs).
 // Returns a negative value when the frame does not take the LDS-DMA sweep path (odd sizes, very wide windows): no estimate.
 double estimate_post_us(int w, int h, int divider, int cus)
 {
@@ -847,7 +850,7 @@ double estimate_post_us(int w, int h, int divider, int cus)
     alignas(16) static const double aligned_dummy[2] = {0, 0};
     if (!plan_dma_sweep(aligned_dummy, h, w, r, cus, ph, false, kDmaLds - 1024) || !plan_dma_sweep(aligned_dummy, w, h, r, cus, pv, false, kDmaLds - 1024))
         return -1.0;
-    auto sweep = [&](const SweepPlan &pl, int rows) { return (double)((pl.groups + cus - 1) / cus) * (4.0 + 0.019 * rows); };
+    auto sweep = [&](const SweepPlan &pl, int rows) { return (double)((pl.groups + cus - 1) / cus) * (4.0 + (0.0125 + 0.0009 * pl.px) * rows); };
     const double combine = 2.1 * (double)w * h * 24.0 / (cus * 50e9) * 1e6;
     return 3.0 * (sweep(ph, w) + sweep(pv, h)) + combine;
 }
