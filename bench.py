@@ -526,6 +526,8 @@ def run_ranks(args):
     W, H = cfg["width"], cfg["height"]
     star_bytes = synthetic.catalogue_bytes(args.catalogue)
     stars = bs.read_map(star_bytes)
+    if world > ndev:  # smoke mode: ranks share a device, and every context would set the SAME few CUs aside for its post stage
+        os.environ.setdefault("BLACKSTAR_POST_CUS", "0")
     tree = bs.StarTree(stars, device=local_rank)
     tree.set_mode(_lib.BS_MODE_FAST if args.mode == "fast" else _lib.BS_MODE_STRICT)
 
@@ -700,6 +702,8 @@ def run_single_process(args):
     stars = bs.read_map(star_bytes)
     n_streams = args.streams or (2 if frames_cfg is not None else 1)
     trees, outs, streams, lanes = [], [], [], []
+    if world > ndev:  # smoke mode: contexts share a device, and every one of them would set the SAME few CUs aside for its post stage
+        os.environ.setdefault("BLACKSTAR_POST_CUS", "0")
     for d in devs:
         t = bs.StarTree(stars, device=d)
         t.set_mode(_lib.BS_MODE_FAST if args.mode == "fast" else _lib.BS_MODE_STRICT)
