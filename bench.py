@@ -27,6 +27,7 @@ line carries, measured after the timed region (--form all, the default):
 --catalogue clustered | PATH swaps the uniform synthetic sky for the non-uniform one or a real PPM catalogue file (reported as such).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -584,6 +585,8 @@ def run_ranks(args):
             gather_to_root()  # also establishes RCCL's point-to-point channels outside the timed region
         fence()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        gc.collect()   # no collector pause inside the 90 ms of the timed region (the catalogue's temporaries are garbage by now)
+        gc.disable()
         t0 = time.perf_counter()
         for a, b in ev:
             s = lanes[counter["k"] % n_streams][1]
@@ -599,8 +602,10 @@ def run_ranks(args):
             t_gather = time.perf_counter() - tg
         fence()
         dt_local = time.perf_counter() - t0
+        gc.enable()
         st = tree.stats()
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # per launch incl. the 64-B counter memset/copy nodes
+        kernel_each = [float(a.elapsed_time(b)) for a, b in ev]  # per launch incl. the 64-B counter memset/copy nodes
+        kernel_ms = float(np.mean(kernel_each))
         allt = all_ranks(dt_local)
         per_rank_ms = [t / args.steps * 1e3 for t in allt]
         dt = max(allt)  # MAX over ranks
@@ -656,6 +661,8 @@ def run_ranks(args):
             per_rank_ms = [kernel_ms] * world
         res = result_line(args, world, launcher, value, dt, W, H, frames_cfg, st, kernel_ms, extra, peak, catalogue_note(args, len(stars)))
         res["per_rank_ms_per_step"] = per_rank_ms
+        if resident and n_streams == 1:
+            res["kernel_ms_each"] = [round(x, 4) for x in kernel_each]  # the timed launches one by one (rank 0): a clock ramp after the idle start-up shows here
         if rccl is not None:
             res["rccl"] = rccl
         if t_gather is not None:
@@ -754,6 +761,8 @@ def run_single_process(args):
         for k in range(world):
             with torch.cuda.device(devs[k]):
                 ev.append([(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)])
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for s in range(args.steps):
             for k in range(world):
@@ -771,6 +780,7 @@ def run_single_process(args):
             t_gather = time.perf_counter() - tg
         fence()
         dt = time.perf_counter() - t0  # one clock for all devices: this IS the max over "ranks"
+        gc.enable()
         kms = [[a.elapsed_time(b) for a, b in ev[k]] for k in range(world)]
         per_rank_ms = [dt / args.steps * 1e3] * world if n_streams > 1 else [ev[k][0][0].elapsed_time(ev[k][-1][1]) / args.steps for k in range(world)]
         kernel_ms = float(np.mean(kms[0]))

@@ -40,7 +40,7 @@ RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4
 SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
            "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
            "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots",
-           "bs_effective_mode", "bs_validate_config", "bs_debug_post_cus", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch")
+           "bs_effective_mode", "bs_validate_config", "bs_debug_post_cus", "bs_debug_last_post_cus", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch")
 
 _lib = None
 
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
     L.bs_effective_mode.argtypes = [vp, C.POINTER(BsConfig)]
     L.bs_validate_config.argtypes = [C.POINTER(BsConfig)]
     L.bs_debug_post_cus.argtypes = [C.POINTER(BsConfig), dp, C.c_int, C.c_int, C.c_int]
+    L.bs_debug_last_post_cus.argtypes = [vp]
     L.bs_set_max_steps.argtypes = [vp, C.c_int]
     L.bs_stats.argtypes = [vp, C.POINTER(BsStats)]
     L.bs_last_error.restype = C.c_char_p

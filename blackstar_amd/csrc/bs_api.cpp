@@ -104,6 +104,7 @@ struct bs_ctx {
     int post_cus_req = -1;       // env BLACKSTAR_POST_CUS: -1 = choose per batch (default), 0 = never partition, 8..32 = always that many
     int post_plan_cus = 0;       // CUs the blur sweeps are PLANNED for on the post stream (env BLACKSTAR_POST_PLAN_CUS; 0 = the partition's)
     int launch_cus = 0;          // CUs the next trace launches may use (0 = n_cu): sizes the persistent grid
+    int last_post_cus = -1;      // CUs the post stage owned in this context's share of the last bs_render_rgb8_batch (0: shared chip; -1: none yet)
     int bloom_plan_cus = 0;      // probe only (env BLACKSTAR_BLOOM_PLAN_CUS): CU count bs_bloom_device plans its sweeps for (0 = n_cu)
     struct Partition {
         hipStream_t trace[2] = {nullptr, nullptr};  // CU mask: every CU but the post stage's
@@ -1128,6 +1129,8 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
     return BS_OK;
 }
 
+int bs_debug_last_post_cus(const bs_ctx *ctx) { return ctx ? ctx->last_post_cus : BS_EINVAL; }
+
 int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_divider, int n_cu, int mode)
 {
     if (!cfg || n_cu < 1) return fail(BS_EINVAL, "bad argument");
@@ -1150,7 +1153,16 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
         th.emplace_back([&, c]() {
             bs_ctx *x = ctxs[c];
             int post_cus = choose_post_cus(x, cfgs, bloom_strengths, bloom_dividers, c, n_frames, n_ctx);
+            // Only with page-locked outputs, which the last kernel of a frame writes itself: a copy into PAGEABLE memory blocks the
+            // host thread until the frame's post stage has finished -- 3.8 ms on 8 CUs instead of 0.2 ms on the whole chip -- and the
+            // next trace kernel is not enqueued meanwhile (measured 9.1 against 4.8 ms per frame: scripts/post_partition_pageable_ab.py)
+            for (int i = c; post_cus && i < n_frames; i += n_ctx) {
+                if (!outs[i] || cfgs[i].width <= 0 || cfgs[i].height <= 0 || hipSetDevice(x->device) != hipSuccess ||
+                    !device_alias_of_pinned(x, outs[i], (size_t)cfgs[i].width * cfgs[i].height * 3))
+                    post_cus = 0;
+            }
             if (post_cus && !ensure_partition(x, post_cus)) post_cus = 0;
+            x->last_post_cus = post_cus;
             rcs[c] = post_cus ? render_rgb8_frames_partitioned(x, post_cus, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx)
                               : render_rgb8_frames_pipelined(x, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx);
             if (rcs[c]) errs[c] = g_err;

@@ -201,14 +201,16 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
  * frame's bloom runs on the first CUs the next trace kernel frees.  Where it pays (supersampled frames with bloom up to about 2 Mpixel:
  * the default-aa frame 4.38 instead of 4.67 ms) the chip is PARTITIONED instead: the trace kernels run on streams whose CU mask leaves 8
  * or 16 CUs out, bloom + sRGB8 of the previous frames run on a stream that owns exactly those, three frames in flight
- * (env BLACKSTAR_POST_CUS=0 turns it off, 8|16|24|32 forces it).  Page-locked outs[i] (bs_host_alloc) are written by the last
- * kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame either way; bs_stats is not updated. */
+ * (only when every outs[i] is page-locked; env BLACKSTAR_POST_CUS=0 turns it off, 8|16|24|32 forces it).  Page-locked outs[i]
+ * (bs_host_alloc) are written by the last kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame either way; bs_stats is not updated. */
 int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                          const int *bloom_dividers, unsigned char *const *outs);
 
 /* Test hook, host-only: how many CUs bs_render_rgb8_batch would set aside for the post stage of a batch made of this frame on a chip
  * of n_cu CUs in the given BS_MODE_* (0 = none: the post stage shares the chip with the trace kernels).  See bs_render_rgb8_batch. */
 int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_divider, int n_cu, int mode);
+/* Test hook: the CUs the post stage owned in this context's share of the last bs_render_rgb8_batch (0 = the shared chip, -1 = no batch yet). */
+int bs_debug_last_post_cus(const bs_ctx *ctx);
 
 /* Test hook: trace the given traced-resolution pixels (y,x pairs) and return per-ray records (host buffers). */
 int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out);

@@ -68,7 +68,7 @@ anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml
 anim.nFrames = 600
 frames = bs.generate_frames(anim)[::25]
 outs8 = [bs.alloc_image(tree, 1080, 1920, dtype=np.uint8) for _ in frames]
-bs.render_rgb8_batch(frames[:2], [tree], outs=outs8[:2])
+bs.render_rgb8_batch(frames[:4], [tree], outs=outs8[:4])  # (the first batch of a context makes its streams and images: ~20 ms once)
 t0 = time.perf_counter()
 for c, o in zip(frames, outs8):
     bs.render_rgb8(c, tree, out=o)

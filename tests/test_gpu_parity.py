@@ -1484,14 +1484,19 @@ def test_rgb8_batch_on_a_partitioned_chip_is_byte_identical(post, catalogue_byte
         cfgs[6].scene.bloomDivider = 9           # r = 35
         refs = [bs.render_rgb8(c, t).copy() for c in cfgs]
         assert len({r.tobytes() for r in refs}) == len(refs)
-        outs = [bs.alloc_image(t, c.scene.resolution[1], c.scene.resolution[0], dtype=np.uint8) if i % 3 else
-                np.zeros((c.scene.resolution[1], c.scene.resolution[0], 3), np.uint8) for i, c in enumerate(cfgs)]
-        for rep in range(2):
-            for o in outs:
-                o[:] = 7
-            got = bs.render_rgb8_batch(cfgs, [t], outs=outs)
-            for k, (g, r) in enumerate(zip(got, refs)):
-                assert np.array_equal(g, r), (post, rep, k)
+        L = _lib.lib()
+        assert L.bs_debug_last_post_cus(t.handle) == -1
+        pinned = [bs.alloc_image(t, c.scene.resolution[1], c.scene.resolution[0], dtype=np.uint8) for c in cfgs]
+        mixed = [p if i % 3 else np.zeros_like(p) for i, p in enumerate(pinned)]  # every third output pageable
+        for outs, want_cus in ((pinned, {"auto": 0, "0": 0, "8": 8, "16": 16}[post]), (mixed, 0)):  # pageable outputs: never partitioned
+            for rep in range(2):
+                for o in outs:
+                    o[:] = 7
+                got = bs.render_rgb8_batch(cfgs, [t], outs=outs)
+                assert L.bs_debug_last_post_cus(t.handle) == want_cus
+                for k, (g, r) in enumerate(zip(got, refs)):
+                    assert np.array_equal(g, r), (post, rep, k)
+        outs = pinned
         bad = [c for c in cfgs]
         bad[4] = bad[4].with_resolution(320, 180)
         bad[4].scene.diskColor = (1.5, 0.1, 1.0)  # hue 540 deg: the reference raises an error
@@ -1522,6 +1527,7 @@ def test_rgb8_batch_partition_at_full_size():
         ref = bs.render_rgb8(cfg, t).copy()
         bs.render_rgb8_batch([cfg] * 16, [t], outs=outs)
         assert all(np.array_equal(o, ref) for o in ring)
+        assert _lib.lib().bs_debug_last_post_cus(t.handle) == (8 if post == "auto" else 0)
         t0 = time.perf_counter()
         bs.render_rgb8_batch([cfg] * 16, [t], outs=outs)
         times[post] = (time.perf_counter() - t0) / 16 * 1e3
