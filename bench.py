@@ -220,7 +220,10 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps before the timed ones.  The chip comes out of idle while the host builds the catalogue and the star grid: "
+                         "the first launches after an idle spell run 5.3, 5.0, 4.8, 4.65, 4.5, 4.4 ms before the clocks settle at 4.3 (kernel_ms_each), "
+                         "so the default gives that ramp ten launches")
     ap.add_argument("--mode", choices=["strict", "fast"], default=os.environ.get("BLACKSTAR_BENCH_MODE", "fast"))
     ap.add_argument("--workload", choices=["default-aa", "animation"], default="default-aa",
                     help="default-aa = BASELINE configs[2] (the headline metric); animation = configs[4]: frames of "
@@ -579,14 +582,17 @@ def run_ranks(args):
     resident = args.form in ("all", "resident")
     dt_local = kernel_ms = None
     if resident:
+        # Everything the host has to do around the timed region is done BEFORE the warm-up steps: the chip drops its clocks within a
+        # millisecond of idling and takes ~8 launches (35 ms) to bring them back (kernel_ms_each: 5.5, 5.1, 4.9, 4.7, 4.6, 4.5 ... 4.3 ms
+        # after a 40 ms collector pause between the warm-up and the timed steps), so nothing but the fence stands between the two.
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        gc.collect()   # no collector pause inside the 90 ms of the timed region (the catalogue's temporaries are garbage by now)
+        gc.disable()
         for _ in range(args.warmup):
             step()
         if world > 1 and args.gather:
             gather_to_root()  # also establishes RCCL's point-to-point channels outside the timed region
         fence()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        gc.collect()   # no collector pause inside the 90 ms of the timed region (the catalogue's temporaries are garbage by now)
-        gc.disable()
         t0 = time.perf_counter()
         for a, b in ev:
             s = lanes[counter["k"] % n_streams][1]
@@ -748,6 +754,13 @@ def run_single_process(args):
                 gathered[k].copy_(outs[k], non_blocking=True)
 
     resident = args.form in ("all", "resident")
+    ev = []
+    if resident:  # (host work first, then warm-up, fence, timed steps: see run_ranks)
+        for k in range(world):
+            with torch.cuda.device(devs[k]):
+                ev.append([(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)])
+        gc.collect()
+        gc.disable()
     for _ in range(args.warmup if resident else max(1, args.warmup)):
         for k in range(world):
             step(k)
@@ -757,12 +770,6 @@ def run_single_process(args):
     fence()
     t_gather = None
     if resident:
-        ev = []
-        for k in range(world):
-            with torch.cuda.device(devs[k]):
-                ev.append([(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)])
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         for s in range(args.steps):
             for k in range(world):

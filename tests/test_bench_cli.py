@@ -26,7 +26,7 @@ def test_help_and_defaults():
         a = bench.parse_args()
     finally:
         sys.argv = old
-    assert (a.gpus, a.steps, a.warmup, a.form, a.catalogue, a.mode, a.workload) == (1, 20, 3, "all", "synthetic", "fast", "default-aa")
+    assert (a.gpus, a.steps, a.warmup, a.form, a.catalogue, a.mode, a.workload) == (1, 20, 10, "all", "synthetic", "fast", "default-aa")
     assert a.sustained_frames == 500 and a.cpu_seconds > 0
 
 
