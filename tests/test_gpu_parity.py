@@ -1533,4 +1533,4 @@ def test_rgb8_batch_partition_at_full_size():
         times[post] = (time.perf_counter() - t0) / 16 * 1e3
         t.close()
     print(f"bs_render_rgb8_batch, C3: shared chip {times['0']:.3f} ms per frame, partitioned {times['auto']:.3f}")
-    assert times["auto"] < times["0"] * 1.01
+    assert times["auto"] < times["0"] * 1.05  # (measured 4.4 against 4.7 ms; the bar only guards against the partition going badly wrong)
