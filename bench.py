@@ -517,7 +517,8 @@ def run_ranks(args):
         # Untimed: one all_gather of (rank, PCI bus of the rank's device) -- the path itself has no collective, so this is what shows
         # that RCCL saw N ranks on N distinct devices (and it establishes the communicator outside the timed region).
         dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
-        me = torch.tensor([rank, pci_bus_of(torch, local_rank) or -1], dtype=torch.int64, device=dev)
+        bus = pci_bus_of(torch, local_rank)
+        me = torch.tensor([rank, -1 if bus is None else bus], dtype=torch.int64, device=dev)
         got = [torch.empty_like(me) for _ in range(world)]
         dist.all_gather(got, me)
         torch.cuda.synchronize()
