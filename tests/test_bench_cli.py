@@ -119,3 +119,18 @@ def test_device_sampler_reads_only_the_devices_it_was_given(tmp_path):
     with bench.DeviceSampler([0x99, None], sysfs=str(tmp_path / "drm")) as s:
         time.sleep(0.05)
     assert s.summary() is None
+
+
+def test_catalogue_option_reads_a_real_ppm_file(tmp_path):
+    """--catalogue PATH: the bytes of a PPM catalogue file go through the product's own reader (src/StarMap.hs:45-58 layout)."""
+    import blackstar_amd as bs
+    from blackstar_amd import synthetic
+    data = synthetic.ppm_catalogue_bytes(300, seed=5)
+    path = tmp_path / "PPM"
+    path.write_bytes(data)
+    assert synthetic.catalogue_bytes(str(path)) == data
+    assert len(bs.read_map(synthetic.catalogue_bytes(str(path)))) == 300
+    assert synthetic.catalogue_bytes("synthetic") == synthetic.ppm_catalogue_bytes()
+    assert len(synthetic.catalogue_bytes("clustered")) > len(synthetic.catalogue_bytes("synthetic"))
+    args = types.SimpleNamespace(catalogue=str(path))
+    assert "REAL catalogue file PPM (300 stars" in bench.catalogue_note(args, 300)
