@@ -1292,8 +1292,8 @@ def test_clustered_sky_frame_and_rays(mode, tree_clustered, oracle, oracle_index
 
 def test_clustered_full_size_catalogue_lookup_and_frame(oracle):
     """bench.py --catalogue clustered: 470,000 uniform stars + 3,000 clusters + a band at 10x the mean density (686 k stars; grid cells
-    hold from 0 to ~100 entries).  Lookups aimed at clusters, at the band and anywhere vs the oracle's index, and a 480x270 supersampled
-    C3 frame in both modes vs the oracle's render."""
+    hold from 0 to ~100 entries).  Lookups aimed at clusters, at the band and anywhere vs the oracle's index, and a 960x540 supersampled
+    C3 frame (every pixel) in both modes vs the oracle's render."""
     data = synthetic.clustered_catalogue_bytes()
     stars = bs.read_map(data)
     t = bs.StarTree(stars)
@@ -1309,7 +1309,7 @@ def test_clustered_full_size_catalogue_lookup_and_frame(oracle):
         ref, nref = oracle.star_lookup(ix, 0.4, 1.5, dirs[k])
         assert hits[k] == nref, k
         np.testing.assert_allclose(rgb[k], ref, rtol=1e-12, atol=1e-15)
-    cfg = scenes.with_res(scenes.DEFAULT_AA, 480, 270)
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 960, 540)  # 2.07 M rays, like test_c3_full_frame_both_modes_vs_oracle on the uniform sky
     ref, ost = oracle.render(cfg, ix, threads=0)
     for mode, rtol, atol in ((_lib.BS_MODE_STRICT, RTOL_STRICT, ATOL_STRICT), (_lib.BS_MODE_FAST, RTOL_FAST, ATOL_FAST)):
         t.set_mode(mode)
