@@ -22,8 +22,10 @@ if res:
 H, W = cfg.scene.resolution[1], cfg.scene.resolution[0]
 stars = bs.read_map(synthetic.ppm_catalogue_bytes())
 variants = [(v, 0) for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else ["auto", "0", "8", "16", "auto", "0"])]
-if len(sys.argv) > 5:
+if len(sys.argv) > 5 and sys.argv[5]:
     cfg.scene.bloomDivider = int(sys.argv[5])
+if len(sys.argv) > 6:
+    cfg.scene.bloomStrength = float(sys.argv[6])  # 0: the post stage is the sRGB8 map alone -> what the trace kernels cost on the masked streams
 ref = None
 for post, plan in variants:
     os.environ["BLACKSTAR_POST_CUS"] = str(post)
