@@ -104,6 +104,11 @@ class Dump:
     def assocs(self):
         return np.fromfile(os.path.join(self.dir, "assocs.f64"), "<f8").reshape(-1, 6)
 
+    def animation_frames(self):
+        """(n, 10) cameras of Animation.generateFrames on inputs/<set>/animation.yaml (position, lookAt, upVec, fov), or None."""
+        fn = os.path.join(self.dir, "animation_frames.f64")
+        return np.fromfile(fn, "<f8").reshape(-1, 10) if os.path.exists(fn) else None
+
     def kdt_bytes(self):
         with open(os.path.join(self.dir, "stars.kdt"), "rb") as f:
             return f.read()
@@ -142,3 +147,18 @@ def compare(dump, render, star_lookup, bloom, srgb8, rtol, atol, exact_bytes=Tru
         assert diff == 0 or not exact_bytes, f"writeImg {name}: {diff} bytes differ (max {int(np.abs(png.astype(int) - mine.astype(int)).max())} LSB)"
         rep["scenes"] += 1
     return rep
+
+
+def compare_animation(dump):
+    """Row f3: blackstar_amd.animation.generate_frames on the same animation file against Animation.generateFrames (src/Animation.hs:45-86).
+    Linear interpolation in the same operation order: equal to the last bit is the expectation, 4e-16 relative the bar."""
+    import blackstar_amd as bs
+    want = dump.animation_frames()
+    if want is None:
+        return 0
+    anim = bs.Animation.from_file(os.path.join(dump.inputs, "animation.yaml"))
+    bs.validate_keyframes(anim.keyframes)
+    got = np.array([list(c.camera.position) + list(c.camera.lookAt) + list(c.camera.upVec) + [c.camera.fov] for c in bs.generate_frames(anim)])
+    assert got.shape == want.shape, (got.shape, want.shape)
+    np.testing.assert_allclose(got, want, rtol=4e-16, atol=0)
+    return len(want)

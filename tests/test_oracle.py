@@ -418,6 +418,8 @@ def test_oracle_against_the_reference_itself(which, oracle):
     back = kdt_file.read_kdt(d.kdt_bytes())
     got = np.stack([back["x"], back["y"], back["z"], back["mag"].astype(float), back["hue"], back["sat"]], axis=1)
     assert np.array_equal(got, d.assocs()), "stars.kdt decodes to other stars (or another order) than KdMap.assocs"
+    if which == "uniform":
+        assert ghc_pin.compare_animation(d) == 375  # row f3: generateFrames on animations/default-ani.yaml
 
 
 def test_ghc_pin_harness_on_a_stand_in_dump(tmp_path, oracle):
@@ -453,12 +455,18 @@ def test_ghc_pin_harness_on_a_stand_in_dump(tmp_path, oracle):
     (out / "stars.kdt").write_bytes(kdt)
     back = kdt_file.read_kdt(kdt)
     np.stack([back["x"], back["y"], back["z"], back["mag"].astype(float), back["hue"], back["sat"]], axis=1).astype("<f8").tofile(out / "assocs.f64")
-    (out / "manifest.txt").write_text(f"compiler STAND-IN numpy-restatement\nstars {len(stars6)} dirs {len(dirs)}\nscene {name} 96 54 bloom\n")
+    (out / "manifest.txt").write_text(f"compiler STAND-IN numpy-restatement\nstars {len(stars6)} dirs {len(dirs)}\nscene {name} 96 54 bloom\nanimation 375\n")
+    shutil.copyfile(os.path.join(ghc_pin.INPUTS, "uniform", "animation.yaml"), tmp_path / "animation.yaml")
+    cams = [scenes.ani_frame(i, 375) for i in range(375)]  # oracle/scenes.py: an independent restatement of the two-keyframe interpolation
+    np.array([list(c["cam_pos"]) + list(c["cam_lookat"]) + list(c["cam_up"]) + [c["fov"]] for c in cams]).astype("<f8").tofile(out / "animation_frames.f64")
     assert ghc_pin.available(which, root=str(tmp_path / "dumps"))
     d = ghc_pin.Dump(which, root=str(tmp_path / "dumps"))
     assert np.array_equal(d.png(name), np_oracle.srgb8(bl))  # own PNG decoder reads back what the encoder wrote
     rep = ghc_pin.compare(d, rtol=1e-12, atol=1e-15, **_oracle_callables(oracle, d))
     assert rep["scenes"] == 1 and rep["values"] == 96 * 54 * 3 + 3 * len(dirs) and rep["bit_equal"] > 0.9 * rep["values"]
+    d.inputs = str(tmp_path)  # (the stand-in's animation file sits beside it)
+    assert ghc_pin.compare_animation(d) == 375
+    d.inputs = os.path.join(ghc_pin.INPUTS, which)
     # a single wrong value anywhere must fail the comparison
     for victim, offset in ((f"{name}.render.f64", 8 * 1234), ("starlookup.f64", 0), (f"{name}.bloom.f64", 8 * 77)):
         bad_root = tmp_path / ("bad_" + victim)

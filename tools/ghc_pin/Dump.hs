@@ -10,6 +10,7 @@
 --     ImageFilters.bloom
 --     Data.Yaml.decodeFileEither  (the way app/Main.hs:85 decodes a scene file)
 --     Data.KdMap.Static.assocs    (kdt: the order and content of the tree the reference builds)
+--     Animation.validateKeyframes / generateFrames   (what `animate` does, app/Animate.hs:47-53)
 --
 -- It could NOT be compiled where it was written (no GHC in that image): expect to fix an import or two.  Written against
 -- resolver lts-13.16 (stack.yaml:1): GHC 8.6.4, massiv 0.2.x (`size` returns an Ix2), massiv-io 0.1.x, kdt 0.2.4, cereal 0.5.8.
@@ -20,9 +21,10 @@
 --   INPUT_DIR/dirs.f64          n x 3 little-endian doubles: un-normalised directions for starLookup
 --   INPUT_DIR/lookup.txt        one line: "<starIntensity> <starSaturation>" used for dirs.f64
 --   INPUT_DIR/scenes/*.yaml     scene files in the reference's own format (scenes/default.yaml)
+--   INPUT_DIR/animation.yaml    (optional) an animation file in the reference's format (animations/default-ani.yaml)
 module Main (main) where
 
-import           Control.Monad            (forM_, unless)
+import           Control.Monad            (forM_, unless, when)
 import qualified Data.ByteString          as B
 import qualified Data.ByteString.Builder  as BB
 import qualified Data.ByteString.Lazy     as BL
@@ -36,13 +38,14 @@ import           Data.Version             (showVersion)
 import qualified Data.Yaml                as Y
 import           Graphics.ColorSpace
 import           Linear                   (V3 (..))
-import           System.Directory         (createDirectoryIfMissing, listDirectory)
+import           System.Directory         (createDirectoryIfMissing, doesFileExist, listDirectory)
 import           System.Environment       (getArgs)
 import           System.Exit              (die)
 import           System.FilePath          (takeBaseName, takeExtension, (<.>), (</>))
 import           System.Info              (arch, compilerName, compilerVersion, os)
 import           System.IO                (IOMode (WriteMode), hPutStrLn, withFile)
 
+import qualified Animation                as An   -- qualified: it exports its own `scene` and `camera`
 import           ConfigFile
 import           ImageFilters             (bloom)
 import           Raytracer                (render, writeImg)
@@ -112,4 +115,19 @@ main = do
                 else return img
             writeImg final (outDir </> name <.> "png")
             hPutStrLn hdl $ unwords ["scene", name, show w, show h, if bloomStrength scn /= 0 then "bloom" else "nobloom"]
+    -- animate's path (app/Animate.hs:47-53): decode, validateKeyframes, generateFrames -> one camera per frame, 10 doubles each
+    -- (position, lookAt, upVec, fov)
+    haveAni <- doesFileExist (inDir </> "animation.yaml")
+    when haveAni $ do
+        eani <- Y.decodeFileEither (inDir </> "animation.yaml")
+        ani :: An.Animation <- either (die . Y.prettyPrintParseException) return eani
+        either die return (An.validateKeyframes (An.keyframes ani))
+        BL.writeFile (outDir </> "animation_frames.f64") . BB.toLazyByteString . mconcat $
+            [ mconcat (map BB.doubleLE [px, py, pz, lx, ly, lz, ux, uy, uz, fov cam])
+            | c <- An.generateFrames ani
+            , let cam = camera c
+            , let V3 px py pz = position cam
+            , let V3 lx ly lz = lookAt cam
+            , let V3 ux uy uz = upVec cam ]
+        appendFile (outDir </> "manifest.txt") (unwords ["animation", show (An.nFrames ani)] ++ "\n")
     unless (null names) $ putStrLn ("wrote " ++ show (length names) ++ " scenes to " ++ outDir)

@@ -3,7 +3,8 @@
     python tools/ghc_pin/make_inputs.py
 
   inputs/uniform/    catalogue.ppm = tests/golden/catalogue_2000.ppm; scenes/*.yaml = the configurations of the eleven image goldens
-                     (tests/conftest.py IMAGE_GOLDENS) in the reference's own scene-file format; dirs.f64 = 10 000 starLookup directions
+                     (tests/conftest.py IMAGE_GOLDENS) in the reference's own scene-file format; dirs.f64 = 10 000 starLookup directions;
+                     animation.yaml = animations/default-ani.yaml (Animation.generateFrames, row f3)
   inputs/clustered/  catalogue.ppm = tests/golden/catalogue_clustered.ppm (clusters of 5..40 stars inside one lookup radius);
                      the clustered frame; dirs.f64 = the 1 500 directions of tests/golden/lookup_clustered.npz
 
@@ -84,6 +85,8 @@ def main():
     near = stars[rng.integers(0, len(stars), 6000), :3]
     dirs = np.concatenate([near * rng.uniform(0.5, 3, (6000, 1)) + rng.normal(scale=5e-4, size=(6000, 3)), rng.normal(size=(4000, 3))])
     write_set("uniform", "catalogue_2000.ppm", cfgs, dirs, 0.4, 1.5)
+    # the animation file of this repository (the reference's animations/default-ani.yaml restated, same format, nFrames 375): row f3
+    shutil.copyfile(os.path.join(ROOT, "animations", "default-ani.yaml"), os.path.join(HERE, "inputs", "uniform", "animation.yaml"))
     gc = load_golden("image_clustered_default_aa_96x54")["cfg"]
     lk = load_golden("lookup_clustered")
     write_set("clustered", "catalogue_clustered.ppm", {"clustered_default_aa_96x54": (gc, bloom_of(gc))}, lk["dirs"], float(lk["intensity"]), float(lk["saturation"]))
