@@ -161,4 +161,13 @@ def compare_animation(dump):
     got = np.array([list(c.camera.position) + list(c.camera.lookAt) + list(c.camera.upVec) + [c.camera.fov] for c in bs.generate_frames(anim)])
     assert got.shape == want.shape, (got.shape, want.shape)
     np.testing.assert_allclose(got, want, rtol=4e-16, atol=0)
+    fn = os.path.join(dump.dir, "padzero.txt")
+    if os.path.exists(fn):  # padZero mis-pads index 0 (logBase 10 0); from index 1 on it is plain zero padding
+        width = len(str(len(want) - 1))
+        for line in open(fn):
+            i, name = line.split()
+            if int(i) >= 1:
+                assert name == str(int(i)).zfill(width), (i, name)
+            else:
+                print(f"reference names frame 0 {name!r} (render_animation writes {'0'.zfill(width)!r})")
     return len(want)

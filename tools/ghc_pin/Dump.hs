@@ -10,7 +10,7 @@
 --     ImageFilters.bloom
 --     Data.Yaml.decodeFileEither  (the way app/Main.hs:85 decodes a scene file)
 --     Data.KdMap.Static.assocs    (kdt: the order and content of the tree the reference builds)
---     Animation.validateKeyframes / generateFrames   (what `animate` does, app/Animate.hs:47-53)
+--     Animation.validateKeyframes / generateFrames, Util.padZero   (what `animate` does, app/Animate.hs:47-56)
 --
 -- It could NOT be compiled where it was written (no GHC in that image): expect to fix an import or two.  Written against
 -- resolver lts-13.16 (stack.yaml:1): GHC 8.6.4, massiv 0.2.x (`size` returns an Ix2), massiv-io 0.1.x, kdt 0.2.4, cereal 0.5.8.
@@ -50,6 +50,7 @@ import           ConfigFile
 import           ImageFilters             (bloom)
 import           Raytracer                (render, writeImg)
 import           StarMap
+import           Util                     (padZero)
 
 -- h*w*3 little-endian doubles, row-major, interleaved RGB: the layout of bs_render's out_rgb
 imageBytes :: Image A.U RGB Double -> BL.ByteString
@@ -130,4 +131,7 @@ main = do
             , let V3 lx ly lz = lookAt cam
             , let V3 ux uy uz = upVec cam ]
         appendFile (outDir </> "manifest.txt") (unwords ["animation", show (An.nFrames ani)] ++ "\n")
+        -- the frame-file names `animate` would give them (app/Animate.hs:55-56, src/Util.hs:43-48): index 0 goes through logBase 10 0
+        writeFile (outDir </> "padzero.txt") . unlines $
+            [ unwords [show i, padZero (An.nFrames ani - 1) i] | i <- [0, 1, 9, 10, 99, 100, An.nFrames ani - 1] ]
     unless (null names) $ putStrLn ("wrote " ++ show (length names) ++ " scenes to " ++ outDir)
