@@ -477,3 +477,31 @@ def test_ghc_pin_harness_on_a_stand_in_dump(tmp_path, oracle):
         (bad_root / which / victim).write_bytes(bytes(raw))
         with pytest.raises(AssertionError):
             ghc_pin.compare(ghc_pin.Dump(which, root=str(bad_root)), rtol=1e-12, atol=1e-15, **_oracle_callables(oracle, d))
+
+
+def test_ghc_pin_kit_is_complete_and_consistent():
+    """The hand-off must not rot: every input Dump.hs reads exists, the scene files decode with this repository's own decoder, the
+    runner script parses, and Dump.hs names only functions the reference's library stanza exports (blackstar.cabal:16-24 modules)."""
+    import subprocess
+    import ghc_pin
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ghc_pin")
+    assert subprocess.run(["sh", "-n", os.path.join(root, "run.sh")]).returncode == 0
+    for which, n_scenes, n_dirs in (("uniform", 11, 10000), ("clustered", 1, 1500)):
+        d = os.path.join(ghc_pin.INPUTS, which)
+        assert os.path.getsize(os.path.join(d, "catalogue.ppm")) % 28 == 0
+        assert os.path.getsize(os.path.join(d, "dirs.f64")) == n_dirs * 24
+        assert len(open(os.path.join(d, "lookup.txt")).read().split()) == 2
+        names = sorted(f for f in os.listdir(os.path.join(d, "scenes")) if f.endswith(".yaml"))
+        assert len(names) == n_scenes
+        import blackstar_amd as bs
+        for f in names:
+            c = bs.Config.from_file(os.path.join(d, "scenes", f))
+            assert c.scene.resolution[0] // c.scene.bloomDivider >= 1  # bloom would crash the reference otherwise (foldl1' on [])
+    assert os.path.exists(os.path.join(ghc_pin.INPUTS, "uniform", "animation.yaml"))
+    src = open(os.path.join(root, "Dump.hs")).read()
+    for fn in ("readMapFromFile", "buildStarTree", "treeToByteString", "readTreeFromFile", "starLookup", "render cfg tree", "writeImg", "bloom (bloomStrength scn)",
+               "An.generateFrames", "An.validateKeyframes", "K.assocs", "padZero"):
+        assert fn in src, fn
+    stanza = open(os.path.join(root, "run.sh")).read()
+    for dep in ("blackstar", "cereal", "yaml", "kdt", "massiv-io"):
+        assert dep in stanza
