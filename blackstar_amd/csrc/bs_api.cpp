@@ -1018,6 +1018,8 @@ static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *str
 }
 
 // The CU-masked streams of a partition (post stage on bits [0, post_cus), trace kernels on the rest), made once per context and M.
+// (hipExtStreamCreateWithCUMask takes no flags: unlike the context's other streams these synchronise with the NULL stream -- only a
+// matter of overlap, and only if another thread of the caller keeps the NULL stream busy during a bs_render_rgb8_batch call.)
 // false: the runtime would not make them (no CU-mask support on this device / driver) -- the caller falls back to the shared chip.
 static bool ensure_partition(bs_ctx *ctx, int post_cus)
 {
