@@ -1534,3 +1534,38 @@ def test_rgb8_batch_partition_at_full_size():
         t.close()
     print(f"bs_render_rgb8_batch, C3: shared chip {times['0']:.3f} ms per frame, partitioned {times['auto']:.3f}")
     assert times["auto"] < times["0"] * 1.05  # (measured 4.4 against 4.7 ms; the bar only guards against the partition going badly wrong)
+
+
+# ---- size-independent properties at sizes the oracle would take too long for ---------------------------------------------------
+
+def test_bloom_is_exactly_linear_under_power_of_two_scaling_at_4k(tree):
+    """boxBlur is a chain of additions, subtractions and one multiplication by 1/(2r+1) per sample (src/ImageFilters.hs:59-64): scaling the
+    image by a power of two scales every intermediate exactly, so bloom(2^k img) == 2^k bloom(img) BIT FOR BIT -- at 3840x2160, where
+    the CPU oracle is not consulted -- for every sweep path the library can take; and a constant image stays constant away from the borders."""
+    rng = np.random.default_rng(77)
+    img = rng.uniform(0, 1.5, (2160, 3840, 3))
+    for path in ("dma", "lds", "direct"):
+        os.environ["BLACKSTAR_BLOOM_PATH"] = path
+        try:
+            a = bs.bloom(0.15, 25, img, tree)
+            for k in (-3, 1, 5):
+                assert np.array_equal(bs.bloom(0.15, 25, img * 2.0 ** k, tree), a * 2.0 ** k), (path, k)
+        finally:
+            del os.environ["BLACKSTAR_BLOOM_PATH"]
+        assert (a >= img).all()  # blurred light is only ever added
+    r = 3840 // 25
+    flat = bs.bloom(1.0, 25, np.full((2160, 3840, 3), 0.5), tree)
+    inner = flat[4 * r:-4 * r, 4 * r:-4 * r]  # three passes reach 3 r from a border
+    expect = 0.5 + 0.5 * ((2.0 * r) / (2 * r + 1)) ** 6  # every sweep sums 2r samples and divides by 2r+1 (SURVEY F.4)
+    np.testing.assert_allclose(inner, expect, rtol=1e-13)
+    assert inner.max() - inner.min() < 1e-15
+
+
+def test_srgb8_is_monotone_and_clamped_on_a_full_frame(tree):
+    """toWord8 . sRGB is monotone and clamps to [0, 255] (src/Raytracer.hs:23-32): on 25 M sorted values the bytes are sorted, start at 0
+    for x <= 0, end at 255 for x >= 1, and every one of the 256 bytes occurs."""
+    x = np.sort(np.random.default_rng(78).uniform(-0.2, 1.3, 3840 * 2160 * 3)).reshape(2160, 3840, 3)
+    b = bs.srgb8(x, tree).ravel()
+    assert (np.diff(b.astype(np.int16)) >= 0).all()
+    xs = x.ravel()
+    assert (b[xs <= 0] == 0).all() and (b[xs >= 1] == 255).all() and len(np.unique(b)) == 256
