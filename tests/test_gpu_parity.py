@@ -1569,3 +1569,21 @@ def test_srgb8_is_monotone_and_clamped_on_a_full_frame(tree):
     assert (np.diff(b.astype(np.int16)) >= 0).all()
     xs = x.ravel()
     assert (b[xs <= 0] == 0).all() and (b[xs >= 1] == 255).all() and len(np.unique(b)) == 256
+
+
+@pytest.mark.parametrize("mode", [_lib.BS_MODE_STRICT, _lib.BS_MODE_FAST])
+def test_supersample_identity_at_full_size(mode, tree):
+    """render with supersampling == supersample (render at twice the resolution) (src/Raytracer.hs:58,67; src/ImageFilters.hs:94-96), bit
+    for bit, on the BASELINE configs[2] frame itself: 8.3 M rays traced as one 3840x2160 frame and as the fused 1920x1080 one."""
+    tree.set_mode(mode)
+    try:
+        big = bs.render(scenes.with_res(scenes.DEFAULT_AA, 3840, 2160, ss=False), tree)
+        st_big = tree.stats()
+        small = bs.render(scenes.DEFAULT_AA, tree)
+        st_small = tree.stats()
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    exp = 0.25 * (((big[0::2, 0::2] + big[1::2, 0::2]) + big[0::2, 1::2]) + big[1::2, 1::2])
+    assert np.array_equal(small, exp)
+    for k in ("rays", "steps", "horizon", "escaped", "disk_hits", "star_hits", "capped"):
+        assert st_big[k] == st_small[k], k
