@@ -1587,3 +1587,25 @@ def test_supersample_identity_at_full_size(mode, tree):
     assert np.array_equal(small, exp)
     for k in ("rays", "steps", "horizon", "escaped", "disk_hits", "star_hits", "capped"):
         assert st_big[k] == st_small[k], k
+
+
+def test_row_bands_and_split_at_full_size(catalogue_bytes):
+    """The BASELINE configs[2] frame as ragged row bands on one context and split over three contexts (one huge frame sharded
+    by rows, no halo): bit-identical to the one-launch frame in the shipped FAST mode, statistics adding up."""
+    trees = [bs.StarTree(bs.read_map(catalogue_bytes), device=0) for _ in range(3)]
+    try:
+        cfg = scenes.DEFAULT_AA
+        whole = bs.render(cfg, trees[0])
+        st = trees[0].stats()
+        cuts = [0, 1, 8, 135, 136, 541, 1079, 1080]
+        parts, steps = [], 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            parts.append(bs.render_rows(cfg, trees[0], a, b))
+            steps += trees[0].stats()["steps"]
+        assert np.array_equal(np.concatenate(parts, axis=0), whole) and steps == st["steps"]
+        out = bs.alloc_image(trees[0], 1080, 1920)
+        assert np.array_equal(bs.render_split(cfg, trees, out=out), whole)
+        assert np.array_equal(bs.render_split(cfg, trees), whole)  # pageable output: staged per band
+    finally:
+        for t in trees:
+            t.close()
