@@ -191,6 +191,7 @@ BAD_CONFIGS = {  # what -> (override, substring of the message).  src/Raytracer.
     "lookAt 1e-7 from position": (dict(cam_lookat=(1e-7, 1.0, -20.0)), "lookAt equals"),
     "bad hue": (dict(disk_hsi=(1.0, 0.1, 1.0)), "not properly scaled"),
     "zero width": (dict(width=0), "resolution"),
+    "more than 2^28 pixels": (dict(width=32768, height=16384), "resolution too large"),
 }
 
 
@@ -204,6 +205,7 @@ def test_validate_config_rejects_what_the_reference_never_returns_from(what):
     assert L.bs_validate_config(C.byref(_lib.make_config(dict(scenes.with_res(scenes.DEFAULT, 8, 8), **over)))) == -1
     assert msg.encode() in L.bs_last_error(), L.bs_last_error()
     assert L.bs_validate_config(None) == -1
+    assert L.bs_validate_config(C.byref(_lib.make_config(dict(scenes.DEFAULT, width=16384, height=16384)))) == 0  # 2^28 pixels: the largest frame accepted
 
 
 def test_every_shipped_scene_and_animation_frame_validates():
