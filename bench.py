@@ -341,6 +341,19 @@ def sustained_leg(bs, torch, np, trees, cfgs, outs, streams, devs, n_frames):
     return wall, per_dev
 
 
+def optional_leg(name, safe, fn):
+    """Run a leg that is reported NEXT TO the headline value.  With safe=True (one rank, and the headline does not come from this
+    leg) a failure becomes {"error": ...} in the line instead of costing the value already measured; otherwise it propagates
+    (with several ranks, one rank leaving a leg early would leave the others waiting in its barrier)."""
+    if not safe:
+        return fn()
+    try:
+        return fn()
+    except Exception as e:
+        print(f"bench.py: optional leg {name!r} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def roofline_block(args, st, kernel_ms, W, H, peak_measured=None):
     executed = int(st["steps"]) - int(st["rays"])  # the kernel skips the reference's final, discarded rk4 per ray
     flops = FLOP_PER_STEP * executed
@@ -626,10 +639,10 @@ def run_ranks(args):
     d2h = None
     want = {"all": ["batch", "rgb8-batch"], "resident": [], "batch": ["batch"], "rgb8-batch": ["rgb8-batch"]}[args.form]
     if want:
-        d2h = d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x)))
+        d2h = optional_leg("with_d2h", world == 1 and resident,
+                           lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x))))
 
-    sustained = None
-    if args.sustained_frames >= 50 and resident:
+    def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
         fence()
         with DeviceSampler([pci_bus_of(torch, local_rank)]) as smp:
@@ -642,15 +655,20 @@ def run_ranks(args):
             objs = [None] * world
             dist.all_gather_object(objs, devices)
             devices = [d for o in objs for d in (o or [None])]
-        sustained = dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / max(ms_all) / 1e3, per_rank_ms_per_frame=ms_all,
-                         device=devices, note="back-to-back launches of the same frame on one stream per GPU, all ranks at once; "
-                                              "Mpixel_s from the slowest rank; device = sampled sclk / power, one entry per rank")
+        return dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / max(ms_all) / 1e3, per_rank_ms_per_frame=ms_all,
+                    device=devices, note="back-to-back launches of the same frame on one stream per GPU, all ranks at once; "
+                                         "Mpixel_s from the slowest rank; device = sampled sclk / power, one entry per rank")
+
+    sustained = None
+    if args.sustained_frames >= 50 and resident:
+        sustained = optional_leg("sustained", world == 1, sustained_block)
 
     if rank == 0:
         frames = args.steps * world
         peak = None
         if world == 1 and not args.no_boundary and frames_cfg is None and resident:
-            peak = measure_peak(tree, _lib)
+            peak = optional_leg("measure_peak", True, lambda: measure_peak(tree, _lib))
+            peak = None if isinstance(peak, dict) and "error" in peak else peak
         extra = {"backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else "none (single rank)",
                  "devices_visible": ndev, "oversubscribed": world > ndev, "launches_in_flight_per_gpu": n_streams,
                  "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])]}
@@ -680,13 +698,17 @@ def run_ranks(args):
         if sustained:
             res["sustained"] = sustained
         if world == 1 and not args.no_boundary and frames_cfg is None and resident:
-            res["boundary"], res["strict"] = boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream)
+            both = optional_leg("boundary", True, lambda: boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream))
+            res["boundary"], res["strict"] = both if isinstance(both, tuple) else (both, both)
         if world == 1 and args.cpu_seconds > 0:
-            res["cpu_baseline"] = cpu_baseline(cfg, star_bytes, args.cpu_seconds)
+            res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds))
         if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and frames_cfg is None:
             # LAST: the profiler's child processes run after every timed leg of this process (a PMC session may leave the device in
             # another clock state for a while), and only the counter values are taken from them
-            args.traffic_live = pmc_traffic_live(args.mode, args.catalogue)
+            try:
+                args.traffic_live = pmc_traffic_live(args.mode, args.catalogue)
+            except Exception as e:  # nothing about the profiler may cost the line that has already been measured
+                args.traffic_live = (None, f"{type(e).__name__}: {e}")
             fresh = roofline_block(args, st, kernel_ms, W, H)
             res["roofline"].update({k: fresh[k] for k in ("traffic", "traffic_kind", "traffic_source")})
         print(json.dumps(res), flush=True)
@@ -800,18 +822,21 @@ def run_single_process(args):
     if want:  # frame i on context i % world, args.steps frames per context, ONE call over all contexts
         n = args.steps * world
         objs = [cfg_obj] * n if frames_obj is None else [frames_obj[i % len(frames_obj)] for i in range(n)]
-        d2h = d2h_forms(bs, np, trees, objs, W, H, 1, want, fence, lambda x: x)
+        d2h = optional_leg("with_d2h", resident, lambda: d2h_forms(bs, np, trees, objs, W, H, 1, want, fence, lambda x: x))
 
-    sustained = None
-    if args.sustained_frames >= 50 and resident:
+    def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
         with DeviceSampler([pci_bus_of(torch, d) for d in devs]) as smp:
             wall, per_dev = sustained_leg(bs, torch, np, trees, [cfg if frames_cfg is None else frames_cfg[k % len(frames_cfg)] for k in range(world)],
                                           outs, streams, devs, n_sus)
         worst = max(p["ms_per_frame"] for p in per_dev) if world <= ndev else wall / n_sus * 1e3
-        sustained = dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / (wall / n_sus * 1e3) / 1e3, wall_ms_per_round=wall / n_sus * 1e3,
-                         per_rank_ms_per_frame=[p["ms_per_frame"] for p in per_dev], slowest_device_ms_per_frame=worst, device=smp.summary(),
-                         note="back-to-back launches of the same frame, one stream per device, all devices at once; Mpixel_s from the wall clock")
+        return dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / (wall / n_sus * 1e3) / 1e3, wall_ms_per_round=wall / n_sus * 1e3,
+                    per_rank_ms_per_frame=[p["ms_per_frame"] for p in per_dev], slowest_device_ms_per_frame=worst, device=smp.summary(),
+                    note="back-to-back launches of the same frame, one stream per device, all devices at once; Mpixel_s from the wall clock")
+
+    sustained = None
+    if args.sustained_frames >= 50 and resident:
+        sustained = optional_leg("sustained", True, sustained_block)
 
     extra = {"backend": "none (one process, one bs_ctx + stream per device; frames never leave their GPU)",
              "devices_visible": ndev, "oversubscribed": world > ndev, "devices": devs, "launches_in_flight_per_gpu": n_streams,
