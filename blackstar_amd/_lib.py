@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BLACKSTAR_LIB") or os.path.join(_HERE, "libblackstar_gpu.so")  # BLACKSTAR_LIB: A/B builds of the same ABI
 
 BS_MODE_STRICT, BS_MODE_FAST = 0, 1
-BS_ABI_VERSION = 2  # include/blackstar_gpu.h
+BS_ABI_VERSION = 3  # include/blackstar_gpu.h
 
 
 class BsConfig(C.Structure):
@@ -40,7 +40,8 @@ RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4
 SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
            "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
            "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots",
-           "bs_effective_mode", "bs_validate_config", "bs_debug_post_cus", "bs_debug_last_post_cus", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch")
+           "bs_effective_mode", "bs_validate_config", "bs_debug_post_cus", "bs_debug_last_post_cus", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch",
+           "bs_png_bound", "bs_encode_png_device", "bs_encode_png", "bs_render_png", "bs_render_png_batch")
 
 _lib = None
 
@@ -136,6 +137,11 @@ def lib() -> C.CDLL:
         L.bs_render_rgb8.argtypes = [vp, C.POINTER(BsConfig), dp, C.c_int, vp, sz]
     if hasattr(L, "bs_render_rgb8_batch"):
         L.bs_render_rgb8_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.bs_png_bound.argtypes = [C.c_int, C.c_int, C.POINTER(sz)]
+    L.bs_encode_png_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz, vp, vp]
+    L.bs_encode_png.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz, C.POINTER(sz)]
+    L.bs_render_png.argtypes = [vp, C.POINTER(BsConfig), dp, C.c_int, vp, sz, C.POINTER(sz)]
+    L.bs_render_png_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -62,6 +62,36 @@ def render_rgb8_batch(cfgs: Sequence[Config], trees: Sequence[StarTree], outs: S
     return outs
 
 
+def render_png_batch(cfgs: Sequence[Config], trees: Sequence[StarTree], outs: Sequence[np.ndarray] = None) -> List[memoryview]:
+    """render_rgb8_batch with finished PNG files instead of pixels (`bs_render_png_batch`): the whole of doRender (app/Main.hs:105-123)
+    but the write(2) on the device, two frames in flight per tree.  Returns the files' bytes in order (views of `outs` -- flat uint8
+    buffers of at least png_bound(h, w) bytes each, e.g. from raytracer.alloc_png, which the encoder fills itself -- if given)."""
+    from .raytracer import png_bound
+    if not trees:
+        raise ValueError("need at least one StarTree")
+    if any(not isinstance(c, Config) for c in cfgs):
+        raise TypeError("render_png_batch takes Config objects (the scene's bloom parameters are part of the frame)")
+    cs = [_lib.make_config(c.to_bs_config()) for c in cfgs]
+    n = len(cs)
+    if outs is None:
+        outs = [np.empty(png_bound(c.height, c.width), np.uint8) for c in cs]
+    else:
+        outs = list(outs)
+        if len(outs) != n or any(o.ndim != 1 or o.dtype != np.uint8 or not o.flags["C_CONTIGUOUS"] for o in outs):
+            raise ValueError("outs must hold one flat C-contiguous uint8 buffer per frame")
+    if n == 0:
+        return []
+    arr = (_lib.BsConfig * n)(*cs)
+    strengths = (C.c_double * n)(*[float(c.scene.bloomStrength) for c in cfgs])
+    dividers = (C.c_int * n)(*[int(c.scene.bloomDivider) for c in cfgs])
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    caps = (C.c_size_t * n)(*[o.size for o in outs])
+    sizes = (C.c_size_t * n)()
+    ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
+    _lib.check(_lib.lib().bs_render_png_batch(ctxs, len(trees), arr, n, strengths, dividers, ptrs, caps, sizes), "bs_render_png_batch")
+    return [memoryview(o)[:sizes[i]] for i, o in enumerate(outs)]
+
+
 def render_split(cfg, trees: Sequence[StarTree], out: np.ndarray = None) -> np.ndarray:
     """ONE frame over several StarTrees (one per GPU): tree k renders the k-th contiguous band of rows (`bs_render_split`).
     Bit-identical to render(cfg, trees[0]).  `out`: the (h, w, 3) float64 buffer to fill; a page-locked one (alloc_image) is

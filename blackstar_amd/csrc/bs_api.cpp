@@ -117,6 +117,17 @@ struct bs_ctx {
     size_t img3_cap = 0;
     unsigned char *d_u8c = nullptr;
     size_t u8c_cap = 0;
+    // writeImg's PNG encoder on the device (png_kernels.hip): per frame in flight its scratch (filter types, chunk sizes / offsets, staging
+    // slots), a device copy of the file for callers with pageable buffers, and the file's size in page-locked memory
+    static constexpr int kPngSlots = 3;
+    void *d_png_scratch[kPngSlots] = {nullptr, nullptr, nullptr};
+    size_t png_scratch_cap[kPngSlots] = {0, 0, 0};
+    unsigned char *d_png_file[kPngSlots] = {nullptr, nullptr, nullptr};
+    size_t png_file_cap[kPngSlots] = {0, 0, 0};
+    uint64_t *h_png_bytes = nullptr;   // page-locked, kPngSlots entries (the kernels write them through the device alias)
+    hipEvent_t ev_png = nullptr;       // behind the last user of PNG slot 0 (the enqueue-only entry point): see acquire_png
+    hipStream_t png_stream = nullptr;
+    bool png_busy = false;
     struct VerifiedRange { const void *host = nullptr; size_t bytes = 0; };
     VerifiedRange verified[8];  // host buffers device_alias_of_pinned has walked page by page (registered memory without a queryable range)
     int verified_next = 0;
@@ -264,6 +275,18 @@ double *device_alias_of_pinned(bs_ctx *ctx, const void *host, size_t bytes, bool
 
 const char *kStraddleMsg = "output buffer starts in page-locked memory but is not contained in it (it runs past the end of its hipHostMalloc / "
                            "hipHostRegister range, e.g. into pageable memory between two registered ranges): neither the kernel nor the runtime's copy can deliver into it";
+
+template <class T>
+bool grow_device(T *&buf, size_t &cap, size_t elems)
+{
+    if (cap >= elems) return true;
+    if (buf) (void)hipFree(buf);
+    buf = nullptr;
+    cap = 0;
+    if (hipMalloc((void **)&buf, elems * sizeof(T)) != hipSuccess) return false;
+    cap = elems;
+    return true;
+}
 
 int ensure_scratch(bs_ctx *ctx, size_t bytes)
 {
@@ -480,6 +503,12 @@ void bs_destroy(bs_ctx *ctx)
         if (ctx->d_u8b) (void)hipFree(ctx->d_u8b);
         if (ctx->d_u8c) (void)hipFree(ctx->d_u8c);
         if (ctx->d_img3) (void)hipFree(ctx->d_img3);
+        for (void *b : ctx->d_png_scratch)
+            if (b) (void)hipFree(b);
+        for (unsigned char *b : ctx->d_png_file)
+            if (b) (void)hipFree(b);
+        if (ctx->h_png_bytes) (void)hipHostFree(ctx->h_png_bytes);
+        if (ctx->ev_png) (void)hipEventDestroy(ctx->ev_png);
         for (bs_ctx::Partition &pt : ctx->parts)
             for (hipStream_t st : {pt.trace[0], pt.trace[1], pt.post})
                 if (st) (void)hipStreamDestroy(st);
@@ -644,6 +673,29 @@ int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
     return BS_OK;
 }
 
+static int check_bloom_args(int width, double strength, int divider)
+{
+    if (strength != 0 && (divider <= 0 || width / divider == 0))  // the reference crashes here: foldl1' over an empty window (ImageFilters.hs:59)
+        return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+    return BS_OK;
+}
+
+// What doRender does with the rendered image (app/Main.hs:113-123): bloom when bloomStrength /= 0, then writeImg's pixel map -- d_img
+// (f64, w x h x 3) -> d_u8 (RGB8), on stream s.  The final img + strength * blurred is fused with the sRGB8 map: the bloomed f64
+// image is never written.  plan_cus: the CUs the blur sweeps are planned for.
+static int enqueue_post_rgb8(bs_ctx *ctx, const double *d_img, int w, int h, double strength, int divider, unsigned char *d_u8, int plan_cus, hipStream_t s)
+{
+    if (strength != 0) {
+        int rc = acquire_post(ctx, s);
+        if (rc) return rc;
+        if (bs::launch_bloom_srgb8(d_img, d_u8, ctx->d_post[0], ctx->d_post[1], w, h, strength, divider, plan_cus, ctx->d_srgb_table, s))
+            return fail(BS_EDEVICE, "bloom launch failed");
+        return release_post(ctx, s);
+    }
+    if (bs::launch_srgb8(d_img, d_u8, (size_t)w * h * 3, ctx->d_srgb_table, s)) return fail(BS_EDEVICE, "srgb8 launch failed");
+    return BS_OK;
+}
+
 int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_rgb8, size_t out_bytes)
 {
     if (!ctx || !cfg || !out_rgb8) return fail(BS_EINVAL, "null argument");
@@ -651,18 +703,11 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     auto t0 = std::chrono::steady_clock::now();
     const size_t n = (size_t)cfg->width * cfg->height * 3;
     if (out_bytes < n) return fail(BS_EINVAL, "output buffer too small");
-    if (bloom_strength != 0 && (bloom_divider <= 0 || cfg->width / bloom_divider == 0))
-        return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+    if (int rc = check_bloom_args(cfg->width, bloom_strength, bloom_divider)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
-    if (ctx->u8_cap < n) {
-        if (ctx->d_u8) (void)hipFree(ctx->d_u8);
-        ctx->d_u8 = nullptr;
-        ctx->u8_cap = 0;
-        if (hipMalloc((void **)&ctx->d_u8, n) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc failed");
-        ctx->u8_cap = n;
-    }
+    if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
     // a page-locked out_rgb8 is written by the sRGB8 kernel itself (zero copy), otherwise staged through d_u8
     unsigned char *u8_target = ctx->d_u8;
     bool straddles = false;
@@ -672,21 +717,146 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     // doRender (app/Main.hs:105-123): render -> bloom if bloomStrength /= 0 -> writeImg's sRGB + toWord8, all in HBM
     rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
     if (rc) return rc;
-    if (bloom_strength != 0) {  // bloom's final img + strength * blurred is fused with the sRGB8 map: the bloomed f64 image is never written
-        rc = acquire_post(ctx, ctx->stream);
-        if (rc) return rc;
-        if (bs::launch_bloom_srgb8(ctx->d_post[2], u8_target, ctx->d_post[0], ctx->d_post[1], cfg->width, cfg->height, bloom_strength, bloom_divider,
-                                   ctx->n_cu, ctx->d_srgb_table, ctx->stream))
-            return fail(BS_EDEVICE, "bloom launch failed");
-        rc = release_post(ctx, ctx->stream);
-        if (rc) return rc;
-    } else {
-        rc = bs_srgb8_device(ctx, ctx->d_post[2], u8_target, n, ctx->stream);
-        if (rc) return rc;
-    }
+    rc = enqueue_post_rgb8(ctx, ctx->d_post[2], cfg->width, cfg->height, bloom_strength, bloom_divider, u8_target, ctx->n_cu, ctx->stream);
+    if (rc) return rc;
     if (u8_target == ctx->d_u8) HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_zero_copy = u8_target != ctx->d_u8;
+    ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return BS_OK;
+}
+
+// ---- writeImg's file on the device (png_kernels.hip) --------------------------------------------------------------------------------
+
+static int check_png_frame(int width, int height)
+{
+    if (width <= 0 || height <= 0) return fail(BS_EINVAL, "resolution must be positive");
+    if ((double)width * (double)height > 1.0e9 || bs::png_file_bound(width, height) > 0xFFFFFFFFull)
+        return fail(BS_EINVAL, "frame too large for one PNG file of this encoder (chunk offsets are 32 bits)");
+    return BS_OK;
+}
+
+int bs_png_bound(int width, int height, size_t *out_bytes)
+{
+    if (!out_bytes) return fail(BS_EINVAL, "null argument");
+    if (int rc = check_png_frame(width, height)) return rc;
+    *out_bytes = (size_t)bs::png_file_bound(width, height);
+    return BS_OK;
+}
+
+// PNG slot k of the context sized for a w x h frame: the encoder's scratch, the page-locked size slots, and (device_file) a device copy
+// of the file for a caller whose buffer the GPU cannot write.
+static int ensure_png(bs_ctx *ctx, int k, int w, int h, bool device_file)
+{
+    if (!grow_device(reinterpret_cast<unsigned char *&>(ctx->d_png_scratch[k]), ctx->png_scratch_cap[k], bs::png_scratch_bytes(w, h)))
+        return fail(BS_ENOMEM, "hipMalloc PNG scratch failed");
+    if (device_file && !grow_device(ctx->d_png_file[k], ctx->png_file_cap[k], (size_t)bs::png_file_bound(w, h)))
+        return fail(BS_ENOMEM, "hipMalloc PNG file failed");
+    if (!ctx->h_png_bytes) HIP_TRY(hipHostMalloc((void **)&ctx->h_png_bytes, bs_ctx::kPngSlots * sizeof(uint64_t), hipHostMallocDefault));
+    return BS_OK;
+}
+
+static uint64_t *png_bytes_slot(bs_ctx *ctx, int k)
+{
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, ctx->h_png_bytes, 0) != hipSuccess || !d) return nullptr;
+    return static_cast<uint64_t *>(d) + k;
+}
+
+// PNG slot 0 serves the enqueue-only entry point: like the blur scratch, a user on another stream first waits for the previous one.
+static int acquire_png(bs_ctx *ctx, hipStream_t s)
+{
+    if (!ctx->ev_png) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_png, hipEventDisableTiming));
+    if (ctx->png_busy && ctx->png_stream != s) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_png, 0));
+    return BS_OK;
+}
+
+static int release_png(bs_ctx *ctx, hipStream_t s)
+{
+    HIP_TRY(hipEventRecord(ctx->ev_png, s));
+    ctx->png_busy = true;
+    ctx->png_stream = s;
+    return BS_OK;
+}
+
+int bs_encode_png_device(bs_ctx *ctx, const void *d_rgb8, int width, int height, void *d_png, size_t cap, void *d_file_bytes, void *hip_stream)
+{
+    if (!ctx || !d_rgb8 || !d_png || !d_file_bytes) return fail(BS_EINVAL, "null argument");
+    if (int rc = check_png_frame(width, height)) return rc;
+    if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_png(ctx, 0, width, height, false);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    rc = acquire_png(ctx, s);
+    if (rc) return rc;
+    if (bs::launch_png_encode(static_cast<const unsigned char *>(d_rgb8), width, height, ctx->d_png_scratch[0], static_cast<unsigned char *>(d_png),
+                              static_cast<uint64_t *>(d_file_bytes), s))
+        return fail(BS_EDEVICE, "PNG encoder launch failed");
+    return release_png(ctx, s);
+}
+
+// d_u8 (w x h RGB8 in HBM) -> the PNG file in the caller's out_png, on ctx->stream, blocking.  A page-locked out_png is written by the
+// encoder's last kernel itself; otherwise the file is assembled in HBM and exactly its bytes are copied.
+static int png_to_host(bs_ctx *ctx, const unsigned char *d_u8, int w, int h, unsigned char *out_png, size_t *out_bytes)
+{
+    bool straddles = false;
+    double *alias = device_alias_of_pinned(ctx, out_png, (size_t)bs::png_file_bound(w, h), &straddles);
+    if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+    int rc = ensure_png(ctx, 0, w, h, alias == nullptr);
+    if (rc) return rc;
+    uint64_t *d_bytes = png_bytes_slot(ctx, 0);
+    if (!d_bytes) return fail(BS_EDEVICE, "hipHostGetDevicePointer failed");
+    unsigned char *target = alias ? reinterpret_cast<unsigned char *>(alias) : ctx->d_png_file[0];
+    rc = acquire_png(ctx, ctx->stream);
+    if (rc) return rc;
+    if (bs::launch_png_encode(d_u8, w, h, ctx->d_png_scratch[0], target, d_bytes, ctx->stream)) return fail(BS_EDEVICE, "PNG encoder launch failed");
+    rc = release_png(ctx, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t bytes = (size_t)ctx->h_png_bytes[0];
+    if (!alias) {
+        HIP_TRY(hipMemcpyAsync(out_png, ctx->d_png_file[0], bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->last_zero_copy = alias != nullptr;
+    *out_bytes = bytes;
+    return BS_OK;
+}
+
+int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned char *out_png, size_t cap, size_t *out_bytes)
+{
+    if (!ctx || !rgb8 || !out_png || !out_bytes) return fail(BS_EINVAL, "null argument");
+    if (int rc = check_png_frame(width, height)) return rc;
+    if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)width * height * 3;
+    if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
+    StreamDrain drain(ctx);
+    HIP_TRY(hipMemcpyAsync(ctx->d_u8, rgb8, n, hipMemcpyHostToDevice, ctx->stream));
+    return png_to_host(ctx, ctx->d_u8, width, height, out_png, out_bytes);
+}
+
+int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_png, size_t cap, size_t *out_bytes)
+{
+    if (!ctx || !cfg || !out_png || !out_bytes) return fail(BS_EINVAL, "null argument");
+    if (int rc = check_png_frame(cfg->width, cfg->height)) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    if (cap < bs::png_file_bound(cfg->width, cfg->height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
+    if (int rc = check_bloom_args(cfg->width, bloom_strength, bloom_divider)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)cfg->width * cfg->height * 3;
+    int rc = ensure_post(ctx, n);
+    if (rc) return rc;
+    if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
+    StreamDrain drain(ctx);
+    // doRender (app/Main.hs:105-123) to the end: render -> bloom -> sRGB8 -> the PNG file, all on the device
+    rc = enqueue_render(ctx, cfg, ctx->d_post[2], n, ctx->stream);
+    if (rc) return rc;
+    rc = enqueue_post_rgb8(ctx, ctx->d_post[2], cfg->width, cfg->height, bloom_strength, bloom_divider, ctx->d_u8, ctx->n_cu, ctx->stream);
+    if (rc) return rc;
+    rc = png_to_host(ctx, ctx->d_u8, cfg->width, cfg->height, out_png, out_bytes);
+    if (rc) return rc;
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BS_OK;
 }
@@ -907,36 +1077,85 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
     return BS_OK;
 }
 
+// Where a batch's frames go: RGB8 pixels (png == nullptr) or finished PNG files (bs_render_png_batch).
+struct PngSink {
+    const size_t *caps;   // capacity of outs[i]
+    size_t *sizes;        // receives the size of file i
+};
+
+// What every frame of a context's share must satisfy before anything is launched; returns the largest frame (values) in *need.
+static int check_rgb8_share(const bs_config *cfgs, const double *strengths, const int *dividers, unsigned char *const *outs, const PngSink *png,
+                            int first, int n_frames, int step, size_t *need)
+{
+    *need = 0;
+    for (int i = first; i < n_frames; i += step) {
+        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
+        const double st = strengths ? strengths[i] : 0.0;
+        if (st != 0 && !dividers) return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+        if (int rc = check_bloom_args(cfgs[i].width, st, st != 0 ? dividers[i] : 1)) return rc;
+        if (png) {
+            if (int rc = check_png_frame(cfgs[i].width, cfgs[i].height)) return rc;
+            if (png->caps[i] < bs::png_file_bound(cfgs[i].width, cfgs[i].height))
+                return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
+        }
+        *need = std::max(*need, (size_t)cfgs[i].width * cfgs[i].height * 3);
+    }
+    return BS_OK;
+}
+
+// The PNG files of a batch in flight: frame `frame` was encoded into slot k (its scratch, its size word), into the caller's page-locked
+// buffer or -- staged -- into the slot's device copy of the file.  retire() is called once everything enqueued for the slot has
+// finished: it reports the size and, for a staged file, copies exactly its bytes (a copy of unknown length cannot be enqueued ahead).
+struct PngSlots {
+    int frame[bs_ctx::kPngSlots] = {-1, -1, -1};
+    bool staged[bs_ctx::kPngSlots] = {false, false, false};
+
+    int enqueue(bs_ctx *ctx, int k, int i, const unsigned char *d_u8, const bs_config &cfg, unsigned char *out, hipStream_t s)
+    {
+        bool straddles = false;
+        double *alias = device_alias_of_pinned(ctx, out, (size_t)bs::png_file_bound(cfg.width, cfg.height), &straddles);
+        if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        int rc = ensure_png(ctx, k, cfg.width, cfg.height, alias == nullptr);
+        if (rc) return rc;
+        uint64_t *d_bytes = png_bytes_slot(ctx, k);
+        if (!d_bytes) return fail(BS_EDEVICE, "hipHostGetDevicePointer failed");
+        unsigned char *target = alias ? reinterpret_cast<unsigned char *>(alias) : ctx->d_png_file[k];
+        if (bs::launch_png_encode(d_u8, cfg.width, cfg.height, ctx->d_png_scratch[k], target, d_bytes, s)) return fail(BS_EDEVICE, "PNG encoder launch failed");
+        frame[k] = i;
+        staged[k] = alias == nullptr;
+        return BS_OK;
+    }
+
+    int retire(bs_ctx *ctx, int k, unsigned char *const *outs, const PngSink &png, hipStream_t s)
+    {
+        if (frame[k] < 0) return BS_OK;
+        const size_t bytes = (size_t)ctx->h_png_bytes[k];
+        png.sizes[frame[k]] = bytes;
+        if (staged[k]) {
+            HIP_TRY(hipMemcpyAsync(outs[frame[k]], ctx->d_png_file[k], bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        frame[k] = -1;
+        return BS_OK;
+    }
+};
+
 // doRender (app/Main.hs:105-123) for frames first, first+step, ... on one context, two frames in flight: frame k runs render ->
-// bloom -> sRGB8 on compute stream k & 1 with its own f64 image, so frame k+1's trace kernel fills the SIMDs frame k's last
+// bloom -> sRGB8 (-> PNG) on compute stream k & 1 with its own f64 image, so frame k+1's trace kernel fills the SIMDs frame k's last
 // tiles leave (the fixed ~0.25 ms of a launch) and frame k's bloom runs on the CUs the next trace kernel frees
 // first.  The blur scratch is one pair per context: the bloom of frame k+1 is ordered behind frame k's by acquire/release_post.
 static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, unsigned char *const *outs,
-                                        int first, int n_frames, int step)
+                                        int first, int n_frames, int step, const PngSink *png)
 {
     if (first >= n_frames) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     size_t need = 0;
-    for (int i = first; i < n_frames; i += step) {
-        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
-        const double st = strengths ? strengths[i] : 0.0;
-        if (st != 0 && (!dividers || dividers[i] <= 0 || cfgs[i].width / dividers[i] == 0))
-            return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
-        need = std::max(need, (size_t)cfgs[i].width * cfgs[i].height * 3);
-    }
-    auto grow = [&](auto *&buf, size_t &cap, size_t elems) {
-        if (cap >= elems) return true;
-        if (buf) (void)hipFree(buf);
-        buf = nullptr;
-        cap = 0;
-        if (hipMalloc((void **)&buf, elems * sizeof(*buf)) != hipSuccess) return false;
-        cap = elems;
-        return true;
-    };
-    if (!grow(ctx->d_img, ctx->img_cap, need) || !grow(ctx->d_img2, ctx->img2_cap, need) || !grow(ctx->d_u8, ctx->u8_cap, need) ||
-        !grow(ctx->d_u8b, ctx->u8b_cap, need))
+    int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, first, n_frames, step, &need);
+    if (rc) return rc;
+    if (!grow_device(ctx->d_img, ctx->img_cap, need) || !grow_device(ctx->d_img2, ctx->img2_cap, need) || !grow_device(ctx->d_u8, ctx->u8_cap, need) ||
+        !grow_device(ctx->d_u8b, ctx->u8b_cap, need))
         return fail(BS_ENOMEM, "hipMalloc image failed");
-    int rc = ensure_post(ctx, need);
+    rc = ensure_post(ctx, need);
     if (rc) return rc;
     if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     for (hipEvent_t &e : ctx->ev_frame)
@@ -944,35 +1163,38 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
     double *img[2] = {ctx->d_img, ctx->d_img2};
     unsigned char *stage[2] = {ctx->d_u8, ctx->d_u8b};
     hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+    PngSlots files;
     StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
     int k = 0;
     for (int i = first; i < n_frames; i += step, k++) {
         const int b = k & 1;
-        if (k >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
+        if (k >= 2) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
+            if (png && (rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
+        }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
         unsigned char *target = stage[b];
-        bool straddles = false;
-        if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
-        if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        if (!png) {
+            bool straddles = false;
+            if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
+            if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        }
         rc = enqueue_render(ctx, &cfgs[i], img[b], n, cs[b], 0, -1, true, true, /*quiet=*/true);
         if (rc) return rc;
-        const double st = strengths ? strengths[i] : 0.0;
-        if (st != 0) {
-            rc = acquire_post(ctx, cs[b]);
+        rc = enqueue_post_rgb8(ctx, img[b], cfgs[i].width, cfgs[i].height, strengths ? strengths[i] : 0.0, dividers ? dividers[i] : 1, target, ctx->n_cu, cs[b]);
+        if (rc) return rc;
+        if (png) {
+            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], cs[b]);
             if (rc) return rc;
-            if (bs::launch_bloom_srgb8(img[b], target, ctx->d_post[0], ctx->d_post[1], cfgs[i].width, cfgs[i].height, st, dividers[i], ctx->n_cu,
-                                       ctx->d_srgb_table, cs[b]))
-                return fail(BS_EDEVICE, "bloom launch failed");
-            rc = release_post(ctx, cs[b]);
-            if (rc) return rc;
-        } else if (bs::launch_srgb8(img[b], target, n, ctx->d_srgb_table, cs[b])) {
-            return fail(BS_EDEVICE, "srgb8 launch failed");
+        } else if (target == stage[b]) {
+            HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, cs[b]));
         }
-        if (target == stage[b]) HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, cs[b]));
         HIP_TRY(hipEventRecord(ctx->ev_frame[b], cs[b]));
     }
     HIP_TRY(hipStreamSynchronize(cs[0]));
     HIP_TRY(hipStreamSynchronize(cs[1]));
+    for (int b = 0; png && b < 2; b++)
+        if ((rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
     return BS_OK;
 }
 
@@ -1051,31 +1273,17 @@ static bool ensure_partition(bs_ctx *ctx, int post_cus)
 // n_cu of the trace rate.  Mask bit i is CU i / 8 of XCD i % 8 (scripts/cumask_probe.py, profiles/r03_cumask_probe.txt: an XCD
 // without a single bit gets ALL its CUs), so bits [0, post_cus) are post_cus / 8 CUs in every XCD.  Three images in flight.
 static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_config *cfgs, const double *strengths, const int *dividers,
-                                          unsigned char *const *outs, int first, int n_frames, int step)
+                                          unsigned char *const *outs, int first, int n_frames, int step, const PngSink *png)
 {
     if (first >= n_frames) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     size_t need = 0;
-    for (int i = first; i < n_frames; i += step) {
-        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
-        const double st = strengths ? strengths[i] : 0.0;
-        if (st != 0 && (!dividers || dividers[i] <= 0 || cfgs[i].width / dividers[i] == 0))
-            return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
-        need = std::max(need, (size_t)cfgs[i].width * cfgs[i].height * 3);
-    }
-    auto grow = [&](auto *&buf, size_t &cap, size_t elems) {
-        if (cap >= elems) return true;
-        if (buf) (void)hipFree(buf);
-        buf = nullptr;
-        cap = 0;
-        if (hipMalloc((void **)&buf, elems * sizeof(*buf)) != hipSuccess) return false;
-        cap = elems;
-        return true;
-    };
-    if (!grow(ctx->d_img, ctx->img_cap, need) || !grow(ctx->d_img2, ctx->img2_cap, need) || !grow(ctx->d_img3, ctx->img3_cap, need) ||
-        !grow(ctx->d_u8, ctx->u8_cap, need) || !grow(ctx->d_u8b, ctx->u8b_cap, need) || !grow(ctx->d_u8c, ctx->u8c_cap, need))
+    int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, first, n_frames, step, &need);
+    if (rc) return rc;
+    if (!grow_device(ctx->d_img, ctx->img_cap, need) || !grow_device(ctx->d_img2, ctx->img2_cap, need) || !grow_device(ctx->d_img3, ctx->img3_cap, need) ||
+        !grow_device(ctx->d_u8, ctx->u8_cap, need) || !grow_device(ctx->d_u8b, ctx->u8b_cap, need) || !grow_device(ctx->d_u8c, ctx->u8c_cap, need))
         return fail(BS_ENOMEM, "hipMalloc image failed");
-    int rc = ensure_post(ctx, need);
+    rc = ensure_post(ctx, need);
     if (rc) return rc;
     bs_ctx::Partition &pt = ctx->parts[post_cus / 8 - 1];  // streams made by ensure_partition
     for (hipEvent_t &e : ctx->ev_traced)
@@ -1090,17 +1298,24 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         LaunchCus(bs_ctx *c_, int n) : c(c_) { c->launch_cus = n; }
         ~LaunchCus() { c->launch_cus = 0; }
     } cus(ctx, ctx->n_cu - post_cus);
+    PngSlots files;
+    hipStream_t posted_on[3] = {pt.post, pt.post, pt.post};
     StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
     int k = 0;
     for (int i = first; i < n_frames; i += step, k++) {
         const int b = k % 3;
         hipStream_t ts = pt.trace[k & 1];
-        if (k >= 3) HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));  // frame k-3 (same image, same staging) has left the device
+        if (k >= 3) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));  // frame k-3 (same image, same staging) has left the device
+            if (png && (rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
+        }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
         unsigned char *target = stage[b];
-        bool straddles = false;
-        if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);
-        if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        if (!png) {
+            bool straddles = false;
+            if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);
+            if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        }
         rc = enqueue_render(ctx, &cfgs[i], img[b], n, ts, 0, -1, true, true, /*quiet=*/true);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ctx->ev_traced[b], ts));
@@ -1108,26 +1323,25 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         // planned for all CUs: 0.2 instead of 3.8 ms for a 1080p frame -- on a 20-frame batch that tail alone was 0.19 ms per frame).
         const bool last = i + step >= n_frames;
         hipStream_t ps = last ? ctx->stream : pt.post;
+        posted_on[b] = ps;
         HIP_TRY(hipStreamWaitEvent(ps, ctx->ev_traced[b], 0));
-        const double st = strengths ? strengths[i] : 0.0;
-        if (st != 0) {
-            rc = acquire_post(ctx, ps);
+        rc = enqueue_post_rgb8(ctx, img[b], cfgs[i].width, cfgs[i].height, strengths ? strengths[i] : 0.0, dividers ? dividers[i] : 1, target,
+                               last ? ctx->n_cu : plan_cus, ps);
+        if (rc) return rc;
+        if (png) {
+            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], ps);
             if (rc) return rc;
-            if (bs::launch_bloom_srgb8(img[b], target, ctx->d_post[0], ctx->d_post[1], cfgs[i].width, cfgs[i].height, st, dividers[i],
-                                       last ? ctx->n_cu : plan_cus, ctx->d_srgb_table, ps))
-                return fail(BS_EDEVICE, "bloom launch failed");
-            rc = release_post(ctx, ps);
-            if (rc) return rc;
-        } else if (bs::launch_srgb8(img[b], target, n, ctx->d_srgb_table, ps)) {
-            return fail(BS_EDEVICE, "srgb8 launch failed");
+        } else if (target == stage[b]) {
+            HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, ps));
         }
-        if (target == stage[b]) HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, ps));
         HIP_TRY(hipEventRecord(ctx->ev_posted[b], ps));
     }
     HIP_TRY(hipStreamSynchronize(pt.trace[0]));
     HIP_TRY(hipStreamSynchronize(pt.trace[1]));
     HIP_TRY(hipStreamSynchronize(pt.post));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; png && b < 3; b++)
+        if ((rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
     return BS_OK;
 }
 
@@ -1143,8 +1357,9 @@ int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_div
     return 0;
 }
 
-int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
-                         unsigned char *const *outs)
+// bs_render_rgb8_batch / bs_render_png_batch: one host thread per context, frame i on context i % n_ctx.
+static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                             unsigned char *const *outs, const PngSink *png)
 {
     if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
@@ -1154,19 +1369,21 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
     for (int c = 0; c < n_ctx; c++) {
         th.emplace_back([&, c]() {
             bs_ctx *x = ctxs[c];
-            int post_cus = choose_post_cus(x, cfgs, bloom_strengths, bloom_dividers, c, n_frames, n_ctx);
+            // PNG batches take the partition only when BLACKSTAR_POST_CUS forces one: the cost model behind the automatic choice
+            // (post_cus_for_frame) knows bloom + sRGB8, not the encoder's kernels
+            int post_cus = png && x->post_cus_req <= 0 ? 0 : choose_post_cus(x, cfgs, bloom_strengths, bloom_dividers, c, n_frames, n_ctx);
             // Only with page-locked outputs, which the last kernel of a frame writes itself: a copy into PAGEABLE memory blocks the
             // host thread until the frame's post stage has finished -- 3.8 ms on 8 CUs instead of 0.2 ms on the whole chip -- and the
             // next trace kernel is not enqueued meanwhile (measured 9.1 against 4.8 ms per frame: scripts/post_partition_pageable_ab.py)
             for (int i = c; post_cus && i < n_frames; i += n_ctx) {
                 if (!outs[i] || cfgs[i].width <= 0 || cfgs[i].height <= 0 || hipSetDevice(x->device) != hipSuccess ||
-                    !device_alias_of_pinned(x, outs[i], (size_t)cfgs[i].width * cfgs[i].height * 3))
+                    !device_alias_of_pinned(x, outs[i], png ? (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height) : (size_t)cfgs[i].width * cfgs[i].height * 3))
                     post_cus = 0;
             }
             if (post_cus && !ensure_partition(x, post_cus)) post_cus = 0;
             x->last_post_cus = post_cus;
-            rcs[c] = post_cus ? render_rgb8_frames_partitioned(x, post_cus, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx)
-                              : render_rgb8_frames_pipelined(x, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx);
+            rcs[c] = post_cus ? render_rgb8_frames_partitioned(x, post_cus, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx, png)
+                              : render_rgb8_frames_pipelined(x, cfgs, bloom_strengths, bloom_dividers, outs, c, n_frames, n_ctx, png);
             if (rcs[c]) errs[c] = g_err;
         });
     }
@@ -1174,6 +1391,20 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
+}
+
+int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                         unsigned char *const *outs)
+{
+    return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, nullptr);
+}
+
+int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                        unsigned char *const *outs, const size_t *caps, size_t *out_bytes)
+{
+    if (n_frames > 0 && (!caps || !out_bytes)) return fail(BS_EINVAL, "null argument");
+    const PngSink sink{caps, out_bytes};
+    return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, &sink);
 }
 
 int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)

@@ -113,6 +113,10 @@ int launch_bloom_srgb8(const double *d_in, unsigned char *d_out_u8, double *d_a,
 double estimate_post_us(int w, int h, int divider, int cus);
 int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *stream);
 int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, const double *d_table, void *stream);
+// png_kernels.hip: writeImg's file format on the device (algorithm: png_block.h)
+uint64_t png_file_bound(int w, int h);   // bytes a w x h RGB8 frame can take at most as a file of this encoder
+size_t png_scratch_bytes(int w, int h);  // device scratch one encode needs
+int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream);
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
 int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);
 

@@ -30,10 +30,12 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
+/* 3 (round 3): the PNG entry points (bs_png_bound, bs_encode_png[_device], bs_render_png[_batch]) -- additions only, every
+ * struct and every version-2 signature is unchanged.
+ * 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
  * non-finite fields, stepSize <= 0, negative radii, lookAt within 1e-6 of position).  1: rounds 1-2.  A binding should compare
  * bs_abi_version() with the BS_ABI_VERSION it was written against before anything else. */
-#define BS_ABI_VERSION 2
+#define BS_ABI_VERSION 3
 
 enum {
     BS_OK = 0,
@@ -205,6 +207,32 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
  * (bs_host_alloc) are written by the last kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame either way; bs_stats is not updated. */
 int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                          const int *bloom_dividers, unsigned char *const *outs);
+
+/* ---- writeImg's FILE on the device (src/Raytracer.hs:30-32: `writeImage path`; app/Main.hs:119-123) ----
+ * The reference hands the RGB8 image to massiv-io's writeImage, i.e. JuicyPixels' PNG encoder over zlib: 0.1-0.25 s of one host core per
+ * 1080p frame, 25-60x what this library needs to render it.  These entry points produce the finished PNG FILE on the device (filter
+ * choice, deflate with per-block dynamic Huffman codes, CRCs, Adler-32: blackstar_amd/csrc/png_block.h), so a frame crosses PCIe as
+ * about 1 MB of file and the caller only has to write(2) it.  What the format guarantees is the DECODED image: every file decodes
+ * (zlib, libpng, Pillow) to exactly the RGB8 frame bs_render_rgb8 returns; its bytes differ from JuicyPixels' like any two zlib versions'.
+ * Files are 5-15 % larger than zlib level 6 on rendered frames (distance-1 matches only), never larger than bs_png_bound. */
+
+/* Bytes a width x height RGB8 frame needs at most as a PNG file of this encoder (about 0.2 % above the pixels): the capacity every
+ * out_png / d_png buffer below must have.  BS_EINVAL for non-positive sizes and frames above 1e9 pixels / files of 4 GiB. */
+int bs_png_bound(int width, int height, size_t *out_bytes);
+/* Enqueue-only: d_rgb8 (height*width*3 bytes, device) -> the file in d_png (cap >= bs_png_bound; device memory or a page-locked host
+ * buffer's device alias), its size in *d_file_bytes (one 8-byte-aligned uint64, same choice), both valid once the stream has passed. */
+int bs_encode_png_device(bs_ctx *ctx, const void *d_rgb8, int width, int height, void *d_png, size_t cap, void *d_file_bytes, void *hip_stream);
+/* Host buffers, blocking: the parity hook of the encoder alone (rgb8 -> file).  A page-locked out_png is written by the GPU itself. */
+int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned char *out_png, size_t cap, size_t *out_bytes);
+/* Replaces: the whole of doRender (app/Main.hs:105-123) except the write(2): render, bloom when bloom_strength != 0, writeImg's pixel
+ * map and file format.  Blocking; *out_bytes bytes of out_png are the file.  Decodes to bs_render_rgb8's bytes. */
+int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_png, size_t cap, size_t *out_bytes);
+/* bs_render_rgb8_batch with files instead of pixels: outs[i] (capacity caps[i] >= bs_png_bound of frame i) receives frame i's PNG file,
+ * out_bytes[i] its size.  Two frames in flight per context, the encoder of frame k running under the trace kernel of frame k+1;
+ * page-locked outs[i] are written by the encoder itself (only the file's bytes cross PCIe).  The chip is partitioned only on request
+ * (BLACKSTAR_POST_CUS=8|16|24|32).  Blocking; bs_stats is not updated. */
+int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
+                        const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
 
 /* Test hook, host-only: how many CUs bs_render_rgb8_batch would set aside for the post stage of a batch made of this frame on a chip
  * of n_cu CUs in the given BS_MODE_* (0 = none: the post stage shares the chip with the trace kernels).  See bs_render_rgb8_batch. */

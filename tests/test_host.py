@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L, sym), f"{sym} declared in include/blackstar_gpu.h but not exported"
     assert set(_lib.SYMBOLS) <= declared
-    assert L.bs_abi_version() == _lib.BS_ABI_VERSION == 2
+    assert L.bs_abi_version() == _lib.BS_ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header():

@@ -1,0 +1,246 @@
+"""The device PNG encoder (blackstar_amd/csrc/png_block.h + png_kernels.hip; writeImg's file format, src/Raytracer.hs:30-32).
+
+CPU tests run the encoder's phase program lane by lane on the host (tests/cpp/png_emul.cpp: the same functions the GPU kernel calls) and
+check its files with zlib, a by-hand chunk reader and Pillow.  GPU tests check that the HIP kernels produce the SAME BYTES as that
+emulation and that the render -> file entry points decode to bs_render_rgb8's pixels."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import png_emul
+from tests.conftest import load_golden
+
+RNG = np.random.default_rng(20260927)
+SCENES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
+
+
+def scene(name, w, h, bloom=None):
+    import blackstar_amd as bs
+    c = bs.Config.from_file(os.path.join(SCENES, name + ".yaml")).with_resolution(w, h)
+    if bloom is not None:
+        c.scene.bloomStrength = bloom
+    return c
+
+
+def frame_like(h, w, seed=0):
+    """Something shaped like a rendered frame: a dark sky with a few blurred stars, a bright smooth disk, 8-bit quantised."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w, 3))
+    for _ in range(max(3, h * w // 4000)):
+        cy, cx, s = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(0.6, 2.5)
+        img += np.exp(-((y - cy) ** 2 + (x - cx) ** 2) / (2 * s * s))[..., None] * rng.uniform(0.2, 1.0, 3)
+    r = np.hypot((y - h / 2) / (h / 5 + 1), (x - w / 2) / (w / 3 + 1))
+    img += (np.clip(1.2 - np.abs(r - 1.0) * 3, 0, 1) ** 2)[..., None] * np.array([1.0, 0.8, 0.5])
+    return np.rint(255 * np.clip(img, 0, 1)).astype(np.uint8)
+
+
+def cases():
+    yield "1x1", np.full((1, 1, 3), 200, np.uint8)
+    yield "black 5x7", np.zeros((5, 7, 3), np.uint8)
+    yield "white 100x3000", np.full((100, 3000, 3), 255, np.uint8)
+    yield "noise 40x33 (stored blocks)", RNG.integers(0, 256, (40, 33, 3)).astype(np.uint8)
+    yield "width 1", (RNG.integers(0, 2, (300, 1, 3)) * 255).astype(np.uint8)
+    yield "height 1", RNG.integers(0, 4, (1, 5000, 3)).astype(np.uint8)
+    yield "stream = exactly 2 blocks (4 x 1365)", frame_like(4, 1365, 1)
+    yield "stream = 2 blocks + 1 byte", np.concatenate([frame_like(4, 1365, 1).reshape(-1), [7, 7, 7]]).astype(np.uint8)[:4 * 1365 * 3].reshape(4, 1365, 3)
+    yield "frame-like 270x480", frame_like(270, 480, 2)
+    yield "frame-like odd 37x23", frame_like(37, 23, 3)
+    yield "two values, long runs", np.repeat(RNG.integers(0, 2, (64, 20, 3)) * 255, 40, axis=1).astype(np.uint8)
+    yield "every byte value", np.arange(256 * 3 * 4, dtype=np.uint32).astype(np.uint8).reshape(4, 256, 3)
+    g = load_golden("image_c3_default_aa_96x54") if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "image_c3_default_aa_96x54.npz")) else None
+    if g is not None:
+        v = np.clip(g["img"], 0, 1)
+        yield "golden c3 96x54 (sRGB8 on the host)", np.rint(255 * np.where(v < 0.0031308, 12.92 * v, 1.055 * v ** (1 / 2.4) - 0.055)).astype(np.uint8)
+
+
+CASES = list(cases())
+
+
+@pytest.mark.parametrize("name,img", CASES, ids=[c[0] for c in CASES])
+def test_emulated_encoder_writes_valid_png(name, img):
+    data, stats, filt = png_emul.encode(img)
+    facts = png_emul.check_file(data, img)
+    assert len(data) <= png_emul.bound(*img.shape[:2])
+    assert facts["idat_chunks"] == stats[0] + 2                      # one per block + the zlib header's + the final block's
+    assert np.array_equal(np.bincount(filt, minlength=5), facts["filters"])
+    for order in (1, 2, 3):  # lanes of a phase run concurrently on the GPU: the order they run in here must not matter
+        assert png_emul.encode(img, order)[0] == data, f"lane order {order} changes the file"
+
+
+def test_emulated_encoder_compresses_like_zlib_on_frames():
+    """Ratio is not the point of this encoder (distance-1 matches only, a code table per 8 KiB), but it must stay in zlib's neighbourhood
+    on what the renderer produces: at most 15 % above libpng + zlib level 1 and 70 % above level 6 on a frame-like image (a frame the
+    oracle rendered at 960x540 came out 13 % above level 6, 5 % above level 1), and far below the pixels on a black one."""
+    import io
+
+    from PIL import Image
+    img = frame_like(540, 960, 5)
+    data, stats, _ = png_emul.encode(img)
+    png_emul.check_file(data, img)
+    ref = {}
+    for level in (1, 6):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, format="PNG", compress_level=level)
+        ref[level] = len(b.getvalue())
+    assert stats[1] == 0 and len(data) < 1.15 * ref[1] and len(data) < 1.7 * ref[6], (len(data), ref)
+    black = np.zeros((540, 960, 3), np.uint8)
+    assert len(png_emul.encode(black)[0]) < black.size / 60
+
+
+def test_noise_falls_back_to_stored_blocks_within_bound():
+    img = RNG.integers(0, 256, (128, 256, 3)).astype(np.uint8)
+    data, stats, _ = png_emul.encode(img)
+    png_emul.check_file(data, img)
+    assert stats[1] == stats[0] and len(data) <= png_emul.bound(128, 256)
+
+
+def test_crc_pieces_match_zlib():
+    L = png_emul.lib()
+    for n in (0, 1, 3, 4, 63, 64, 65, 4097, 8209):
+        a = RNG.integers(0, 256, n).astype(np.uint8)
+        assert L.png_emul_crc(a.ctypes.data, n) == zlib.crc32(a.tobytes()) & 0xFFFFFFFF
+        for m in (0, 1, 7, 128, 5000):
+            b = RNG.integers(0, 256, m).astype(np.uint8)
+            got = L.png_emul_crc_combine(zlib.crc32(a.tobytes()), zlib.crc32(b.tobytes()), m)
+            assert got == zlib.crc32(a.tobytes() + b.tobytes()) & 0xFFFFFFFF, (n, m)
+
+
+def test_python_bound_is_the_encoders():
+    import blackstar_amd as bs
+    for h, w in ((1, 1), (54, 96), (1080, 1920), (2160, 3840), (7, 10000)):
+        assert bs.png_bound(h, w) == png_emul.bound(h, w)
+    with pytest.raises(bs._lib.BlackstarError):
+        bs.png_bound(0, 10)
+    with pytest.raises(bs._lib.BlackstarError):
+        bs.png_bound(100000, 100000)
+
+
+# ---- on the GPU ------------------------------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def tree(catalogue_bytes):
+    import blackstar_amd as bs
+    t = bs.StarTree(bs.read_map(catalogue_bytes))
+    yield t
+    t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,img", CASES, ids=[c[0] for c in CASES])
+def test_gpu_encoder_writes_the_emulations_bytes(tree, name, img):
+    """bs_encode_png: byte for byte the file of the host emulation (same phase functions), into pageable and into page-locked memory."""
+    import blackstar_amd as bs
+    want = png_emul.encode(img)[0]
+    got = bytes(bs.encode_png(img, tree))
+    assert got == want
+    assert tree.stats()["zero_copy"] == 0
+    buf = bs.alloc_png(tree, *img.shape[:2])
+    assert bytes(bs.encode_png(img, tree, out=buf)) == want
+    assert tree.stats()["zero_copy"] == 1
+    png_emul.check_file(got, img)
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_full_size_frames(tree):
+    """BASELINE-sized frames: 1080p and 4K frame-like images decode to themselves; the 1080p file equals the emulation's; timing printed."""
+    import time
+
+    import blackstar_amd as bs
+    small = frame_like(270, 480, 7)
+    for scale, emulate in ((4, True), (8, False)):
+        img = np.ascontiguousarray(np.kron(small, np.ones((scale, scale, 1), np.uint8)))
+        img[::3, ::5] ^= (RNG.integers(0, 4, img[::3, ::5].shape)).astype(np.uint8)   # some texture, so that not every block is runs
+        buf = bs.alloc_png(tree, *img.shape[:2])
+        data = bytes(bs.encode_png(img, tree, out=buf))
+        t0 = time.perf_counter()
+        for _ in range(5):
+            bs.encode_png(img, tree, out=buf)
+        dt = (time.perf_counter() - t0) / 5
+        png_emul.check_file(data, img)
+        if emulate:
+            assert data == png_emul.encode(img)[0]
+        print(f"bs_encode_png {img.shape[1]}x{img.shape[0]}: {len(data)} bytes ({img.size / len(data):.1f}x), {dt * 1e3:.2f} ms per call incl. H2D of the pixels")
+
+
+@pytest.mark.gpu
+def test_render_png_decodes_to_render_rgb8(tree):
+    """bs_render_png = doRender to the end (app/Main.hs:105-123): its file decodes to exactly bs_render_rgb8's pixels -- with and without
+    bloom, odd sizes, pageable and page-locked file buffers."""
+    import io
+
+    from PIL import Image
+
+    import blackstar_amd as bs
+    for name, w, h, strength in (("default-aa", 192, 108, 0.4), ("default", 160, 90, 0.0), ("lensing-disk", 97, 61, 0.25)):
+        cfg = scene(name, w, h, strength)
+        want = bs.render_rgb8(cfg, tree)
+        for out in (None, bs.alloc_png(tree, h, w)):
+            data = bytes(bs.render_png(cfg, tree, out=out))
+            assert np.array_equal(np.array(Image.open(io.BytesIO(data)).convert("RGB")), want)
+            png_emul.check_file(data, want)
+            assert data == png_emul.encode(want)[0]
+
+
+@pytest.mark.gpu
+def test_render_png_batch_equals_frame_by_frame(tree):
+    """bs_render_png_batch (two frames in flight, the encoder of one frame under the trace kernel of the next): every file is the file
+    bs_render_png writes for that frame; mixed sizes, bloom on and off, pageable and page-locked buffers mixed; also on two contexts
+    and with the chip partitioned on request."""
+    import blackstar_amd as bs
+    cfgs = []
+    for k in range(7):
+        name, w, h = (("default-aa", 160, 90), ("lensing-disk", 120, 68), ("default", 96, 54))[k % 3]
+        c = scene(name, w, h, 0.0 if k == 2 else 0.3)
+        c.camera.position = (c.camera.position[0], c.camera.position[1] + 0.05 * k, c.camera.position[2])
+        cfgs.append(c)
+    want = [bytes(bs.render_png(c, tree)) for c in cfgs]
+    outs = [bs.alloc_png(tree, c.scene.resolution[1], c.scene.resolution[0]) if k % 2 == 0 else np.empty(bs.png_bound(c.scene.resolution[1], c.scene.resolution[0]), np.uint8)
+            for k, c in enumerate(cfgs)]
+    got = bs.render_png_batch(cfgs, [tree], outs=outs)
+    assert [bytes(g) for g in got] == want
+    pinned = [bs.alloc_png(tree, c.scene.resolution[1], c.scene.resolution[0]) for c in cfgs]
+    assert [bytes(g) for g in bs.render_png_batch(cfgs, [tree], outs=pinned)] == want
+    t2 = bs.StarTree(tree.stars)
+    try:
+        assert [bytes(g) for g in bs.render_png_batch(cfgs, [tree, t2])] == want
+        os.environ["BLACKSTAR_POST_CUS"] = "16"   # read at bs_create: this context partitions the chip for every batch
+        t3 = bs.StarTree(tree.stars)
+        del os.environ["BLACKSTAR_POST_CUS"]
+        try:
+            pinned3 = [bs.alloc_png(t3, c.scene.resolution[1], c.scene.resolution[0]) for c in cfgs]
+            assert [bytes(g) for g in bs.render_png_batch(cfgs, [t3], outs=pinned3)] == want
+            assert bs._lib.lib().bs_debug_last_post_cus(t3.handle) == 16
+        finally:
+            t3.close()
+    finally:
+        os.environ.pop("BLACKSTAR_POST_CUS", None)
+        t2.close()
+    assert bs.render_png_batch([], [tree]) == []
+    with pytest.raises(bs._lib.BlackstarError, match="too small"):
+        bs.render_png_batch(cfgs[:1], [tree], outs=[np.empty(100, np.uint8)])
+    assert [bytes(g) for g in bs.render_png_batch(cfgs, [tree])] == want   # the context is usable after the refusal
+
+
+@pytest.mark.gpu
+def test_encode_png_device_is_enqueue_only(tree):
+    """bs_encode_png_device on torch tensors and a torch stream: the file and its size appear once the stream has passed."""
+    import torch
+
+    import blackstar_amd as bs
+    from blackstar_amd import _lib
+    img = frame_like(120, 200, 11)
+    d_img = torch.from_numpy(img).cuda()
+    d_png = torch.zeros(bs.png_bound(120, 200), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.Stream()
+    for _ in range(3):   # back to back on one stream, and once more on another: the context's scratch is handed over in order
+        _lib.check(_lib.lib().bs_encode_png_device(tree.handle, d_img.data_ptr(), 200, 120, d_png.data_ptr(), d_png.numel(), d_n.data_ptr(), s.cuda_stream), "bs_encode_png_device")
+    s.synchronize()
+    want = png_emul.encode(img)[0]
+    assert int(d_n.item()) == len(want) and bytes(d_png[:len(want)].cpu().numpy()) == want
+    rc = _lib.lib().bs_encode_png_device(tree.handle, d_img.data_ptr(), 200, 120, d_png.data_ptr(), 1000, d_n.data_ptr(), s.cuda_stream)
+    assert rc == -1 and "too small" in _lib.last_error()   # BS_EINVAL
