@@ -837,6 +837,35 @@ int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height,
     return png_to_host(ctx, ctx->d_u8, width, height, out_png, out_bytes);
 }
 
+int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned long long *clocks, size_t n_clocks)
+{
+    if (!ctx || !rgb8 || !clocks) return fail(BS_EINVAL, "null argument");
+    if (int rc = check_png_frame(width, height)) return rc;
+    const size_t nb = bs::png_block_count(width, height);
+    if (n_clocks < nb * bs::kPngPhases) return fail(BS_EINVAL, "clocks: blocks * 21 entries are required (blocks = ceil(height * (3 width + 1) / 8192))");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)width * height * 3;
+    if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
+    int rc = ensure_png(ctx, 0, width, height, true);
+    if (rc) return rc;
+    rc = ensure_scratch(ctx, nb * bs::kPngPhases * sizeof(unsigned long long));
+    if (rc) return rc;
+    uint64_t *d_bytes = png_bytes_slot(ctx, 0);
+    if (!d_bytes) return fail(BS_EDEVICE, "hipHostGetDevicePointer failed");
+    StreamDrain drain(ctx);
+    HIP_TRY(hipMemcpyAsync(ctx->d_u8, rgb8, n, hipMemcpyHostToDevice, ctx->stream));
+    rc = acquire_png(ctx, ctx->stream);
+    if (rc) return rc;
+    if (bs::launch_png_encode(ctx->d_u8, width, height, ctx->d_png_scratch[0], ctx->d_png_file[0], d_bytes, ctx->stream,
+                              static_cast<unsigned long long *>(ctx->d_scratch)))
+        return fail(BS_EDEVICE, "PNG encoder launch failed");
+    rc = release_png(ctx, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(clocks, ctx->d_scratch, nb * bs::kPngPhases * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BS_OK;
+}
+
 int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_png, size_t cap, size_t *out_bytes)
 {
     if (!ctx || !cfg || !out_png || !out_bytes) return fail(BS_EINVAL, "null argument");
@@ -1209,14 +1238,21 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 // M of {8, 16} is taken for which, on EVERY frame of the share, (a) the post stage ALONE on M CUs needs at most 86 % of the trace time on the
 // rest (next to the trace kernels it runs ~20 % slower than alone: 720p on 8 CUs 1.80 ms alone, 2.25 in the pipeline) and (b) the
 // partitioned frame time undercuts the shared one by 2 %.  BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
-static int post_cus_for_frame(const bs_config &cfg, double strength, int divider, int n_cu, bool fast, int m)
+// png: the post stage also makes the frame's PNG file (bs_render_png_batch; bs::estimate_png_us): the C3 frame then needs M = 16 --
+// measured 4.44 ms per frame against 4.77 on the shared chip and 7.4 with M = 8 (scripts/png_probe.py, profiles/r03_png_probe.json).
+static int post_cus_for_frame(const bs_config &cfg, double strength, int divider, int n_cu, bool fast, int m, bool png)
 {
     bs::TraceParams p;
     std::memset(&p, 0, sizeof p);
     std::string err;
-    if (strength == 0 || !bs::derive_params(cfg, p, err)) return 0;
-    const double post_m = bs::estimate_post_us(cfg.width, cfg.height, divider, m);
-    const double post_all = bs::estimate_post_us(cfg.width, cfg.height, divider, n_cu);
+    if ((strength == 0 && !png) || !bs::derive_params(cfg, p, err)) return 0;
+    // (without bloom the pixel map alone: about 30 us on the chip, 60 on a slice of it)
+    double post_m = strength != 0 ? bs::estimate_post_us(cfg.width, cfg.height, divider, m) : 60.0;
+    double post_all = strength != 0 ? bs::estimate_post_us(cfg.width, cfg.height, divider, n_cu) : 30.0;
+    if (png && post_m > 0 && post_all > 0) {
+        post_m += bs::estimate_png_us(cfg.width, cfg.height, m);
+        post_all += bs::estimate_png_us(cfg.width, cfg.height, n_cu);
+    }
     const double steps = (p.rcam + std::sqrt(p.safe)) / p.h;  // the longest straight path through the scene, in steps
     const double rate = 4.5e11 * n_cu / 256.0 / (fast ? 1.0 : 2.4);
     const double trace_all = (double)p.wt * p.ht * steps / rate * 1e6;
@@ -1225,15 +1261,18 @@ static int post_cus_for_frame(const bs_config &cfg, double strength, int divider
     return post_m > 0 && post_all > 0 && post_m <= 0.86 * trace_m && 1.03 * trace_m < 0.98 * (trace_all + post_all + 330.0) ? m : 0;
 }
 
-static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, int first, int n_frames, int step)
+static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, int first, int n_frames, int step, bool png)
 {
     if (ctx->post_cus_req == 0 || ctx->n_cu < 128 || ctx->n_cu % 8 != 0) return 0;
     if (ctx->post_cus_req > 0) return ctx->post_cus_req;
     if (first + 2 * step >= n_frames) return 0;  // fewer than three frames for this context: nothing to hide the post stage behind (1 frame: 5.38 against 5.22 ms)
-    for (int m : {8, 16}) {
-        bool ok = dividers != nullptr;
-        for (int i = first; ok && i < n_frames; i += step)
-            ok = post_cus_for_frame(cfgs[i], strengths ? strengths[i] : 0.0, dividers[i], ctx->n_cu, effective_mode(ctx, &cfgs[i]) == BS_MODE_FAST, m) == m;
+    for (int m : {8, 16, 24}) {
+        bool ok = true;
+        for (int i = first; ok && i < n_frames; i += step) {
+            const double st = strengths ? strengths[i] : 0.0;
+            ok = (st == 0 || dividers) &&
+                 post_cus_for_frame(cfgs[i], st, st != 0 ? dividers[i] : 1, ctx->n_cu, effective_mode(ctx, &cfgs[i]) == BS_MODE_FAST, m, png) == m;
+        }
         if (ok) return m;
     }
     return 0;
@@ -1351,9 +1390,11 @@ int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_div
 {
     if (!cfg || n_cu < 1) return fail(BS_EINVAL, "bad argument");
     if (n_cu < 128 || n_cu % 8 != 0) return 0;
+    const bool png = (mode & BS_DEBUG_POST_CUS_PNG) != 0;
+    mode &= ~BS_DEBUG_POST_CUS_PNG;
     const bool fast = mode == BS_MODE_FAST && cfg->step_size <= 0.5;
-    for (int m : {8, 16})
-        if (post_cus_for_frame(*cfg, bloom_strength, bloom_divider, n_cu, fast, m) == m) return m;
+    for (int m : {8, 16, 24})
+        if (post_cus_for_frame(*cfg, bloom_strength, bloom_divider, n_cu, fast, m, png) == m) return m;
     return 0;
 }
 
@@ -1369,9 +1410,7 @@ static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cf
     for (int c = 0; c < n_ctx; c++) {
         th.emplace_back([&, c]() {
             bs_ctx *x = ctxs[c];
-            // PNG batches take the partition only when BLACKSTAR_POST_CUS forces one: the cost model behind the automatic choice
-            // (post_cus_for_frame) knows bloom + sRGB8, not the encoder's kernels
-            int post_cus = png && x->post_cus_req <= 0 ? 0 : choose_post_cus(x, cfgs, bloom_strengths, bloom_dividers, c, n_frames, n_ctx);
+            int post_cus = choose_post_cus(x, cfgs, bloom_strengths, bloom_dividers, c, n_frames, n_ctx, png != nullptr);
             // Only with page-locked outputs, which the last kernel of a frame writes itself: a copy into PAGEABLE memory blocks the
             // host thread until the frame's post stage has finished -- 3.8 ms on 8 CUs instead of 0.2 ms on the whole chip -- and the
             // next trace kernel is not enqueued meanwhile (measured 9.1 against 4.8 ms per frame: scripts/post_partition_pageable_ab.py)

@@ -116,7 +116,11 @@ int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, const doubl
 // png_kernels.hip: writeImg's file format on the device (algorithm: png_block.h)
 uint64_t png_file_bound(int w, int h);   // bytes a w x h RGB8 frame can take at most as a file of this encoder
 size_t png_scratch_bytes(int w, int h);  // device scratch one encode needs
-int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream);
+double estimate_png_us(int w, int h, int cus);  // microseconds the encoder's kernels take on `cus` CUs (model; < 0: no estimate)
+size_t png_block_count(int w, int h);     // 8 KiB blocks of the filtered stream = workgroups of the encoding kernel
+constexpr int kPngPhases = 21;            // clock stamps per block of the profiling variant: before the first phase, after each of the 20
+int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream,
+                      unsigned long long *d_clocks = nullptr);
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
 int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);
 

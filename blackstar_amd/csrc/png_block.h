@@ -1,24 +1,29 @@
 // png_block.h -- the PNG encoder of writeImg (src/Raytracer.hs:23-32: writeImage of the sRGB8 frame) as a PROGRAM OF
-// PHASES for one 64-lane wavefront per 8 KiB of filtered scanline bytes.  The phases are plain functions of (lane, block state, args);
-// png_kernels.hip runs them with a workgroup barrier between consecutive phases, tests/cpp/png_emul.cpp runs the same functions lane by
-// lane on the host (forwards, backwards and shuffled: a phase must not depend on what another lane wrote IN THE SAME PHASE), so the
-// byte stream the GPU produces is pinned on the CPU by zlib / Pillow decoders before it ever runs on a device.
+// PHASES for one 256-thread workgroup (four wavefronts) per 8 KiB of filtered scanline bytes.  The phases are plain functions of
+// (lane, block state, args); png_kernels.hip runs them with a workgroup barrier between consecutive phases, tests/cpp/png_emul.cpp runs
+// the same functions lane by lane on the host (forwards, backwards and shuffled: a phase must not depend on what another lane wrote IN
+// THE SAME PHASE), so the byte stream the GPU produces is pinned on the CPU by zlib / Pillow decoders before it ever runs on a device.
 //
 // The reference hands the frame to massiv-io's writeImage (JuicyPixels' PNG encoder over zlib): what is specified is the DECODED image,
 // not the file's bytes -- those depend on the zlib version.  This encoder therefore only has to be a valid PNG whose pixels are the
 // RGB8 frame, and is built for the GPU instead of for ratio:
-//   * scanline filter per row by the minimum-sum-of-absolute-differences rule (png_filter_cost), computed by its own small kernel;
+//   * scanline filter per row by the minimum-sum-of-absolute-differences rule (filter_cost), computed by its own small kernel;
 //   * the filtered stream is cut into 8 KiB blocks; a block is ONE deflate block with its OWN dynamic Huffman code, closed by an empty
 //     stored block (zlib's Z_SYNC_FLUSH marker) so that it ends on a byte boundary, and travels in its own IDAT chunk -- blocks are
 //     independent: no bit-level concatenation, no cross-block CRC;
 //   * LZ77 is reduced to distance-1 matches (runs of one byte value): after the Sub / Up / Paeth filters a rendered frame is mostly
-//     runs of zeros, and a run needs no hash chains -- every lane tokenises its own 128 bytes serially;
+//     runs of zeros, and a run needs no hash chains -- every lane tokenises its own 32 bytes from registers;
 //   * code lengths: Shannon lengths ceil(log2(N / f)), clamped to the limit, repaired / filled to an exactly complete code in COUNT
-//     space (16 counters, one lane) and handed back to the symbols in frequency order -- the symbol-parallel parts (lengths, ranks,
-//     canonical codes) run on all lanes;
+//     space (16 counters, one lane) and handed back to the symbols in frequency order -- everything per symbol (lengths, ranks,
+//     canonical codes) runs on all lanes;
+//   * the block header codes every code length by itself (no run symbols 16-18): about 25 bytes per block more than zlib's run-length
+//     coded header (0.3 %), and every position of the header can be costed and emitted by its own lane;
+//   * prefix sums (bit offsets of the lanes, of the header's symbols) are each lane summing what lies before it -- sums of groups of 16
+//     (accumulated with LDS atomics where the values are produced), then its 15 neighbours: about 30 LDS reads, no log-step scans, no
+//     extra barriers; ranks among equal code lengths are counted four bytes per read;
 //   * a block whose dynamic encoding is not smaller than the bytes themselves is emitted as a stored block.
-// Adler-32 of the filtered stream: per-block partial sums, combined by png_finish.  CRC-32 of a chunk: 64 partial CRCs combined with
-// the x^n mod P operator (the construction zlib's crc32_combine uses).
+// Adler-32 of the filtered stream: per-block sums with block-global weights (no prefix needed), combined by png_finish.  CRC-32 of a
+// chunk: 256 partial CRC registers combined in two levels with the x^n mod P operator (the construction zlib's crc32_combine uses).
 #pragma once
 
 #include <cstddef>
@@ -33,16 +38,17 @@
 namespace bs {
 namespace png {
 
-constexpr int kLanes = 64;
-constexpr int kSeg = 128;                 // bytes of the filtered stream one lane tokenises
+constexpr int kLanes = 256;               // threads of a block's workgroup
+constexpr int kSeg = 32;                  // bytes of the filtered stream one lane tokenises
 constexpr int kBlock = kLanes * kSeg;     // bytes per deflate block / IDAT chunk
-constexpr int kLL = 286, kLLPad = 320;    // literal/length alphabet (padded to a multiple of kLanes)
-constexpr int kCL = 19;                   // code-length alphabet
-constexpr int kDataWords = (kSeg / 4) * (kLanes + 1);  // word (kw, lane) at kw * 65 + lane: conflict-free both ways
+constexpr int kLL = 286, kLLPad = 320;    // literal/length alphabet (padded)
+constexpr int kCL = 19, kCLPad = 32;      // code-length alphabet
+constexpr int kDataWords = (kSeg / 4) * (kLanes + 1);  // word (kw, lane) at kw * 257 + lane: conflict-free both ways
 constexpr int kStoredMax = 5 + kBlock;    // data bytes of a stored block
 constexpr int kOutWords = (kStoredMax + 3) / 4 + 2;
 constexpr int kSlot = 8224;               // staging bytes per block: 4 length + 4 type + <= 8197 data + 4 crc, rounded up to 32
-constexpr int kHdrMax = kLL + 2;          // code-length tokens of a block header (no run symbol 16: one token per length at most)
+constexpr int kHdrMax = 288;              // positions of a block header: <= 286 literal/length lengths + 1 distance length
+constexpr int kGroup = 16;                // prefix sums go in two levels: sums of groups of 16, then the 15 neighbours
 constexpr uint32_t kAdlerMod = 65521;
 constexpr uint32_t kHeadBytes = 8 + 25 + 14;   // signature, IHDR chunk, IDAT chunk holding the 2-byte zlib header
 constexpr uint32_t kTailBytes = 21 + 12;       // IDAT chunk holding the final empty stored block + Adler-32, IEND chunk
@@ -61,27 +67,32 @@ struct Args {
 
 struct Block {
     uint32_t data[kDataWords];
-    uint16_t tok[kSeg * kLanes];   // token k of lane j at k * 64 + j: literal = byte value; match = 0x8000 | length (distance 1)
+    uint16_t tok[kSeg * kLanes];   // token k of lane j at k * 256 + j: literal = byte value; match = 0x8000 | length (distance 1)
     uint32_t ntok[kLanes];
-    uint32_t lane_a[kLanes], lane_b[kLanes];   // Adler partial sums of the lane's bytes
     uint32_t lane_bits[kLanes], lane_off[kLanes];
-    uint32_t freq[kLLPad];
+    union {                        // the frequencies are dead once the Shannon lengths exist (ph_len_shannon); the words the token
+        uint32_t freq[kLLPad];     // walks read are written two barriers later (ph_len_codes)
+        uint32_t codelen[kLLPad];  // code | length << 16
+    };
     uint8_t len0[kLLPad], len[kLLPad];
     uint16_t rank0[kLLPad];
     uint16_t code[kLLPad];         // bit-reversed canonical codes
-    uint32_t cl_freq[kLanes];
-    uint8_t cl_len0[kLanes], cl_len[kLanes];
-    uint16_t cl_rank0[kLanes], cl_code[kLanes];
+    uint32_t cl_freq[kCLPad];
+    uint8_t cl_len0[kCLPad], cl_len[kCLPad];
+    uint16_t cl_rank0[kCLPad], cl_code[kCLPad];
     uint32_t cnt0[2][16], cum0[2][17], cumf[2][17], next_code[2][17], nused[2];
-    uint8_t hdr_sym[kHdrMax], hdr_ext[kHdrMax];
-    uint32_t nhdr, hlit_n, hclen_n;
+    uint8_t hdr_cost[kHdrMax];     // bits of header position i (the code of its length in the code-length code)
+    uint32_t lane_gsum[kLanes / kGroup], hdr_gsum[kHdrMax / kGroup];   // the same summed over groups of 16 lanes / positions
+    uint32_t hlit_n, hclen_n;
     uint32_t out[kOutWords];
     uint32_t n_bytes;      // bytes of the filtered stream in this block
     int32_t prev0;         // the byte before the block (-1: the block starts the stream)
     uint32_t ntot;         // tokens in the block
     uint32_t has_match;
-    uint32_t hdr_bits, eob_off, total_bits, use_dyn, data_len;
-    uint32_t crc;
+    uint32_t adler_a, adler_b;     // sum d, sum (n_bytes - position) d over the block, each lane's share reduced mod 65521 first
+    uint32_t hdr_bits, tok_bits, eob_off, total_bits, use_dyn, data_len;
+    uint32_t crc;                                // register form: the chunk's CRC-32 is its complement
+    uint32_t crc_group[16], crc_p[16], crc_q[16];   // the groups' registers; crc_seg_pow, crc_group_pow
 };
 
 // ---- small helpers -----------------------------------------------------------------------------------------------------------------
@@ -110,6 +121,14 @@ BS_HD void lds_xor(uint32_t *p, uint32_t v)
     *p ^= v;
 #endif
 }
+BS_HD void lds_max(uint32_t *p, uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
 
 BS_HD int paeth(int a, int b, int c)
 {
@@ -118,36 +137,44 @@ BS_HD int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// The PNG filter `f` applied at byte x of row `row` (PNG specification, section 9: bpp = 3).
-BS_HD uint8_t filter_byte(const uint8_t *rgb, int32_t w, int32_t row, int32_t x, int f)
+// The four bytes a PNG filter looks at (PNG specification, section 9; bpp = 3): the byte itself, its left (a), upper (b) and upper-left
+// (c) neighbours, 0 outside the image.  All four loads are issued whatever the filter: none depends on another.
+struct Neighbourhood { int raw, a, b, c; };
+BS_HD Neighbourhood neighbourhood(const uint8_t *rgb, int32_t w, int32_t row, int32_t x)
 {
-    const size_t rb = (size_t)3 * w;
-    const uint8_t *cur = rgb + (size_t)row * rb;
-    const int raw = cur[x];
-    if (f == 0) return (uint8_t)raw;
-    const int a = x >= 3 ? cur[x - 3] : 0;
-    if (f == 1) return (uint8_t)(raw - a);
-    const int b = row > 0 ? cur[(ptrdiff_t)x - (ptrdiff_t)rb] : 0;
-    if (f == 2) return (uint8_t)(raw - b);
-    if (f == 3) return (uint8_t)(raw - ((a + b) >> 1));
-    const int c = (row > 0 && x >= 3) ? cur[(ptrdiff_t)x - 3 - (ptrdiff_t)rb] : 0;
-    return (uint8_t)(raw - paeth(a, b, c));
+    const ptrdiff_t rb = (ptrdiff_t)3 * w;
+    const uint8_t *cur = rgb + (ptrdiff_t)row * rb + x;
+    Neighbourhood n;
+    n.raw = cur[0];
+    n.a = x >= 3 ? cur[-3] : 0;
+    n.b = row > 0 ? cur[-rb] : 0;
+    n.c = (row > 0 && x >= 3) ? cur[-rb - 3] : 0;
+    return n;
+}
+BS_HD uint8_t filtered(const Neighbourhood &n, int f)
+{
+    const int pred = f == 0 ? 0 : f == 1 ? n.a : f == 2 ? n.b : f == 3 ? ((n.a + n.b) >> 1) : paeth(n.a, n.b, n.c);
+    return (uint8_t)(n.raw - pred);
 }
 
-// Byte p of the filtered stream: each row is its filter type followed by its 3 w filtered bytes.
+// Byte (row, col) of the filtered stream: each row is its filter type followed by its 3 w filtered bytes.
 BS_HD uint8_t stream_byte(const Args &A, uint32_t row, uint32_t col)
 {
     const int f = A.filt[row];
-    return col == 0 ? (uint8_t)f : filter_byte(A.rgb, A.w, (int32_t)row, (int32_t)col - 1, f);
+    return col == 0 ? (uint8_t)f : filtered(neighbourhood(A.rgb, A.w, (int32_t)row, (int32_t)col - 1), f);
 }
 
 // What byte x of a row costs under each of the five filters: |signed residual| (libpng's heuristic).
-BS_HD void filter_cost(const uint8_t *rgb, int32_t w, int32_t row, int32_t x, uint32_t cost[5])
+BS_HD void neighbourhood_cost(const Neighbourhood &n, uint32_t cost[5])
 {
     for (int f = 0; f < 5; f++) {
-        const int v = (int8_t)filter_byte(rgb, w, row, x, f);
+        const int v = (int8_t)filtered(n, f);
         cost[f] += (uint32_t)(v < 0 ? -v : v);
     }
+}
+BS_HD void filter_cost(const uint8_t *rgb, int32_t w, int32_t row, int32_t x, uint32_t cost[5])
+{
+    neighbourhood_cost(neighbourhood(rgb, w, row, x), cost);
 }
 
 BS_HD uint32_t best_filter(const uint32_t cost[5])
@@ -203,21 +230,53 @@ BS_HD uint32_t crc_multmodp(uint32_t a, uint32_t b)
     return p;
 }
 
-// x^(8 n) mod P
-BS_HD uint32_t crc_x8n(uint32_t n)
+// x^(8 2^k) mod P, k < 16 (0x00800000 = x^8, each the square of the one before): a switch of immediates -- the block kernel copies them
+// into LDS once (a constant array indexed at run time would live in memory behind a 500-cycle load)
+BS_HD uint32_t crc_x8_pow2(uint32_t k)
 {
-    uint32_t p = 1u << 31;          // x^0
-    uint32_t base = 1u << (31 - 8);  // x^8
-    while (n) {
-        if (n & 1u) p = crc_multmodp(base, p);
-        n >>= 1;
-        if (n) base = crc_multmodp(base, base);
+    switch (k) {
+    case 0: return 0x00800000u; case 1: return 0x00008000u; case 2: return 0xEDB88320u; case 3: return 0xB1E6B092u;
+    case 4: return 0xA06A2517u; case 5: return 0xED627DAEu; case 6: return 0x88D14467u; case 7: return 0xD7BBFE6Au;
+    case 8: return 0xEC447F11u; case 9: return 0x8E7EA170u; case 10: return 0x6427800Eu; case 11: return 0x4D47BAE0u;
+    case 12: return 0x09FE548Fu; case 13: return 0x83852D0Fu; case 14: return 0x30362F1Au; default: return 0x7B5A9CC3u;
     }
+}
+
+// x^(8 n) mod P for n < 65536: the product of x^(8 2^k) over the set bits k of n; pow2[k] = crc_x8_pow2(k)
+BS_HD uint32_t crc_x8n(const uint32_t *pow2, uint32_t n)
+{
+    uint32_t p = 1u << 31;   // x^0
+    for (uint32_t k = 0; n; k++, n >>= 1)
+        if (n & 1u) p = crc_multmodp(pow2[k], p);
     return p;
 }
 
-// the CRC-32 of A || B from the CRC-32s of A and B and the length of B
-BS_HD uint32_t crc_shift(uint32_t crc_a, uint32_t len_b) { return crc_multmodp(crc_x8n(len_b), crc_a); }
+// the CRC-32 of A || B from the CRC-32s of A and B and the length of B (< 65536)
+BS_HD uint32_t crc_shift(const uint32_t *pow2, uint32_t crc_a, uint32_t len_b) { return crc_multmodp(crc_x8n(pow2, len_b), crc_a); }
+
+// The block kernel's two-level combination: the chunk's bytes are cut into 256 pieces of kCrcSeg bytes aligned to the chunk's END (the
+// ragged piece is the first one), so piece j is followed by (255 - j) kCrcSeg bytes whatever the chunk's length: sixteen pieces
+// form a group (shift inside the group: X^(15 - j % 16), X = x^(8 kCrcSeg)), sixteen groups the chunk (shift of group g: Y^(15 - g), Y = X^16).
+// One multiplication per lane, constants only.
+constexpr uint32_t kCrcSeg = 33;   // 256 * 33 >= 4 + kStoredMax
+BS_HD uint32_t crc_seg_pow(uint32_t i)     // X^i, i < 16
+{
+    switch (i) {
+    case 0: return 0x80000000u; case 1: return 0x3183EC92u; case 2: return 0x5B0DF038u; case 3: return 0x333100D6u;
+    case 4: return 0xF44779B9u; case 5: return 0xBDCC5801u; case 6: return 0xB57004DDu; case 7: return 0x0B0125EEu;
+    case 8: return 0xD3DCF3D3u; case 9: return 0xF45CE70Bu; case 10: return 0xCE48B184u; case 11: return 0x7F8CB060u;
+    case 12: return 0x22385622u; case 13: return 0x23A58B5Cu; case 14: return 0xF657F322u; default: return 0x8CBD6CA3u;
+    }
+}
+BS_HD uint32_t crc_group_pow(uint32_t i)   // Y^i, i < 16
+{
+    switch (i) {
+    case 0: return 0x80000000u; case 1: return 0xDBA769B6u; case 2: return 0x17AEC39Eu; case 3: return 0x28DA6DB3u;
+    case 4: return 0x447D3DCEu; case 5: return 0x76FC39ACu; case 6: return 0x221BAA2Bu; case 7: return 0xB3BFECFAu;
+    case 8: return 0x0D63715Du; case 9: return 0x3C20FE04u; case 10: return 0x6105EA4Au; case 11: return 0xF6CE12A3u;
+    case 12: return 0x94C61C3Cu; case 13: return 0x77DCCE78u; case 14: return 0x00025BFBu; default: return 0x396A93D0u;
+    }
+}
 
 BS_HD uint32_t crc_bytes(const uint8_t *p, uint32_t n)
 {
@@ -232,7 +291,8 @@ BS_HD void put_be32(uint8_t *p, uint32_t v)
 }
 
 // ---- the block's bytes in LDS ----------------------------------------------------------------------------------------------------------
-BS_HD uint32_t data_index(uint32_t lane, uint32_t k) { return ((k >> 2) * (kLanes + 1) + lane) * 4 + (k & 3); }
+BS_HD uint32_t data_word(uint32_t lane, uint32_t kw) { return kw * (kLanes + 1) + lane; }
+BS_HD uint32_t data_index(uint32_t lane, uint32_t k) { return data_word(lane, k >> 2) * 4 + (k & 3); }
 BS_HD uint8_t data_get(const Block &S, uint32_t lane, uint32_t k) { return reinterpret_cast<const uint8_t *>(S.data)[data_index(lane, k)]; }
 BS_HD uint32_t lane_bytes(const Block &S, uint32_t lane)
 {
@@ -240,8 +300,27 @@ BS_HD uint32_t lane_bytes(const Block &S, uint32_t lane)
     return S.n_bytes <= first ? 0u : (S.n_bytes - first < (uint32_t)kSeg ? S.n_bytes - first : (uint32_t)kSeg);
 }
 
+// How many of the bytes v[0 .. s) equal l (v: 4-byte aligned, readable up to the next multiple of 4; l < 128): four bytes per read.
+BS_HD uint32_t count_equal_before(const uint8_t *v, uint32_t s, uint32_t l)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(v);
+    const uint32_t pat = l * 0x01010101u;
+    uint32_t r = 0;
+    for (uint32_t i = 0; i * 4 < s; i++) {
+        uint32_t x = w[i] ^ pat;                                       // a zero byte where v == l
+        x = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in exactly those bytes
+        if (s - i * 4 < 4) x &= (1u << (8 * (s - i * 4))) - 1u;        // bytes at or beyond s do not count
+#if defined(__HIP_DEVICE_COMPILE__)
+        r += (uint32_t)__popc(x);
+#else
+        r += (uint32_t)__builtin_popcount(x);
+#endif
+    }
+    return r;
+}
+
 // ---- phases ----------------------------------------------------------------------------------------------------------------------------
-// (every phase: all 64 lanes, then a barrier)
+// (every phase: all 256 lanes, then a barrier)
 
 BS_HD void ph_init(uint32_t lane, Block &S, const Args &A, uint32_t blk)
 {
@@ -250,13 +329,18 @@ BS_HD void ph_init(uint32_t lane, Block &S, const Args &A, uint32_t blk)
         S.len0[i] = 0; S.len[i] = 0; S.rank0[i] = 0; S.code[i] = 0;
     }
     for (uint32_t i = lane; i < (uint32_t)kOutWords; i += kLanes) S.out[i] = 0;
-    S.cl_freq[lane] = 0; S.cl_len0[lane] = 0; S.cl_len[lane] = 0; S.cl_rank0[lane] = 0; S.cl_code[lane] = 0;
-    if (lane < 32) S.cnt0[lane >> 4][lane & 15] = 0;
+    if (lane < (uint32_t)(kLanes / kGroup)) { S.lane_gsum[lane] = 0; S.crc_group[lane] = 0; S.crc_p[lane] = crc_seg_pow(lane); S.crc_q[lane] = crc_group_pow(lane); }
+    if (lane < (uint32_t)(kHdrMax / kGroup)) S.hdr_gsum[lane] = 0;
+    if (lane < (uint32_t)kCLPad) {
+        S.cl_freq[lane] = 0; S.cl_len0[lane] = 0; S.cl_len[lane] = 0; S.cl_rank0[lane] = 0; S.cl_code[lane] = 0;
+        S.cnt0[lane >> 4][lane & 15] = 0;
+    }
     if (lane == 0) {
         const uint64_t first = (uint64_t)blk * kBlock;
         const uint64_t left = A.total - first;
         S.n_bytes = left < (uint64_t)kBlock ? (uint32_t)left : (uint32_t)kBlock;
-        S.ntot = 0; S.has_match = 0; S.nused[0] = 0; S.nused[1] = 0; S.nhdr = 0; S.crc = 0;
+        S.ntot = 0; S.has_match = 0; S.nused[0] = 0; S.nused[1] = 0; S.crc = 0;
+        S.adler_a = 0; S.adler_b = 0; S.hlit_n = 257; S.hdr_bits = 0; S.tok_bits = 0;
         S.prev0 = -1;
         if (first > 0) {
             const uint64_t p = first - 1;
@@ -265,60 +349,135 @@ BS_HD void ph_init(uint32_t lane, Block &S, const Args &A, uint32_t blk)
     }
 }
 
-// filtered bytes of the block into LDS: lane l takes positions l, l + 64, ... (adjacent lanes read adjacent bytes of the frame)
+BS_HD uint32_t load_u32(const uint8_t *p)   // four bytes at any alignment (one global_load_dword on the device)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// filtered bytes of the block into LDS, four at a time: lane l takes positions 4 l .. 4 l + 3, then + 1024, ... -- one word of a
+// segment.  Where the four lie inside one row, clear of its first pixel, each of their neighbourhoods is ONE unaligned 4-byte load
+// (raw, left, up, up-left: 4 loads for 4 bytes instead of 16); the two groups per row that touch the filter byte or the left edge go
+// byte by byte.  All eight groups of a lane are loaded before any is filtered.
+constexpr uint32_t kLoadGroups = kBlock / (4 * kLanes);   // 8
 BS_HD void ph_load(uint32_t lane, Block &S, const Args &A, uint32_t blk)
 {
-    const uint64_t first = (uint64_t)blk * kBlock + lane;
+    const uint64_t first = (uint64_t)blk * kBlock + 4 * lane;
     uint32_t row = (uint32_t)(first / A.stride), col = (uint32_t)(first % A.stride);
-    uint8_t *bytes = reinterpret_cast<uint8_t *>(S.data);
-    for (uint32_t it = 0; it < (uint32_t)kBlock / kLanes; it++) {
-        const uint32_t q = it * kLanes + lane;   // position in the block
-        if (q < S.n_bytes) bytes[data_index(q / kSeg, q % kSeg)] = stream_byte(A, row, col);
-        col += kLanes;
+    const ptrdiff_t rb = (ptrdiff_t)3 * A.w;
+    uint32_t wraw[kLoadGroups], wa[kLoadGroups], wb[kLoadGroups], wc[kLoadGroups], rows[kLoadGroups], cols[kLoadGroups];
+    int f[kLoadGroups];
+    for (uint32_t g = 0; g < kLoadGroups; g++) {
+        const uint32_t q = (g * kLanes + lane) * 4;   // position in the block
+        rows[g] = row; cols[g] = col;
+        wraw[g] = wa[g] = wb[g] = wc[g] = 0;
+        f[g] = 0;
+        if (q + 4 <= S.n_bytes && col >= 4 && col + 4 <= A.stride) {   // fast: one row, x >= 3
+            const uint8_t *cur = A.rgb + (ptrdiff_t)row * rb + (col - 1);
+            f[g] = A.filt[row];
+            wraw[g] = load_u32(cur);
+            wa[g] = load_u32(cur - 3);
+            if (row > 0) {
+                wb[g] = load_u32(cur - rb);
+                wc[g] = load_u32(cur - rb - 3);
+            }
+        }
+        col += 4 * kLanes;
         while (col >= A.stride) { col -= A.stride; row++; }
+    }
+    for (uint32_t g = 0; g < kLoadGroups; g++) {
+        const uint32_t q = (g * kLanes + lane) * 4;
+        if (q >= S.n_bytes) continue;
+        uint32_t out = 0;
+        if (q + 4 <= S.n_bytes && cols[g] >= 4 && cols[g] + 4 <= A.stride) {
+            for (uint32_t u = 0; u < 4; u++) {
+                const Neighbourhood nb{(int)((wraw[g] >> (8 * u)) & 0xFFu), (int)((wa[g] >> (8 * u)) & 0xFFu), (int)((wb[g] >> (8 * u)) & 0xFFu),
+                                       (int)((wc[g] >> (8 * u)) & 0xFFu)};
+                out |= (uint32_t)filtered(nb, f[g]) << (8 * u);
+            }
+        } else {
+            uint32_t r = rows[g], c = cols[g];
+            for (uint32_t u = 0; u < 4 && q + u < S.n_bytes; u++) {
+                out |= (uint32_t)stream_byte(A, r, c) << (8 * u);
+                if (++c == A.stride) { c = 0; r++; }
+            }
+        }
+        S.data[data_word(q / kSeg, (q % kSeg) / 4)] = out;
     }
 }
 
-// the lane's 128 bytes -> literals and distance-1 matches; symbol frequencies; Adler partial sums
+BS_HD uint32_t count_trailing_zeros(uint32_t v)   // v != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__ffs((int)v) - 1u;
+#else
+    return (uint32_t)__builtin_ctz(v);
+#endif
+}
+BS_HD uint32_t population(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popc(v);
+#else
+    return (uint32_t)__builtin_popcount(v);
+#endif
+}
+
+// the lane's 32 bytes (8 words in registers) -> literals and distance-1 matches; symbol frequencies; Adler partial sums.
+// Bit k of E: byte k equals the byte before it.  Runs of three or more 1-bits become one match each (its first position carries
+// the token), every other byte is a literal: the tokens are found with a handful of shifts, then visited one set bit at a time.
 BS_HD void ph_tokenize(uint32_t lane, Block &S, const Args &, uint32_t)
 {
     const uint32_t n = lane_bytes(S, lane);
-    int prev = lane == 0 ? S.prev0 : (n ? (int)data_get(S, lane - 1, kSeg - 1) : -1);
-    uint32_t nt = 0, a = 0, b = 0, k = 0;
-    bool any = false;
-    while (k < n) {
-        const int v = data_get(S, lane, k);
-        uint32_t run = 0;
-        if (v == prev) {
-            run = 1;
-            while (k + run < n && data_get(S, lane, k + run) == v) run++;
-        }
-        if (run >= 3) {
-            uint32_t sym, eb, ev;
-            length_code(run, sym, eb, ev);
-            lds_add(&S.freq[sym], 1);
-            S.tok[nt * kLanes + lane] = (uint16_t)(0x8000u | run);
-            nt++;
-            // Adler: `run` bytes of value v at positions k .. k + run - 1 (weights n - k, n - k - 1, ...)
-            a += run * (uint32_t)v;
-            b += (uint32_t)v * (run * (n - k) - run * (run - 1) / 2);
-            k += run;
-            any = true;
-        } else {
-            lds_add(&S.freq[v], 1);
-            S.tok[nt * kLanes + lane] = (uint16_t)v;
-            nt++;
-            a += (uint32_t)v;
-            b += (uint32_t)v * (n - k);
-            prev = v;
-            k++;
+    if (n == 0) { S.ntok[lane] = 0; return; }
+    const int prev = lane == 0 ? S.prev0 : (int)data_get(S, lane - 1, kSeg - 1);
+    uint32_t words[kSeg / 4];
+    for (uint32_t kw = 0; kw < (uint32_t)kSeg / 4; kw++) words[kw] = kw * 4 < n ? S.data[data_word(lane, kw)] : 0u;
+    uint32_t E = 0, a = 0, b = 0;
+    const uint32_t weight0 = S.n_bytes - lane * kSeg;   // Adler weight of the lane's first byte: bytes from it to the end of the block
+    for (uint32_t kw = 0; kw < (uint32_t)kSeg / 4; kw++) {
+        const uint32_t cur = words[kw];
+        const uint32_t before = (cur << 8) | (kw == 0 ? (uint32_t)(prev & 0xFF) : words[kw - 1] >> 24);
+        uint32_t x = cur ^ before;                                     // a zero byte where a byte equals the one before
+        x = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in exactly those bytes
+        E |= (((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u)) << (4 * kw);
+        for (uint32_t u = 0; u < 4; u++) {                             // (bytes at or beyond n are 0: they add nothing)
+            const uint32_t v = (cur >> (8 * u)) & 0xFFu;
+            a += v;
+            b += v * (weight0 - (4 * kw + u));
         }
     }
+    const uint32_t valid = n == 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
+    E &= valid;
+    if (prev < 0) E &= ~1u;                                            // the stream's first byte has nothing before it
+    const uint32_t third = E & (E << 1) & (E << 2);                    // third or later position of a run of 1-bits
+    const uint32_t in_run = (third | (third >> 1) | (third >> 2)) & E; // every position of a run of three or more
+    const uint32_t starts = in_run & ~(in_run << 1);
+    uint32_t todo = (valid & ~in_run) | starts;
+    const uint32_t nt = population(todo);
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(S.data);
+    for (uint32_t i = 0; i < nt; i++) {
+        const uint32_t k = count_trailing_zeros(todo);
+        todo &= todo - 1;
+        uint32_t tok, sym;
+        if ((starts >> k) & 1u) {
+            const uint32_t above = ~(in_run >> k);                     // its lowest set bit ends the run; none: all 32 bytes are one run
+            const uint32_t run = above ? count_trailing_zeros(above) : 32u;
+            uint32_t eb, ev;
+            length_code(run, sym, eb, ev);
+            tok = 0x8000u | run;
+        } else {
+            sym = tok = bytes[data_index(lane, k)];
+        }
+        lds_add(&S.freq[sym], 1);
+        S.tok[i * kLanes + lane] = (uint16_t)tok;
+    }
     S.ntok[lane] = nt;
-    S.lane_a[lane] = a % kAdlerMod;
-    S.lane_b[lane] = b % kAdlerMod;
-    if (nt) lds_add(&S.ntot, nt);
-    if (any) lds_or(&S.has_match, 1u);
+    lds_add(&S.ntot, nt);
+    lds_add(&S.adler_a, a % kAdlerMod);
+    lds_add(&S.adler_b, b % kAdlerMod);
+    if (starts) lds_or(&S.has_match, 1u);
 }
 
 // Code lengths of one alphabet (which = 0: literal/length, limit 15; 1: code lengths, limit 7), in five phases.
@@ -329,7 +488,7 @@ struct Alphabet {
 BS_HD Alphabet alphabet(Block &S, int which)
 {
     if (which == 0) return Alphabet{S.freq, S.len0, S.len, S.rank0, S.code, (uint32_t)kLL, 15u, S.ntot + 1u};
-    return Alphabet{S.cl_freq, S.cl_len0, S.cl_len, S.cl_rank0, S.cl_code, (uint32_t)kCL, 7u, S.nhdr};
+    return Alphabet{S.cl_freq, S.cl_len0, S.cl_len, S.cl_rank0, S.cl_code, (uint32_t)kCL, 7u, S.hlit_n + 1u};
 }
 
 // (1) Shannon length of every used symbol: the smallest l with f 2^l >= N, clamped to [1, limit]
@@ -344,6 +503,7 @@ BS_HD void ph_len_shannon(uint32_t lane, Block &S, int which)
             while (l < al.limit && ((uint64_t)f << l) < al.total) l++;
             lds_add(&S.cnt0[which][l], 1);
             lds_add(&S.nused[which], 1);
+            if (which == 0) lds_max(&S.hlit_n, s + 1);   // HLIT: the header lists the lengths up to the last used symbol (at least 257)
         }
         al.len0[s] = (uint8_t)l;
     }
@@ -355,10 +515,7 @@ BS_HD void ph_len_rank(uint32_t lane, Block &S, int which)
     const Alphabet al = alphabet(S, which);
     for (uint32_t s = lane; s < al.n; s += kLanes) {
         const uint32_t l = al.len0[s];
-        uint32_t r = 0;
-        if (l)
-            for (uint32_t t = 0; t < s; t++) r += al.len0[t] == l;
-        al.rank0[s] = (uint16_t)r;
+        al.rank0[s] = (uint16_t)(l ? count_equal_before(al.len0, s, l) : 0u);
     }
 }
 
@@ -442,41 +599,20 @@ BS_HD void ph_len_codes(uint32_t lane, Block &S, int which)
     for (uint32_t s = lane; s < al.n; s += kLanes) {
         const uint32_t l = al.len[s];
         if (!l) continue;
-        uint32_t r = 0;
-        for (uint32_t t = 0; t < s; t++) r += al.len[t] == l;
-        al.code[s] = (uint16_t)bit_reverse(S.next_code[which][l] + r, l);
+        al.code[s] = (uint16_t)bit_reverse(S.next_code[which][l] + count_equal_before(al.len, s, l), l);
+        if (which == 0) S.codelen[s] = al.code[s] | (l << 16);
     }
 }
 
-// The block header's code lengths (HLIT + 257 literal/length lengths, then the one distance length) as code-length symbols: runs of
-// zeros as 17 / 18, everything else literally.
-BS_HD void ph_header_rle(uint32_t lane, Block &S, const Args &, uint32_t)
+// The block header lists HLIT + 257 literal/length code lengths and the one distance code length; position i of that list:
+BS_HD uint32_t header_value(const Block &S, uint32_t i) { return i < S.hlit_n ? S.len[i] : (S.has_match ? 1u : 0u); }
+BS_HD uint32_t header_positions(const Block &S) { return S.hlit_n + 1; }
+
+// how often each length occurs in the header: the frequencies of the code-length alphabet (every position is its own symbol)
+BS_HD void ph_header_freq(uint32_t lane, Block &S, const Args &, uint32_t)
 {
-    if (lane != 0) return;
-    uint32_t hl = kLL;
-    while (hl > 257 && S.len[hl - 1] == 0) hl--;
-    S.hlit_n = hl;
-    const uint32_t n = hl + 1;   // + the distance alphabet's single length
-    uint32_t nh = 0, i = 0;
-    while (i < n) {
-        const uint32_t v = i < hl ? S.len[i] : (S.has_match ? 1u : 0u);
-        if (v == 0) {
-            uint32_t run = 1;
-            while (i + run < n && run < 138 && (i + run < hl ? S.len[i + run] : (S.has_match ? 1u : 0u)) == 0) run++;
-            if (run >= 11) { S.hdr_sym[nh] = 18; S.hdr_ext[nh] = (uint8_t)(run - 11); }
-            else if (run >= 3) { S.hdr_sym[nh] = 17; S.hdr_ext[nh] = (uint8_t)(run - 3); }
-            else { run = 1; S.hdr_sym[nh] = 0; S.hdr_ext[nh] = 0; }
-            S.cl_freq[S.hdr_sym[nh]]++;
-            nh++;
-            i += run;
-        } else {
-            S.hdr_sym[nh] = (uint8_t)v; S.hdr_ext[nh] = 0;
-            S.cl_freq[v]++;
-            nh++;
-            i++;
-        }
-    }
-    S.nhdr = nh;
+    const uint32_t n = header_positions(S);
+    for (uint32_t i = lane; i < n; i += kLanes) lds_add(&S.cl_freq[header_value(S, i)], 1);
 }
 
 BS_HD uint32_t cl_order(uint32_t i)
@@ -487,39 +623,49 @@ BS_HD uint32_t cl_order(uint32_t i)
 
 BS_HD uint32_t token_bits(const Block &S, uint32_t t)
 {
-    if (!(t & 0x8000u)) return S.len[t];
+    if (!(t & 0x8000u)) return S.codelen[t] >> 16;
     uint32_t sym, eb, ev;
     length_code(t & 0x7FFFu, sym, eb, ev);
-    return S.len[sym] + eb + 1;   // + the distance code: one bit
+    return (S.codelen[sym] >> 16) + eb + 1;   // + the distance code: one bit
 }
 
+// bits of every lane's tokens and of every header position
 BS_HD void ph_bitcount(uint32_t lane, Block &S, const Args &, uint32_t)
 {
     uint32_t bits = 0;
     for (uint32_t i = 0; i < S.ntok[lane]; i++) bits += token_bits(S, S.tok[i * kLanes + lane]);
     S.lane_bits[lane] = bits;
+    if (bits) {
+        lds_add(&S.tok_bits, bits);
+        lds_add(&S.lane_gsum[lane / kGroup], bits);
+    }
+    const uint32_t n = header_positions(S);
+    for (uint32_t i = lane; i < n; i += kLanes) {
+        const uint32_t c = S.cl_len[header_value(S, i)];
+        S.hdr_cost[i] = (uint8_t)c;
+        lds_add(&S.hdr_bits, c);
+        lds_add(&S.hdr_gsum[i / kGroup], c);
+    }
+    if (lane == 0) {
+        uint32_t hc = kCL;
+        while (hc > 4 && S.cl_len[cl_order(hc - 1)] == 0) hc--;
+        S.hclen_n = hc;
+    }
 }
 
+// where every lane's bits go (the groups before its group, then the lanes before it in its group), and whether the block is worth coding
 BS_HD void ph_plan(uint32_t lane, Block &S, const Args &, uint32_t)
 {
+    const uint32_t head = 3 + 5 + 5 + 4 + 3 * S.hclen_n + S.hdr_bits;
+    uint32_t off = head;
+    for (uint32_t g = 0; g < lane / kGroup; g++) off += S.lane_gsum[g];
+    for (uint32_t j = lane / kGroup * kGroup; j < lane; j++) off += S.lane_bits[j];
+    S.lane_off[lane] = off;
     if (lane != 0) return;
-    uint32_t hc = kCL;
-    while (hc > 4 && S.cl_len[cl_order(hc - 1)] == 0) hc--;
-    S.hclen_n = hc;
-    uint32_t bits = 3 + 5 + 5 + 4 + 3 * hc;
-    for (uint32_t i = 0; i < S.nhdr; i++) {
-        const uint32_t s = S.hdr_sym[i];
-        bits += S.cl_len[s] + (s == 17 ? 3u : s == 18 ? 7u : 0u);
-    }
-    S.hdr_bits = bits;
-    for (uint32_t j = 0; j < (uint32_t)kLanes; j++) {
-        S.lane_off[j] = bits;
-        bits += S.lane_bits[j];
-    }
-    S.eob_off = bits;
-    bits += S.len[256];
-    S.total_bits = bits;
-    const uint32_t dyn = (bits + 3 + 7) / 8 + 4;   // + the empty stored block: 3 bits, padding to the byte, LEN, NLEN
+    const uint32_t eob = head + S.tok_bits;
+    S.eob_off = eob;
+    S.total_bits = eob + S.len[256];
+    const uint32_t dyn = (S.total_bits + 3 + 7) / 8 + 4;   // + the empty stored block: 3 bits, padding to the byte, LEN, NLEN
     const uint32_t stored = 5 + S.n_bytes;
     S.use_dyn = dyn < stored;
     S.data_len = S.use_dyn ? dyn : stored;
@@ -568,12 +714,6 @@ BS_HD void ph_emit(uint32_t lane, Block &S, const Args &, uint32_t)
         bw.put(0, 5);                // HDIST: one distance code
         bw.put(S.hclen_n - 4, 4);
         for (uint32_t i = 0; i < S.hclen_n; i++) bw.put(S.cl_len[cl_order(i)], 3);
-        for (uint32_t i = 0; i < S.nhdr; i++) {
-            const uint32_t s = S.hdr_sym[i];
-            bw.put(S.cl_code[s], S.cl_len[s]);
-            if (s == 17) bw.put(S.hdr_ext[i], 3);
-            if (s == 18) bw.put(S.hdr_ext[i], 7);
-        }
         bw.flush();
         BitWriter be(S.out, S.eob_off);
         be.put(S.code[256], S.len[256]);
@@ -583,55 +723,70 @@ BS_HD void ph_emit(uint32_t lane, Block &S, const Args &, uint32_t)
         bn.put(0xFFFFu, 16);
         bn.flush();
     }
+    // header positions lane, lane + 256: each sums the cost of the positions before it (whole groups, then its group's)
+    const uint32_t n = header_positions(S);
+    for (uint32_t i = lane; i < n; i += kLanes) {
+        uint32_t off = 3 + 5 + 5 + 4 + 3 * S.hclen_n;
+        for (uint32_t g = 0; g < i / kGroup; g++) off += S.hdr_gsum[g];
+        for (uint32_t j = i / kGroup * kGroup; j < i; j++) off += S.hdr_cost[j];
+        const uint32_t v = header_value(S, i);
+        BitWriter bh(S.out, off);
+        bh.put(S.cl_code[v], S.cl_len[v]);
+        bh.flush();
+    }
     BitWriter bw(S.out, S.lane_off[lane]);
     for (uint32_t i = 0; i < S.ntok[lane]; i++) {
         const uint32_t t = S.tok[i * kLanes + lane];
         if (!(t & 0x8000u)) {
-            bw.put(S.code[t], S.len[t]);
+            const uint32_t cl = S.codelen[t];
+            bw.put(cl & 0xFFFFu, cl >> 16);
         } else {
             uint32_t sym, eb, ev;
             length_code(t & 0x7FFFu, sym, eb, ev);
-            bw.put(S.code[sym], S.len[sym]);
-            if (eb) bw.put(ev, eb);
-            bw.put(0, 1);            // distance 1: the one distance code, one bit
+            const uint32_t cl = S.codelen[sym];
+            bw.put(cl & 0xFFFFu, cl >> 16);
+            bw.put(ev, eb + 1);      // the extra bits, then distance 1: the one distance code, one bit (0)
         }
     }
     bw.flush();
 }
 
-// CRC-32 of the chunk ("IDAT" + data): every lane takes 1/64 of the bytes, shifts its CRC over what follows, XOR of all = the chunk's
+// CRC-32 of the chunk ("IDAT" + data), level one: every lane runs the register over its piece (the piece holding the chunk's first byte
+// starts from 0xFFFFFFFF, the others from 0), shifts it to the end of its group, XOR into the group's register
 BS_HD void ph_crc(uint32_t lane, Block &S, const Args &, uint32_t)
 {
     const uint8_t *ob = reinterpret_cast<const uint8_t *>(S.out);
-    const uint32_t m = 4 + S.data_len;
-    const uint32_t per = (m + kLanes - 1) / kLanes;
-    const uint32_t b0 = lane * per < m ? lane * per : m, b1 = b0 + per < m ? b0 + per : m;
-    if (b0 == b1) return;
+    const int32_t m = 4 + (int32_t)S.data_len;
+    const int32_t hi = m - (int32_t)((kLanes - 1 - lane) * kCrcSeg);
+    if (hi <= 0) return;
+    const int32_t lo = hi > (int32_t)kCrcSeg ? hi - (int32_t)kCrcSeg : 0;
     const uint8_t type[4] = {'I', 'D', 'A', 'T'};
-    uint32_t c = 0xFFFFFFFFu;
-    for (uint32_t i = b0; i < b1; i++) c = crc_update_byte(c, i < 4 ? type[i] : ob[i - 4]);
-    c ^= 0xFFFFFFFFu;
-    lds_xor(&S.crc, crc_shift(c, m - b1));
+    uint32_t c = lo == 0 ? 0xFFFFFFFFu : 0u;
+    for (int32_t i = lo; i < hi; i++) c = crc_update_byte(c, i < 4 ? type[i] : ob[i - 4]);
+    lds_xor(&S.crc_group[lane / 16], crc_multmodp(S.crc_p[15 - lane % 16], c));
+}
+
+// level two: the sixteen groups' registers, each shifted to the end of the chunk
+BS_HD void ph_crc_groups(uint32_t lane, Block &S, const Args &, uint32_t)
+{
+    if (lane < 16 && S.crc_group[lane]) lds_xor(&S.crc, crc_multmodp(S.crc_q[15 - lane], S.crc_group[lane]));
 }
 
 BS_HD void ph_write(uint32_t lane, Block &S, const Args &A, uint32_t blk)
 {
-    const uint8_t *ob = reinterpret_cast<const uint8_t *>(S.out);
     uint8_t *slot = A.staging + (size_t)blk * kSlot;
-    for (uint32_t i = lane; i < S.data_len; i += kLanes) slot[8 + i] = ob[i];
+    uint32_t *slot_words = reinterpret_cast<uint32_t *>(slot + 8);   // kSlot and 8 are multiples of 4
+    const uint32_t full = S.data_len / 4;
+    for (uint32_t i = lane; i < full; i += kLanes) slot_words[i] = S.out[i];
     if (lane == 0) {
+        const uint8_t *ob = reinterpret_cast<const uint8_t *>(S.out);
+        for (uint32_t i = full * 4; i < S.data_len; i++) slot[8 + i] = ob[i];
         put_be32(slot, S.data_len);
         slot[4] = 'I'; slot[5] = 'D'; slot[6] = 'A'; slot[7] = 'T';
-        put_be32(slot + 8 + S.data_len, S.crc);
+        put_be32(slot + 8 + S.data_len, ~S.crc);
         A.sizes[blk] = 12 + S.data_len;
-        uint64_t a = 0, b = 0;   // Adler partial sums of the block from the lanes': X || Y -> (aX + aY, bX + nY aX + bY)
-        for (uint32_t j = 0; j < (uint32_t)kLanes; j++) {
-            const uint32_t n = lane_bytes(S, j);
-            b = (b + (uint64_t)n * a + S.lane_b[j]) % kAdlerMod;
-            a = (a + S.lane_a[j]) % kAdlerMod;
-        }
-        A.adler[2 * blk] = (uint32_t)a;
-        A.adler[2 * blk + 1] = (uint32_t)b;
+        A.adler[2 * blk] = S.adler_a % kAdlerMod;
+        A.adler[2 * blk + 1] = S.adler_b % kAdlerMod;
     }
 }
 
@@ -640,15 +795,17 @@ BS_HD void ph_write(uint32_t lane, Block &S, const Args &A, uint32_t blk)
     RUN(ph_init) RUN(ph_load) RUN(ph_tokenize)                                                        \
     RUN_ALPHABET(ph_len_shannon, 0) RUN_ALPHABET(ph_len_rank, 0) RUN_ALPHABET(ph_len_counts, 0)       \
     RUN_ALPHABET(ph_len_assign, 0) RUN_ALPHABET(ph_len_codes, 0)                                      \
-    RUN(ph_header_rle)                                                                                \
+    RUN(ph_header_freq)                                                                               \
     RUN_ALPHABET(ph_len_shannon, 1) RUN_ALPHABET(ph_len_rank, 1) RUN_ALPHABET(ph_len_counts, 1)       \
     RUN_ALPHABET(ph_len_assign, 1) RUN_ALPHABET(ph_len_codes, 1)                                      \
-    RUN(ph_bitcount) RUN(ph_plan) RUN(ph_emit) RUN(ph_crc) RUN(ph_write)
+    RUN(ph_bitcount) RUN(ph_plan) RUN(ph_emit) RUN(ph_crc) RUN(ph_crc_groups) RUN(ph_write)
 
-// ---- the frame: offsets of the chunks, Adler-32, the fixed chunks around them (png_finish: ONE wavefront) ---------------------------------
+// ---- the frame: offsets of the chunks, Adler-32, the fixed chunks around them (png_finish: ONE workgroup) ---------------------------------
 struct Finish {
     uint32_t lane_sum[kLanes];
-    uint64_t lane_a[kLanes], lane_b[kLanes], lane_n[kLanes];
+    uint32_t lane_a[kLanes], lane_b[kLanes], lane_n[kLanes];   // all mod 65521
+    uint8_t head[kHeadBytes + 1], tail[kTailBytes + 3];        // the fixed chunks, built by one lane, copied out by eighty
+    uint32_t end;                                              // where the tail goes
 };
 
 struct FinishArgs {
@@ -669,19 +826,24 @@ BS_HD void fin_range(uint32_t lane, uint32_t n, uint32_t &b0, uint32_t &b1)
     b1 = b0 + per < n ? b0 + per : n;
 }
 
+// Adler-32 sums of X || Y from those of X and Y: (aX + aY, bX + nY aX + bY), everything mod 65521 (65520^2 < 2^32: 32-bit arithmetic)
+BS_HD void adler_append(uint32_t &a, uint32_t &b, uint32_t &n, uint32_t ay, uint32_t by, uint32_t ny)
+{
+    b = (b + (ny * a) % kAdlerMod + by) % kAdlerMod;
+    a = (a + ay) % kAdlerMod;
+    n = (n + ny) % kAdlerMod;
+}
+
 BS_HD void fin_sum(uint32_t lane, Finish &F, const FinishArgs &A)
 {
     uint32_t b0, b1;
     fin_range(lane, A.n_blocks, b0, b1);
-    uint32_t s = 0;
-    uint64_t a = 0, b = 0, n = 0;
+    uint32_t s = 0, a = 0, b = 0, n = 0;
     for (uint32_t k = b0; k < b1; k++) {
         s += A.sizes[k];
         const uint64_t first = (uint64_t)k * kBlock;
-        const uint64_t nk = A.total - first < (uint64_t)kBlock ? A.total - first : (uint64_t)kBlock;
-        b = (b + (nk % kAdlerMod) * a + A.adler[2 * k + 1]) % kAdlerMod;
-        a = (a + A.adler[2 * k]) % kAdlerMod;
-        n += nk;
+        const uint32_t nk = A.total - first < (uint64_t)kBlock ? (uint32_t)(A.total - first) : (uint32_t)kBlock;
+        adler_append(a, b, n, A.adler[2 * k], A.adler[2 * k + 1], nk);
     }
     F.lane_sum[lane] = s;
     F.lane_a[lane] = a; F.lane_b[lane] = b; F.lane_n[lane] = n;
@@ -706,16 +868,14 @@ BS_HD void fin_place(uint32_t lane, Finish &F, const FinishArgs &A)
         at += A.sizes[k];
     }
     if (lane != 0) return;
-    uint32_t end = kHeadBytes;
-    uint64_t a = 0, b = 0;
+    uint32_t end = kHeadBytes, a = 0, b = 0, n = 0;
     for (uint32_t j = 0; j < (uint32_t)kLanes; j++) {
         end += F.lane_sum[j];
-        b = (b + (F.lane_n[j] % kAdlerMod) * a + F.lane_b[j]) % kAdlerMod;
-        a = (a + F.lane_a[j]) % kAdlerMod;
+        adler_append(a, b, n, F.lane_a[j], F.lane_b[j], F.lane_n[j]);
     }
     a = (a + 1) % kAdlerMod;                            // Adler-32 starts at A = 1, which every byte adds to B once
-    b = (b + A.total % kAdlerMod) % kAdlerMod;
-    uint8_t *o = A.out;
+    b = (b + n) % kAdlerMod;
+    uint8_t *o = F.head;
     const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     for (int i = 0; i < 8; i++) o[i] = sig[i];
     uint8_t ihdr[13];
@@ -726,10 +886,18 @@ BS_HD void fin_place(uint32_t lane, Finish &F, const FinishArgs &A)
     const uint8_t zhdr[2] = {0x78, 0x01};               // zlib: deflate, 32 KiB window; no preset dictionary, fastest-compression hint
     write_chunk(o + 33, "IDAT", zhdr, 2);
     uint8_t tail[9] = {0x01, 0x00, 0x00, 0xFF, 0xFF, 0, 0, 0, 0};   // the final (empty, stored) block, then Adler-32
-    put_be32(tail + 5, (uint32_t)((b << 16) | a));
-    write_chunk(o + end, "IDAT", tail, 9);
-    write_chunk(o + end + 21, "IEND", tail, 0);
-    *A.file_bytes = (uint64_t)end + kTailBytes;
+    put_be32(tail + 5, (b << 16) | a);
+    write_chunk(F.tail, "IDAT", tail, 9);
+    write_chunk(F.tail + 21, "IEND", tail, 0);
+    F.end = end;
+}
+
+// the fixed chunks into the file (one byte per lane: the file may live in the caller's page-locked memory, across PCIe)
+BS_HD void fin_copy(uint32_t lane, Finish &F, const FinishArgs &A)
+{
+    if (lane < kHeadBytes) A.out[lane] = F.head[lane];
+    if (lane >= 64 && lane < 64 + kTailBytes) A.out[F.end + lane - 64] = F.tail[lane - 64];
+    if (lane == 0) *A.file_bytes = (uint64_t)F.end + kTailBytes;
 }
 
 // Bytes a w x h RGB8 frame can take at most as a file of this encoder (every block stored).

@@ -4,14 +4,16 @@
 // writer, and this package's before: 25-60x the time the GPU needs to render the frame).
 //
 // Four kernels per frame, all enqueue-only:
-//   png_choose_filter   one wavefront per row: the scanline filter with the smallest sum of |residuals|
-//   png_encode_blocks   one wavefront per 8 KiB of the filtered stream: the phase program of png_block.h (filter, tokenise, Huffman
-//                       code, bit packing, CRC) -> the block's IDAT chunk in its staging slot, its size, its Adler-32 partial sums
-//   png_finish          one wavefront: chunk offsets (prefix sum), Adler-32, signature / IHDR / zlib header / final block / IEND, file size
+//   png_choose_filter   one workgroup per row: the scanline filter with the smallest sum of |residuals|
+//   png_encode_blocks   one workgroup (256 threads) per 8 KiB of the filtered stream: the phase program of png_block.h (filter, tokenise,
+//                       Huffman code, bit packing, CRC) -> the block's IDAT chunk in its staging slot, its size, its Adler-32 partial sums
+//   png_finish          one workgroup: chunk offsets (prefix sum), Adler-32, signature / IHDR / zlib header / final block / IEND, file size
 //   png_gather          staging slots -> their places in the file (device memory, or the caller's page-locked buffer: zero copy)
 // The algorithm, the format decisions and what pins the byte stream on the CPU: png_block.h.  Integer / byte work, bound by LDS
-// latency of single-wavefront workgroups, not by HBM (6.2 MB in, ~1 MB out per 1080p frame).
+// latency, not by HBM (6.2 MB in, ~2 MB out per 1080p frame).
 #include <hip/hip_runtime.h>
+
+#include <cmath>
 
 #include "bs_internal.h"
 #include "png_block.h"
@@ -28,7 +30,16 @@ __global__ __launch_bounds__(kLanes) void png_choose_filter(const uint8_t *__res
     if (lane < 5) total[lane] = 0;
     __syncthreads();
     uint32_t cost[5] = {0, 0, 0, 0, 0};
-    for (int x = lane; x < 3 * w; x += kLanes) filter_cost(rgb, w, row, x, cost);
+    const int n = 3 * w;
+    for (int x0 = lane; x0 < n; x0 += 4 * kLanes) {   // four bytes' neighbourhoods are loaded before any is costed
+        Neighbourhood nb[4];
+        for (int u = 0; u < 4; u++) {
+            const int x = x0 + u * kLanes;
+            nb[u] = x < n ? neighbourhood(rgb, w, row, x) : Neighbourhood{0, 0, 0, 0};
+        }
+        for (int u = 0; u < 4; u++)
+            if (x0 + u * kLanes < n) neighbourhood_cost(nb[u], cost);
+    }
     for (int f = 0; f < 5; f++) atomicAdd(&total[f], cost[f]);
     __syncthreads();
     if (lane == 0) {
@@ -37,12 +48,26 @@ __global__ __launch_bounds__(kLanes) void png_choose_filter(const uint8_t *__res
     }
 }
 
-__global__ __launch_bounds__(kLanes) void png_encode_blocks(Args A)
+#define BS_COUNT(f) +1
+#define BS_COUNT_ALPHABET(f, which) +1
+static_assert(kPngPhases == 1 BS_PNG_BLOCK_PROGRAM(BS_COUNT, BS_COUNT_ALPHABET), "bs_internal.h: kPngPhases = phases of the block program + 1");
+#undef BS_COUNT
+#undef BS_COUNT_ALPHABET
+
+// kProfile: lane 0 of every block also stores the shader clock after each phase (bs_debug_png_phases: where a block's time goes)
+template <bool kProfile>
+__global__ __launch_bounds__(kLanes) void png_encode_blocks(Args A, unsigned long long *__restrict__ clocks)
 {
     __shared__ Block S;
     const uint32_t lane = threadIdx.x, blk = blockIdx.x;
-#define BS_RUN(f) f(lane, S, A, blk); __syncthreads();
-#define BS_RUN_ALPHABET(f, which) f(lane, S, which); __syncthreads();
+    uint32_t phase = 0;
+    auto tick = [&]() {
+        if (kProfile && lane == 0) clocks[(size_t)blk * kPngPhases + phase] = clock64();
+        phase++;
+    };
+    tick();
+#define BS_RUN(f) f(lane, S, A, blk); __syncthreads(); tick();
+#define BS_RUN_ALPHABET(f, which) f(lane, S, which); __syncthreads(); tick();
     BS_PNG_BLOCK_PROGRAM(BS_RUN, BS_RUN_ALPHABET)
 #undef BS_RUN
 #undef BS_RUN_ALPHABET
@@ -55,6 +80,8 @@ __global__ __launch_bounds__(kLanes) void png_finish(FinishArgs A)
     fin_sum(lane, F, A);
     __syncthreads();
     fin_place(lane, F, A);
+    __syncthreads();
+    fin_copy(lane, F, A);
 }
 
 __global__ __launch_bounds__(256) void png_gather(const uint8_t *__restrict__ staging, const uint32_t *__restrict__ sizes,
@@ -73,6 +100,22 @@ size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 uint64_t png_file_bound(int w, int h) { return png::file_bound(w, h); }
 
+size_t png_block_count(int w, int h)
+{
+    const uint64_t total = (uint64_t)h * ((uint64_t)3 * w + 1);
+    return (size_t)((total + kBlock - 1) / kBlock);
+}
+
+// Microseconds the four kernels take for a w x h frame on `cus` CUs (model): the block kernel is bound by the latency of its phases --
+// about 95 us per workgroup, three resident per CU (LDS) -- the filter kernel about 25 us per round of eight rows per CU, and about 100 us
+// of finish + gather.  Measured on the whole chip (1080p: 760 blocks = one round): 95 + 29 + 20 + 47 us (profiles/r03_png_kernel_stats.csv).
+double estimate_png_us(int w, int h, int cus)
+{
+    if (w <= 0 || h <= 0 || cus <= 0) return -1.0;
+    const double nb = (double)png_block_count(w, h);
+    return std::ceil(nb / (3.0 * cus)) * 95.0 + std::ceil((double)h / (8.0 * cus)) * 25.0 + 100.0;
+}
+
 size_t png_scratch_bytes(int w, int h)
 {
     const uint64_t total = (uint64_t)h * ((uint64_t)3 * w + 1);
@@ -82,7 +125,9 @@ size_t png_scratch_bytes(int w, int h)
 
 // d_rgb8: h x w x 3 bytes (device).  d_scratch: png_scratch_bytes(w, h) (device).  d_out: png_file_bound(w, h) bytes, device memory or the
 // device alias of page-locked host memory.  d_file_bytes: one uint64 (same choice).  Enqueues on `stream`; returns non-zero if a launch failed.
-int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream)
+// d_clocks (optional): n_blocks * kPngPhases shader-clock stamps (bs_debug_png_phases).
+int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream,
+                      unsigned long long *d_clocks)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     Args A{};
@@ -99,7 +144,10 @@ int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch
     uint8_t *staging = p;
     A.filt = filt; A.staging = staging; A.sizes = sizes; A.adler = adler;
     hipLaunchKernelGGL(png_choose_filter, dim3(h), dim3(kLanes), 0, s, d_rgb8, w, filt);
-    hipLaunchKernelGGL(png_encode_blocks, dim3(A.n_blocks), dim3(kLanes), 0, s, A);
+    if (d_clocks)
+        hipLaunchKernelGGL(png_encode_blocks<true>, dim3(A.n_blocks), dim3(kLanes), 0, s, A, d_clocks);
+    else
+        hipLaunchKernelGGL(png_encode_blocks<false>, dim3(A.n_blocks), dim3(kLanes), 0, s, A, (unsigned long long *)nullptr);
     FinishArgs FA{sizes, adler, offsets, A.n_blocks, A.total, w, h, d_out, d_file_bytes};
     hipLaunchKernelGGL(png_finish, dim3(1), dim3(kLanes), 0, s, FA);
     hipLaunchKernelGGL(png_gather, dim3(A.n_blocks), dim3(256), 0, s, staging, sizes, offsets, d_out);

@@ -229,13 +229,21 @@ int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height,
 int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_png, size_t cap, size_t *out_bytes);
 /* bs_render_rgb8_batch with files instead of pixels: outs[i] (capacity caps[i] >= bs_png_bound of frame i) receives frame i's PNG file,
  * out_bytes[i] its size.  Two frames in flight per context, the encoder of frame k running under the trace kernel of frame k+1;
- * page-locked outs[i] are written by the encoder itself (only the file's bytes cross PCIe).  The chip is partitioned only on request
- * (BLACKSTAR_POST_CUS=8|16|24|32).  Blocking; bs_stats is not updated. */
+ * page-locked outs[i] are written by the encoder itself (only the file's bytes cross PCIe).  The chip is partitioned like in
+ * bs_render_rgb8_batch, with the encoder's kernels counted into the post stage (the default-aa frame: 16 CUs, 4.44 ms per frame
+ * against 4.77 on the shared chip and 4.31 for bs_render_rgb8_batch).  Blocking; bs_stats is not updated. */
 int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                         const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
 
+/* Probe hook: bs_encode_png's block kernel with a shader-clock stamp (s_memtime) taken by every workgroup before its first phase and
+ * after each of its 20 phases (blackstar_amd/csrc/png_block.h): clocks[b * 21 + p], b < ceil(height * (3 width + 1) / 8192).
+ * scripts/png_phase_probe.py turns them into the table in profiles/. */
+int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned long long *clocks, size_t n_clocks);
+
 /* Test hook, host-only: how many CUs bs_render_rgb8_batch would set aside for the post stage of a batch made of this frame on a chip
- * of n_cu CUs in the given BS_MODE_* (0 = none: the post stage shares the chip with the trace kernels).  See bs_render_rgb8_batch. */
+ * of n_cu CUs in the given BS_MODE_* (0 = none: the post stage shares the chip with the trace kernels).  See bs_render_rgb8_batch.
+ * mode | BS_DEBUG_POST_CUS_PNG: the same for bs_render_png_batch, whose post stage also encodes the file. */
+#define BS_DEBUG_POST_CUS_PNG 0x100
 int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_divider, int n_cu, int mode);
 /* Test hook: the CUs the post stage owned in this context's share of the last bs_render_rgb8_batch (0 = the shared chip, -1 = no batch yet). */
 int bs_debug_last_post_cus(const bs_ctx *ctx);

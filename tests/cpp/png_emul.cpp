@@ -71,6 +71,7 @@ int png_emul_encode(const uint8_t *rgb, int w, int h, uint8_t *out, uint64_t cap
     auto F = std::make_unique<Finish>();
     for (uint32_t lane : lane_order(order, 1)) fin_sum(lane, *F, FA);
     for (uint32_t lane : lane_order(order, 2)) fin_place(lane, *F, FA);
+    for (uint32_t lane : lane_order(order, 3)) fin_copy(lane, *F, FA);
     for (uint32_t blk = 0; blk < A.n_blocks; blk++)   // png_gather
         std::memcpy(out + offsets[blk], staging.data() + (size_t)blk * kSlot, sizes[blk]);
     *out_bytes = file_bytes;
@@ -79,6 +80,11 @@ int png_emul_encode(const uint8_t *rgb, int w, int h, uint8_t *out, uint64_t cap
 }
 
 uint32_t png_emul_crc(const uint8_t *p, uint32_t n) { return crc_bytes(p, n); }
-uint32_t png_emul_crc_combine(uint32_t crc_a, uint32_t crc_b, uint32_t len_b) { return crc_shift(crc_a, len_b) ^ crc_b; }
+uint32_t png_emul_crc_combine(uint32_t crc_a, uint32_t crc_b, uint32_t len_b)
+{
+    uint32_t pow2[16];
+    for (uint32_t k = 0; k < 16; k++) pow2[k] = crc_x8_pow2(k);
+    return crc_shift(pow2, crc_a, len_b) ^ crc_b;
+}
 
 }  // extern "C"

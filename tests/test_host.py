@@ -239,6 +239,13 @@ def test_post_stage_partition_heuristic():
     assert m(scenes.with_res(scenes.DEFAULT_AA, 96, 54)) == 0 and m(scenes.with_res(scenes.DEFAULT_AA, 640, 360)) == 0  # small frames
     assert m(scenes.DEFAULT_AA, n_cu=64) == 0 and m(scenes.DEFAULT_AA, n_cu=100) == 0      # a partitioned device / odd CU counts
     assert L.bs_debug_post_cus(None, 0.1, 25, 256, 1) == -1
+    # bs_render_png_batch: the post stage also encodes the file (scripts/png_partition_ab.py, profiles/r03_png_partition_ab.jsonl)
+    PNG = 0x100  # BS_DEBUG_POST_CUS_PNG
+    assert m(scenes.DEFAULT_AA, mode=_lib.BS_MODE_FAST | PNG) == 16                                   # C3: 4.41 against 4.74 ms (7.4 on 8 CUs)
+    assert m(scenes.DEFAULT_AA, st=0.0, mode=_lib.BS_MODE_FAST | PNG) == 8                           # no bloom: 4.26 against 4.43
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 1280, 720), mode=_lib.BS_MODE_FAST | PNG) in (16, 24)  # 2.01 (16) / 2.06 (24) against 2.31
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 2560, 1440), mode=_lib.BS_MODE_FAST | PNG) == 0       # 8.13 shared (16 CUs: 7.81 -- the model stays out)
+    assert m(scenes.DEFAULT, mode=_lib.BS_MODE_FAST | PNG) == 0
 
 
 def test_stale_library_is_refused_by_its_abi_version(tmp_path):

@@ -72,9 +72,10 @@ def test_emulated_encoder_writes_valid_png(name, img):
 
 
 def test_emulated_encoder_compresses_like_zlib_on_frames():
-    """Ratio is not the point of this encoder (distance-1 matches only, a code table per 8 KiB), but it must stay in zlib's neighbourhood
-    on what the renderer produces: at most 15 % above libpng + zlib level 1 and 70 % above level 6 on a frame-like image (a frame the
-    oracle rendered at 960x540 came out 13 % above level 6, 5 % above level 1), and far below the pixels on a black one."""
+    """Ratio is not the point of this encoder (distance-1 matches of at most 32 bytes, a code table per 8 KiB), but it must stay in
+    zlib's neighbourhood on what the renderer produces: at most 30 % above libpng + zlib level 1 and 90 % above level 6 on this
+    two-thirds-black frame-like image (its worst case: long runs; a frame the oracle rendered at 960x540 with bloom came out 15 %
+    above level 6 and 7 % above level 1), and far below the pixels on a black one."""
     import io
 
     from PIL import Image
@@ -86,9 +87,9 @@ def test_emulated_encoder_compresses_like_zlib_on_frames():
         b = io.BytesIO()
         Image.fromarray(img).save(b, format="PNG", compress_level=level)
         ref[level] = len(b.getvalue())
-    assert stats[1] == 0 and len(data) < 1.15 * ref[1] and len(data) < 1.7 * ref[6], (len(data), ref)
+    assert stats[1] == 0 and len(data) < 1.3 * ref[1] and len(data) < 1.9 * ref[6], (len(data), ref)
     black = np.zeros((540, 960, 3), np.uint8)
-    assert len(png_emul.encode(black)[0]) < black.size / 60
+    assert len(png_emul.encode(black)[0]) < black.size / 30
 
 
 def test_noise_falls_back_to_stored_blocks_within_bound():
@@ -223,6 +224,49 @@ def test_render_png_batch_equals_frame_by_frame(tree):
     with pytest.raises(bs._lib.BlackstarError, match="too small"):
         bs.render_png_batch(cfgs[:1], [tree], outs=[np.empty(100, np.uint8)])
     assert [bytes(g) for g in bs.render_png_batch(cfgs, [tree])] == want   # the context is usable after the refusal
+
+
+@pytest.mark.gpu
+def test_render_png_batch_at_full_size(tree):
+    """BASELINE's C3 frame (default-aa.yaml, 1920x1080, 4x supersampled) through bs_render_png_batch: every file is bs_render_png's, decodes
+    to bs_render_rgb8's pixels, and the chip is partitioned with 16 CUs for bloom + sRGB8 + the encoder (the cost model's choice);
+    the price of the file over the pixels (bs_render_rgb8_batch) stays below 8 %."""
+    import io
+    import time
+
+    from PIL import Image
+
+    import blackstar_amd as bs
+    import torch
+    cfg = scene("default-aa", 1920, 1080)
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the partition sizes are those of a 256-CU device")
+    from blackstar_amd import synthetic
+    full = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_FULL)))
+    try:
+        n = 8
+        want_px = bs.render_rgb8(cfg, full)
+        want = bytes(bs.render_png(cfg, full))
+        assert np.array_equal(np.array(Image.open(io.BytesIO(want)).convert("RGB")), want_px)
+        png = [bs.alloc_png(full, 1080, 1920) for _ in range(4)]
+        pix = [bs.alloc_image(full, 1080, 1920, dtype=np.uint8) for _ in range(4)]
+        times = {}
+        for name, fn, bufs in (("png", bs.render_png_batch, png), ("rgb8", bs.render_rgb8_batch, pix)):
+            outs = [bufs[i % 4] for i in range(n)]
+            res = fn([cfg] * n, [full], outs=outs)
+            if name == "png":
+                assert all(bytes(r) == want for r in res[-4:])
+                assert bs._lib.lib().bs_debug_last_post_cus(full.handle) == 16
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn([cfg] * n, [full], outs=outs)
+                best = min(best, (time.perf_counter() - t0) / n)
+            times[name] = best * 1e3
+        print(f"C3 per frame: PNG files {times['png']:.3f} ms ({len(want)} bytes each), RGB8 pixels {times['rgb8']:.3f} ms")
+        assert times["png"] < 1.08 * times["rgb8"]
+    finally:
+        full.close()
 
 
 @pytest.mark.gpu
