@@ -22,6 +22,7 @@ line carries, measured after the timed region (--form all, the default):
                        frames in flight per context), every frame delivered as RGB f64 into page-locked host memory (zero copy)
   with_d2h.rgb8_batch  bs_render_rgb8_batch: the reference's batch loop over doRender (app/Main.hs:68-77, :105-123) -- render,
                        bloom, sRGB8 on the device, only RGB8 leaves the GPU
+  with_d2h.png_batch   bs_render_png_batch: the same with writeImg's PNG encoder on the device too -- the finished FILE leaves the GPU
   sustained            500 more frames on one stream with per-50-frame times and sampled sclk / power (clock droop under the
                        package power cap is visible here, not in 20 launches)
 --catalogue clustered | PATH swaps the uniform synthetic sky for the non-uniform one or a real PPM catalogue file (reported as such).
@@ -241,9 +242,10 @@ def parse_args():
     ap.add_argument("--catalogue", default="synthetic",
                     help="synthetic (uniform 470k-star sky, the BASELINE input) | clustered (non-uniform: + clusters + a dense band) | "
                          "PATH of a real PPM catalogue file in the layout src/StarMap.hs:45-58 reads (reported separately)")
-    ap.add_argument("--form", choices=["all", "resident", "batch", "rgb8-batch"], default="all",
-                    help="`value` is the resident form (image stays in HBM) unless batch / rgb8-batch is named here; all (default) = resident "
-                         "as `value` plus the with_d2h block (bs_render_batch and bs_render_rgb8_batch into page-locked host memory)")
+    ap.add_argument("--form", choices=["all", "resident", "batch", "rgb8-batch", "png-batch"], default="all",
+                    help="`value` is the resident form (image stays in HBM) unless batch / rgb8-batch / png-batch is named here; all (default) = "
+                         "resident as `value` plus the with_d2h block (bs_render_batch, bs_render_rgb8_batch and bs_render_png_batch into "
+                         "page-locked host memory)")
     ap.add_argument("--sustained-frames", type=int, default=500, help="frames of the `sustained` leg after the timed region (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bs_render / bs_render_rgb8 / STRICT / ubench legs at N=1")
@@ -277,11 +279,23 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
     NOT part of the timed region.  Timed like the headline: fence, one blocking call, fence; max over ranks."""
     n_t = len(trees)
     res = {}
+    FORMS = {
+        "batch": dict(key="batch", entry="bs_render_batch", call=lambda fo, o: bs.render_batch(fo, trees, outs=o),
+                      alloc=lambda t: bs.alloc_image(t, H, W, dtype=np.float64), nbytes=lambda r: W * H * 3 * 8,
+                      note="RGB f64 frames written into page-locked host memory by the trace kernels themselves (zero copy), two frames in flight per context"),
+        "rgb8-batch": dict(key="rgb8_batch", entry="bs_render_rgb8_batch", call=lambda fo, o: bs.render_rgb8_batch(fo, trees, outs=o),
+                           alloc=lambda t: bs.alloc_image(t, H, W, dtype=np.uint8), nbytes=lambda r: W * H * 3,
+                           note="doRender on the device (render -> bloom -> sRGB8, app/Main.hs:105-123): only RGB8 reaches the host, two frames in flight per context"),
+        "png-batch": dict(key="png_batch", entry="bs_render_png_batch", call=lambda fo, o: bs.render_png_batch(fo, trees, outs=o),
+                          alloc=lambda t: bs.alloc_png(t, H, W), nbytes=lambda r: int(sum(len(f) for f in r) / max(len(r), 1)),
+                          note="doRender on the device to the end (render -> bloom -> sRGB8 -> PNG encoder, app/Main.hs:105-123 with writeImg's file format): "
+                               "the finished file is all that reaches the host (bytes_to_host_per_frame = its mean size); what is left for the host is write(2)"),
+    }
     for form in forms:
-        dtype = np.float64 if form == "batch" else np.uint8
-        rings = [[bs.alloc_image(t, H, W, dtype=dtype) for _ in range(4)] for t in trees]
+        F = FORMS[form]
+        rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
         outs = [rings[i % n_t][(i // n_t) % 4] for i in range(len(frame_objs))]
-        call = (lambda fo, o: bs.render_batch(fo, trees, outs=o)) if form == "batch" else (lambda fo, o: bs.render_rgb8_batch(fo, trees, outs=o))
+        call = F["call"]
         # untimed warm-up = the same call once: the contexts' second stream, device images and blur scratch get created, every ring
         # buffer is written once, and a one-off ~35 ms that the FIRST many-frame batch call of a process pays when no other timed work
         # preceded it (measured: 5.96 ms per frame in the first 20-frame call, 4.10-4.11 in the next three; profiles/EXPERIMENTS.md) is spent
@@ -295,19 +309,15 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                 print(f"[d2h {form} rep {rep}] {(time.perf_counter() - t0) / (len(frame_objs) / n_t) * 1e3:.3f} ms per frame per GPU", file=sys.stderr)
         fence()
         t0 = time.perf_counter()
-        call(frame_objs, outs)
+        got = call(frame_objs, outs)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         frames = len(frame_objs) * world // 1  # every rank runs the same number of frames
         per_gpu = len(frame_objs) / n_t
-        res["batch" if form == "batch" else "rgb8_batch"] = {
+        res[F["key"]] = {
             "Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
-            "bytes_to_host_per_frame": W * H * 3 * (8 if form == "batch" else 1),
-            "entry_point": "bs_render_batch" if form == "batch" else "bs_render_rgb8_batch",
-            "note": ("RGB f64 frames written into page-locked host memory by the trace kernels themselves (zero copy), two frames in flight per context"
-                     if form == "batch" else
-                     "doRender on the device (render -> bloom -> sRGB8, app/Main.hs:105-123): only RGB8 reaches the host, two frames in flight per context")}
-        del rings, outs
+            "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"]}
+        del rings, outs, got
     return res
 
 
@@ -629,7 +639,7 @@ def run_ranks(args):
         allt = all_ranks(dt_local)
         per_rank_ms = [t / args.steps * 1e3 for t in allt]
         dt = max(allt)  # MAX over ranks
-    else:  # --form batch | rgb8-batch: that form IS the timed region (warm-up inside d2h_forms, same fence discipline)
+    else:  # --form batch | rgb8-batch | png-batch: that form IS the timed region (warm-up inside d2h_forms, same fence discipline)
         for _ in range(max(1, args.warmup)):
             step()
         fence()
@@ -637,7 +647,7 @@ def run_ranks(args):
         t_gather = None
 
     d2h = None
-    want = {"all": ["batch", "rgb8-batch"], "resident": [], "batch": ["batch"], "rgb8-batch": ["rgb8-batch"]}[args.form]
+    want = {"all": ["batch", "rgb8-batch", "png-batch"], "resident": []}.get(args.form, [args.form])
     if want:
         d2h = optional_leg("with_d2h", world == 1 and resident,
                            lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x))))
@@ -679,7 +689,7 @@ def run_ranks(args):
         if resident:
             value = frames * W * H / dt / 1e6
         else:  # the named d2h form is the result
-            key = "batch" if args.form == "batch" else "rgb8_batch"
+            key = args.form.replace("-", "_")
             value, dt = d2h[key]["Mpixel_s"], d2h[key]["seconds"]
             kernel_ms = dt / args.steps * 1e3
             extra["image"] = d2h[key]["note"]
@@ -818,7 +828,7 @@ def run_single_process(args):
     st = trees[0].stats()
 
     d2h = None
-    want = {"all": ["batch", "rgb8-batch"], "resident": [], "batch": ["batch"], "rgb8-batch": ["rgb8-batch"]}[args.form]
+    want = {"all": ["batch", "rgb8-batch", "png-batch"], "resident": []}.get(args.form, [args.form])
     if want:  # frame i on context i % world, args.steps frames per context, ONE call over all contexts
         n = args.steps * world
         objs = [cfg_obj] * n if frames_obj is None else [frames_obj[i % len(frames_obj)] for i in range(n)]
@@ -842,7 +852,7 @@ def run_single_process(args):
              "devices_visible": ndev, "oversubscribed": world > ndev, "devices": devs, "launches_in_flight_per_gpu": n_streams,
              "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])]}
     if not resident:
-        key = "batch" if args.form == "batch" else "rgb8_batch"
+        key = args.form.replace("-", "_")
         value, dt = d2h[key]["Mpixel_s"], d2h[key]["seconds"]
         kernel_ms = dt / args.steps * 1e3
         per_rank_ms, kms = [kernel_ms] * world, None

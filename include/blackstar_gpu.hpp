@@ -179,4 +179,32 @@ inline std::vector<unsigned char> toSRGB8(const Image &img, const StarTree &tree
     return out;
 }
 
+// writeImg :: FilePath -> Image U RGB Double -> IO ()  (src/Raytracer.hs:29-32) minus the write: the bytes of the PNG file, its pixel
+// map AND its encoder on the device (massiv-io's writeImage spends 0.1-0.25 s of a host core on a 1080p frame)
+inline std::vector<unsigned char> encodeImg(const Image &img, const StarTree &tree)
+{
+    const std::vector<unsigned char> rgb8 = toSRGB8(img, tree);
+    size_t cap = 0, n = 0;
+    if (bs_png_bound(img.width, img.height, &cap)) throw std::runtime_error(std::string("bs_png_bound: ") + bs_last_error());
+    std::vector<unsigned char> file(cap);
+    if (bs_encode_png(tree.handle(), rgb8.data(), img.width, img.height, file.data(), cap, &n))
+        throw std::runtime_error(std::string("bs_encode_png: ") + bs_last_error());
+    file.resize(n);
+    return file;
+}
+
+// doRender (app/Main.hs:105-123) in one call: render, bloom when scene.bloomStrength /= 0, writeImg's pixel map and file format;
+// returns the bytes to write
+inline std::vector<unsigned char> renderPng(const Config &cfg, const StarTree &tree)
+{
+    const bs_config c = cfg.to_bs_config();
+    size_t cap = 0, n = 0;
+    if (bs_png_bound(c.width, c.height, &cap)) throw std::runtime_error(std::string("bs_png_bound: ") + bs_last_error());
+    std::vector<unsigned char> file(cap);
+    if (bs_render_png(tree.handle(), &c, cfg.scene.bloomStrength, cfg.scene.bloomDivider, file.data(), cap, &n))
+        throw std::runtime_error(std::string("bs_render_png: ") + bs_last_error());
+    file.resize(n);
+    return file;
+}
+
 }  // namespace blackstar

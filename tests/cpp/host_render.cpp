@@ -3,6 +3,7 @@
 // 96x54 (the golden fixture image_c3_default_aa_96x54) through blackstar::render and dumps raw doubles.
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "blackstar_gpu.hpp"
 
@@ -33,7 +34,16 @@ int main(int argc, char **argv)
             std::vector<Image> two = renderBatch({cfg, cfg}, {&tree});
             if (two.size() != 2 || two[0].rgb != img.rgb || two[1].rgb != img.rgb) return 7;
         }
-        if (argc > 3 && !std::strcmp(argv[3], "bloom")) img = bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img, tree);
+        if (argc > 3 && !std::strcmp(argv[3], "bloom")) {
+            img = bloom(cfg.scene.bloomStrength, cfg.scene.bloomDivider, img, tree);
+            // writeImg's file both ways: encodeImg of the bloomed image = renderPng of the scene (OUT.f64.png: checked by the caller)
+            const std::vector<unsigned char> file = encodeImg(img, tree);
+            if (file != renderPng(cfg, tree)) return 8;
+            FILE *g = std::fopen((std::string(argv[2]) + ".png").c_str(), "wb");
+            if (!g) return 3;
+            std::fwrite(file.data(), 1, file.size(), g);
+            std::fclose(g);
+        }
         FILE *f = std::fopen(argv[2], "wb");
         if (!f) return 3;
         std::fwrite(img.rgb.data(), sizeof(double), img.rgb.size(), f);

@@ -81,12 +81,22 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
             time.sleep(0.001)
             return outs
 
+        @staticmethod
+        def alloc_png(tree, h, w):
+            return np.zeros(h * w * 3 + 100, np.uint8)
+
+        @staticmethod
+        def render_png_batch(cfgs, trees, outs=None):
+            calls.append(("png", len(cfgs), len(trees), [id(o) for o in outs], outs[0].dtype))
+            return [memoryview(o)[:40 + i % 2] for i, o in enumerate(outs)]   # files of 40 and 41 bytes
+
     trees = ["t0", "t1", "t2"]
     frames = [f"cfg{i}" for i in range(30)]
     fences = []
-    res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch"], lambda: fences.append(1), lambda x: x)
-    assert set(res) == {"batch", "rgb8_batch"} and len(fences) == 4
-    assert [c[:3] for c in calls] == [("batch", 30, 3), ("batch", 30, 3), ("rgb8", 30, 3), ("rgb8", 30, 3)]  # warm-up call, timed call
+    res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch", "png-batch"], lambda: fences.append(1), lambda x: x)
+    assert set(res) == {"batch", "rgb8_batch", "png_batch"} and len(fences) == 6
+    assert [c[:3] for c in calls] == [("batch", 30, 3), ("batch", 30, 3), ("rgb8", 30, 3), ("rgb8", 30, 3), ("png", 30, 3), ("png", 30, 3)]  # warm-up call, timed call
+    assert res["png_batch"]["entry_point"] == "bs_render_png_batch" and res["png_batch"]["bytes_to_host_per_frame"] == 40   # the mean file size
     assert calls[1][4] == np.float64 and calls[3][4] == np.uint8
     ids = calls[1][3]
     assert len(set(ids)) == 12                                   # 4 buffers x 3 contexts

@@ -344,6 +344,9 @@ def test_cpp_host_mirror(tmp_path, oracle):
     subprocess.check_call([str(exe), os.path.join(root, "tests", "golden", "catalogue_2000.ppm"), str(out), "bloom"])
     bl = np.fromfile(out, np.float64).reshape(54, 96, 3)
     assert np.array_equal(bl, oracle.bloom(0.15, 25, img))
+    from tests.ghc_pin import decode_png_rgb8
+    with open(str(out) + ".png", "rb") as f:   # blackstar::encodeImg / renderPng (writeImg's file): decodes to the oracle's bytes
+        assert np.array_equal(decode_png_rgb8(f.read()), oracle.srgb8(bl))
 
 
 def test_render_rgb8_pipeline(tree, oracle, tmp_path):
@@ -522,6 +525,31 @@ def test_render_animation_single_rank(tree, tmp_path, oracle):
         exp = oracle.srgb8(oracle.bloom(anim.scene.bloomStrength, anim.scene.bloomDivider, img))
         assert np.array_equal(frames[i].numpy(), exp)
     assert not np.array_equal(frames[0].numpy(), frames[4].numpy())  # the camera moved
+    from tests.ghc_pin import decode_png_rgb8
+    for i in range(5):  # the files were encoded on the GPU (bs_encode_png): they decode to the frames that were returned
+        with open(tmp_path / f"ani_{i}.png", "rb") as f:
+            assert np.array_equal(decode_png_rgb8(f.read()), frames[i].numpy())
+
+
+def test_write_animation_files_only(tree, tmp_path):
+    """app/Animate.hs + batch mode end to end with nothing but files leaving the GPU (bs_render_png_batch): 37 frames (more than two
+    pipeline chunks of 16, so both sets of page-locked file buffers are reused), two ranks' shares written one after the other; every
+    file decodes to the frame bs_render_rgb8 gives for that camera."""
+    from blackstar_amd.distributed import shard_frames, write_animation
+    from tests.ghc_pin import decode_png_rgb8
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
+    anim.nFrames = 37
+    anim.scene.resolution = (64, 36)
+    paths = []
+    for rank in range(2):
+        paths.append(write_animation(anim, tree, str(tmp_path), rank=rank, world=2, basename="f"))
+        assert [os.path.basename(p) for p in paths[-1]] == [f"f_{i:02d}.png" for i in shard_frames(37, rank, 2)]
+    assert sorted(os.listdir(tmp_path)) == [f"f_{i:02d}.png" for i in range(37)]
+    cfgs = bs.generate_frames(anim)
+    for i in (0, 1, 15, 16, 17, 31, 32, 36):
+        with open(tmp_path / f"f_{i:02d}.png", "rb") as f:
+            assert np.array_equal(decode_png_rgb8(f.read()), bs.render_rgb8(cfgs[i], tree)), i
 
 
 def _random_scene(rng):
