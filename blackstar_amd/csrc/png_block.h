@@ -12,7 +12,8 @@
 //     stored block (zlib's Z_SYNC_FLUSH marker) so that it ends on a byte boundary, and travels in its own IDAT chunk -- blocks are
 //     independent: no bit-level concatenation, no cross-block CRC;
 //   * LZ77 is reduced to distance-1 matches (runs of one byte value): after the Sub / Up / Paeth filters a rendered frame is mostly
-//     runs of zeros, and a run needs no hash chains -- every lane tokenises its own 32 bytes from registers;
+//     runs of zeros, and a run needs no hash chains -- every lane tokenises its own 32 bytes from a 32-bit equality mask; a run that
+//     reaches the end of its lane continues through the next lanes of its group of eight (matches of up to 256 bytes);
 //   * code lengths: Shannon lengths ceil(log2(N / f)), clamped to the limit, repaired / filled to an exactly complete code in COUNT
 //     space (16 counters, one lane) and handed back to the symbols in frequency order -- everything per symbol (lengths, ranks,
 //     canonical codes) runs on all lanes;
@@ -69,6 +70,7 @@ struct Block {
     uint32_t data[kDataWords];
     uint16_t tok[kSeg * kLanes];   // token k of lane j at k * 256 + j: literal = byte value; match = 0x8000 | length (distance 1)
     uint32_t ntok[kLanes];
+    uint32_t eq[kLanes];           // bit k: byte k of the lane equals the byte before it (ph_runs)
     uint32_t lane_bits[kLanes], lane_off[kLanes];
     union {                        // the frequencies are dead once the Shannon lengths exist (ph_len_shannon); the words the token
         uint32_t freq[kLLPad];     // walks read are written two barriers later (ph_len_codes)
@@ -424,21 +426,19 @@ BS_HD uint32_t population(uint32_t v)
 #endif
 }
 
-// the lane's 32 bytes (8 words in registers) -> literals and distance-1 matches; symbol frequencies; Adler partial sums.
-// Bit k of E: byte k equals the byte before it.  Runs of three or more 1-bits become one match each (its first position carries
-// the token), every other byte is a literal: the tokens are found with a handful of shifts, then visited one set bit at a time.
-BS_HD void ph_tokenize(uint32_t lane, Block &S, const Args &, uint32_t)
+// Bit k of a lane's equality mask: byte k of its 32 equals the byte before it (the previous lane's last byte for k = 0).  Eight words in
+// registers, one SWAR zero-byte test per word; the Adler partial sums come from the same registers.
+BS_HD void ph_runs(uint32_t lane, Block &S, const Args &, uint32_t)
 {
     const uint32_t n = lane_bytes(S, lane);
-    if (n == 0) { S.ntok[lane] = 0; return; }
+    if (n == 0) { S.eq[lane] = 0; return; }
     const int prev = lane == 0 ? S.prev0 : (int)data_get(S, lane - 1, kSeg - 1);
-    uint32_t words[kSeg / 4];
-    for (uint32_t kw = 0; kw < (uint32_t)kSeg / 4; kw++) words[kw] = kw * 4 < n ? S.data[data_word(lane, kw)] : 0u;
-    uint32_t E = 0, a = 0, b = 0;
+    uint32_t E = 0, a = 0, b = 0, before_word = (uint32_t)(prev & 0xFF) << 24;
     const uint32_t weight0 = S.n_bytes - lane * kSeg;   // Adler weight of the lane's first byte: bytes from it to the end of the block
     for (uint32_t kw = 0; kw < (uint32_t)kSeg / 4; kw++) {
-        const uint32_t cur = words[kw];
-        const uint32_t before = (cur << 8) | (kw == 0 ? (uint32_t)(prev & 0xFF) : words[kw - 1] >> 24);
+        const uint32_t cur = kw * 4 < n ? S.data[data_word(lane, kw)] : 0u;
+        const uint32_t before = (cur << 8) | (before_word >> 24);
+        before_word = cur;
         uint32_t x = cur ^ before;                                     // a zero byte where a byte equals the one before
         x = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in exactly those bytes
         E |= (((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u)) << (4 * kw);
@@ -448,22 +448,59 @@ BS_HD void ph_tokenize(uint32_t lane, Block &S, const Args &, uint32_t)
             b += v * (weight0 - (4 * kw + u));
         }
     }
-    const uint32_t valid = n == 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
-    E &= valid;
+    E &= n == 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
     if (prev < 0) E &= ~1u;                                            // the stream's first byte has nothing before it
+    S.eq[lane] = E;
+    lds_add(&S.adler_a, a % kAdlerMod);
+    lds_add(&S.adler_b, b % kAdlerMod);
+}
+
+BS_HD uint32_t low_ones(uint32_t E) { return ~E ? count_trailing_zeros(~E) : 32u; }
+BS_HD uint32_t high_ones(uint32_t E)
+{
+    uint32_t t = 0;
+    while (t < 32 && ((E >> (31 - t)) & 1u)) t++;
+    return t;
+}
+
+// The lane's equality mask -> literals and distance-1 matches (runs of three or more 1-bits become one match each, every other byte a
+// literal: found with a handful of shifts, visited one set bit at a time), and the symbols' frequencies.
+// Runs cross lanes inside a group of kRunGroup = 8 lanes: a match that reaches the end of its lane takes over the leading 1-bits of the
+// lanes that follow (a lane that is ONE run hands on to the next), and those lanes drop the bytes they gave away -- matches of up to
+// 256 bytes instead of 32.  A group's first lane never gives bytes away, so nobody looks further than seven lanes.
+constexpr uint32_t kRunGroup = 8;
+BS_HD void ph_tokenize(uint32_t lane, Block &S, const Args &, uint32_t)
+{
+    const uint32_t n = lane_bytes(S, lane);
+    if (n == 0) { S.ntok[lane] = 0; return; }
+    const uint32_t E = S.eq[lane];
+    const uint32_t valid = n == 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
     const uint32_t third = E & (E << 1) & (E << 2);                    // third or later position of a run of 1-bits
     const uint32_t in_run = (third | (third >> 1) | (third >> 2)) & E; // every position of a run of three or more
     const uint32_t starts = in_run & ~(in_run << 1);
     uint32_t todo = (valid & ~in_run) | starts;
+    // bytes handed to the match that ends the lane before (it is a match if that lane ends in three or more 1-bits)
+    const uint32_t lead = low_ones(E);
+    const bool gives = lane % kRunGroup != 0 && lead > 0 && high_ones(S.eq[lane - 1]) >= 3;
+    if (gives) todo &= lead == 32 ? 0u : ~((1u << lead) - 1u);
+    // bytes taken over by this lane's last match, if it reaches the lane's end
+    uint32_t takes = 0;
+    if (n == 32 && (in_run >> 31))
+        for (uint32_t i = lane + 1; i % kRunGroup != 0 && lane_bytes(S, i) > 0; i++) {
+            const uint32_t l = low_ones(S.eq[i]);   // (a partial lane's mask has no bits beyond its bytes)
+            takes += l;
+            if (l < 32) break;
+        }
     const uint32_t nt = population(todo);
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(S.data);
     for (uint32_t i = 0; i < nt; i++) {
         const uint32_t k = count_trailing_zeros(todo);
         todo &= todo - 1;
         uint32_t tok, sym;
-        if ((starts >> k) & 1u) {
-            const uint32_t above = ~(in_run >> k);                     // its lowest set bit ends the run; none: all 32 bytes are one run
-            const uint32_t run = above ? count_trailing_zeros(above) : 32u;
+        if ((in_run >> k) & 1u) {                                      // (a set bit of todo inside a run is the run's first position --
+            const uint32_t above = ~(in_run >> k);                     //  or what is left of a leading run: then it was given away whole)
+            uint32_t run = above ? count_trailing_zeros(above) : 32u;  // the lowest 0 above k ends the run; none: it reaches bit 31
+            if (k + run == 32) run += takes;
             uint32_t eb, ev;
             length_code(run, sym, eb, ev);
             tok = 0x8000u | run;
@@ -474,9 +511,7 @@ BS_HD void ph_tokenize(uint32_t lane, Block &S, const Args &, uint32_t)
         S.tok[i * kLanes + lane] = (uint16_t)tok;
     }
     S.ntok[lane] = nt;
-    lds_add(&S.ntot, nt);
-    lds_add(&S.adler_a, a % kAdlerMod);
-    lds_add(&S.adler_b, b % kAdlerMod);
+    if (nt) lds_add(&S.ntot, nt);
     if (starts) lds_or(&S.has_match, 1u);
 }
 
@@ -792,7 +827,7 @@ BS_HD void ph_write(uint32_t lane, Block &S, const Args &A, uint32_t blk)
 
 // The phases of a block, in order: RUN(f) runs f on every lane, then a barrier.
 #define BS_PNG_BLOCK_PROGRAM(RUN, RUN_ALPHABET)                                                       \
-    RUN(ph_init) RUN(ph_load) RUN(ph_tokenize)                                                        \
+    RUN(ph_init) RUN(ph_load) RUN(ph_runs) RUN(ph_tokenize)                                                        \
     RUN_ALPHABET(ph_len_shannon, 0) RUN_ALPHABET(ph_len_rank, 0) RUN_ALPHABET(ph_len_counts, 0)       \
     RUN_ALPHABET(ph_len_assign, 0) RUN_ALPHABET(ph_len_codes, 0)                                      \
     RUN(ph_header_freq)                                                                               \

@@ -214,7 +214,8 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
  * choice, deflate with per-block dynamic Huffman codes, CRCs, Adler-32: blackstar_amd/csrc/png_block.h), so a frame crosses PCIe as
  * about 1 MB of file and the caller only has to write(2) it.  What the format guarantees is the DECODED image: every file decodes
  * (zlib, libpng, Pillow) to exactly the RGB8 frame bs_render_rgb8 returns; its bytes differ from JuicyPixels' like any two zlib versions'.
- * Files are 5-15 % larger than zlib level 6 on rendered frames (distance-1 matches only), never larger than bs_png_bound. */
+ * Files are about 4 % larger than libpng's at zlib level 1 and 14 % larger than at level 6 on rendered frames (distance-1 matches
+ * only), never larger than bs_png_bound. */
 
 /* Bytes a width x height RGB8 frame needs at most as a PNG file of this encoder (about 0.2 % above the pixels): the capacity every
  * out_png / d_png buffer below must have.  BS_EINVAL for non-positive sizes and frames above 1e9 pixels / files of 4 GiB. */
@@ -236,7 +237,7 @@ int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
                         const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
 
 /* Probe hook: bs_encode_png's block kernel with a shader-clock stamp (s_memtime) taken by every workgroup before its first phase and
- * after each of its 20 phases (blackstar_amd/csrc/png_block.h): clocks[b * 21 + p], b < ceil(height * (3 width + 1) / 8192).
+ * after each of its 21 phases (blackstar_amd/csrc/png_block.h): clocks[b * 22 + p], b < ceil(height * (3 width + 1) / 8192).
  * scripts/png_phase_probe.py turns them into the table in profiles/. */
 int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned long long *clocks, size_t n_clocks);
 

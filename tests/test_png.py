@@ -50,6 +50,13 @@ def cases():
     yield "frame-like 270x480", frame_like(270, 480, 2)
     yield "frame-like odd 37x23", frame_like(37, 23, 3)
     yield "two values, long runs", np.repeat(RNG.integers(0, 2, (64, 20, 3)) * 255, 40, axis=1).astype(np.uint8)
+    runs = np.zeros(3 * 7000, np.uint8)   # runs of every length 1 .. 300 (matches are cut at 256 bytes and at groups of eight lanes), at every lane phase
+    pos, length = 0, 1
+    while pos + length < runs.size:
+        runs[pos:pos + length] = 1 + (length % 250)
+        pos += length + (length % 3 == 0)   # sometimes a gap of one byte (value 0) between runs
+        length = length % 300 + 1
+    yield "runs of every length", runs.reshape(1, 7000, 3)
     yield "every byte value", np.arange(256 * 3 * 4, dtype=np.uint32).astype(np.uint8).reshape(4, 256, 3)
     g = load_golden("image_c3_default_aa_96x54") if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "image_c3_default_aa_96x54.npz")) else None
     if g is not None:
@@ -72,10 +79,10 @@ def test_emulated_encoder_writes_valid_png(name, img):
 
 
 def test_emulated_encoder_compresses_like_zlib_on_frames():
-    """Ratio is not the point of this encoder (distance-1 matches of at most 32 bytes, a code table per 8 KiB), but it must stay in
-    zlib's neighbourhood on what the renderer produces: at most 30 % above libpng + zlib level 1 and 90 % above level 6 on this
-    two-thirds-black frame-like image (its worst case: long runs; a frame the oracle rendered at 960x540 with bloom came out 15 %
-    above level 6 and 7 % above level 1), and far below the pixels on a black one."""
+    """Ratio is not the point of this encoder (distance-1 matches only, a code table per 8 KiB), but it must stay in zlib's neighbourhood
+    on what the renderer produces: at most 15 % above libpng + zlib level 1 and 70 % above level 6 on this two-thirds-black frame-like
+    image (its worst case: zlib finds the repeats between rows; a frame the oracle rendered at 960x540 with bloom came out 13 % above
+    level 6 and 5 % above level 1), and far below the pixels on a black one."""
     import io
 
     from PIL import Image
@@ -87,9 +94,40 @@ def test_emulated_encoder_compresses_like_zlib_on_frames():
         b = io.BytesIO()
         Image.fromarray(img).save(b, format="PNG", compress_level=level)
         ref[level] = len(b.getvalue())
-    assert stats[1] == 0 and len(data) < 1.3 * ref[1] and len(data) < 1.9 * ref[6], (len(data), ref)
+    assert stats[1] == 0 and len(data) < 1.15 * ref[1] and len(data) < 1.7 * ref[6], (len(data), ref)
     black = np.zeros((540, 960, 3), np.uint8)
-    assert len(png_emul.encode(black)[0]) < black.size / 30
+    assert len(png_emul.encode(black)[0]) < black.size / 60
+
+
+def fuzz_image(rng, case):
+    """An image of random shape made of runs, gradients and noise in random proportions (run lengths 1 .. 600, so matches are cut at 256
+    bytes, at groups of eight lanes, at blocks, at rows)."""
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 700))
+    flat = np.empty(h * w * 3, np.uint8)
+    pos = 0
+    while pos < flat.size:
+        n = int(min(flat.size - pos, rng.integers(1, 600 if case % 3 else 40)))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            flat[pos:pos + n] = rng.integers(0, 256)
+        elif kind == 1:
+            flat[pos:pos + n] = (np.arange(n) // int(rng.integers(1, 9)) + rng.integers(0, 256)) % 256
+        elif kind == 2:
+            flat[pos:pos + n] = rng.integers(0, 256, n)
+        else:
+            flat[pos:pos + n] = rng.integers(0, 2, n) * rng.integers(1, 256)
+        pos += n
+    return flat.reshape(h, w, 3)
+
+
+def test_emulated_encoder_seeded_fuzz():
+    """80 seeded images (fuzz_image): every file passes the strict reader and Pillow, whatever order the lanes of a phase run in."""
+    rng = np.random.default_rng(77)
+    for case in range(80):
+        img = fuzz_image(rng, case)
+        data, stats, _ = png_emul.encode(img, order=case % 4)
+        png_emul.check_file(data, img)
+        assert len(data) <= png_emul.bound(*img.shape[:2])
 
 
 def test_noise_falls_back_to_stored_blocks_within_bound():
@@ -143,6 +181,16 @@ def test_gpu_encoder_writes_the_emulations_bytes(tree, name, img):
     assert bytes(bs.encode_png(img, tree, out=buf)) == want
     assert tree.stats()["zero_copy"] == 1
     png_emul.check_file(got, img)
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_seeded_fuzz(tree):
+    """The same 80 seeded images on the GPU: the emulation's bytes, each one."""
+    import blackstar_amd as bs
+    rng = np.random.default_rng(77)
+    for case in range(80):
+        img = fuzz_image(rng, case)
+        assert bytes(bs.encode_png(img, tree)) == png_emul.encode(img)[0], (case, img.shape)
 
 
 @pytest.mark.gpu
