@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Soak of the pipelined host paths: many rounds of bs_render_batch / bs_render_rgb8_batch / multi-stream bs_render_device with
-random frame sizes, buffer kinds (pageable / page-locked) and bloom settings, every result compared byte for byte with the
-frame-by-frame blocking calls.  Looks for ordering bugs (streams, events, shared scratch) that a single test run might miss."""
+"""Soak of the pipelined host paths: many rounds of bs_render_batch / bs_render_rgb8_batch / bs_render_png_batch / multi-stream
+bs_render_device + bs_bloom_device + bs_encode_png_device with random frame sizes, buffer kinds (pageable / page-locked) and bloom
+settings, every result compared byte for byte with the frame-by-frame blocking calls (PNG files: with the bytes of bs_encode_png of
+the frame's pixels, and every tenth one decoded).  Looks for ordering bugs (streams, events, shared scratch) that a single test run might miss."""
 import copy
 import ctypes as C
 import os
@@ -14,6 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import blackstar_amd as bs  # noqa: E402
 from blackstar_amd import _lib, synthetic  # noqa: E402
+from tests.ghc_pin import decode_png_rgb8  # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -48,7 +50,13 @@ while time.time() < t_end:
     got8 = bs.render_rgb8_batch(cfgs, use, outs=outs8)
     outs = [bs.alloc_image(use[i % len(use)], *wf.shape[:2]) if rng.random() < 0.5 else np.zeros_like(wf) for i, wf in enumerate(want)]
     got = bs.render_batch([c.to_bs_config() for c in cfgs], use, outs=outs)
+    wantp = [bytes(bs.encode_png(w8, trees[0])) for w8 in want8]
+    outsp = [bs.alloc_png(use[i % len(use)], *w8.shape[:2]) if rng.random() < 0.5 else np.zeros(bs.png_bound(*w8.shape[:2]), np.uint8) for i, w8 in enumerate(want8)]
+    gotp = bs.render_png_batch(cfgs, use, outs=outsp)
     for i in range(n):
+        assert bytes(gotp[i]) == wantp[i], f"round {rounds}: png batch frame {i} differs ({cfgs[i].scene.resolution})"
+        if (checked + i) % 10 == 0:
+            assert np.array_equal(decode_png_rgb8(wantp[i]), want8[i]), f"round {rounds}: png of frame {i} does not decode to it"
         assert np.array_equal(got8[i], want8[i]), f"round {rounds}: rgb8 batch frame {i} differs ({cfgs[i].scene.resolution})"
         assert np.array_equal(got[i], want[i]), f"round {rounds}: f64 batch frame {i} differs"
     # the same frames enqueued on as many streams as frames, no synchronisation in between, plus bloom on each stream
@@ -61,10 +69,21 @@ while time.time() < t_end:
             hh, ww = d.shape[:2]
             _lib.check(L.bs_bloom_device(trees[0].handle, d.data_ptr(), d.data_ptr(), ww, hh, float(c.scene.bloomStrength), int(c.scene.bloomDivider),
                                          C.c_void_p(s.cuda_stream)), "bloom on a stream")
+    # ... and the PNG encoder enqueued on each stream behind them (one scratch per context: handed from stream to stream in order)
+    d8 = [torch.from_numpy(w8).cuda() for w8 in want8]
+    dp = [torch.zeros(bs.png_bound(*w8.shape[:2]), dtype=torch.uint8, device="cuda:0") for w8 in want8]
+    dn = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+    for i, s in enumerate(streams):
+        s.wait_stream(torch.cuda.current_stream())
+        hh, ww = want8[i].shape[:2]
+        _lib.check(L.bs_encode_png_device(trees[0].handle, d8[i].data_ptr(), ww, hh, dp[i].data_ptr(), dp[i].numel(), dn.data_ptr() + 8 * i,
+                                          C.c_void_p(s.cuda_stream)), "png on a stream")
     torch.cuda.synchronize()
+    for i in range(n):
+        assert bytes(dp[i][:int(dn[i].item())].cpu().numpy()) == wantp[i], f"round {rounds}: multi-stream png {i} differs"
     for i, (c, d) in enumerate(zip(cfgs, dev)):
         ref = want[i] if c.scene.bloomStrength == 0 else bs.bloom(float(c.scene.bloomStrength), int(c.scene.bloomDivider), want[i], trees[0])
         assert np.array_equal(d.cpu().numpy(), ref), f"round {rounds}: multi-stream frame {i} differs"
     rounds += 1
-    checked += 3 * n
+    checked += 5 * n
 print(f"soak: {rounds} rounds, {checked} frames compared, all identical, {seconds:.0f} s")
