@@ -317,6 +317,20 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
         res[F["key"]] = {
             "Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
             "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"]}
+        if form == "png-batch" and hasattr(bs, "render_rgb8"):
+            # what the same file costs the way the reference makes it (JuicyPixels over zlib, one core): this frame's pixels through zlib
+            # on ONE host core, the Sub-filtered scanlines at levels 1 and 6 -- a reported baseline like cpu_baseline, outside every timed region
+            import zlib
+            px = bs.render_rgb8(frame_objs[0], trees[0])
+            sub = px.copy()
+            sub[:, 1:] -= px[:, :-1]
+            raw = b"".join(b"\x01" + sub[y].tobytes() for y in range(px.shape[0]))
+            host = {}
+            for level in (1, 6):
+                t0 = time.perf_counter()
+                z = zlib.compress(raw, level)
+                host[f"zlib_level{level}"] = {"ms_per_frame_one_core": (time.perf_counter() - t0) * 1e3, "bytes": len(z)}
+            res[F["key"]]["host_encoder_baseline"] = host
         del rings, outs, got
     return res
 

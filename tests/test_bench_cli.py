@@ -82,6 +82,10 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
             return outs
 
         @staticmethod
+        def render_rgb8(cfg, tree):
+            return (np.arange(8 * 16 * 3) % 7).astype(np.uint8).reshape(8, 16, 3)
+
+        @staticmethod
         def alloc_png(tree, h, w):
             return np.zeros(h * w * 3 + 100, np.uint8)
 
@@ -97,6 +101,8 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     assert set(res) == {"batch", "rgb8_batch", "png_batch"} and len(fences) == 6
     assert [c[:3] for c in calls] == [("batch", 30, 3), ("batch", 30, 3), ("rgb8", 30, 3), ("rgb8", 30, 3), ("png", 30, 3), ("png", 30, 3)]  # warm-up call, timed call
     assert res["png_batch"]["entry_point"] == "bs_render_png_batch" and res["png_batch"]["bytes_to_host_per_frame"] == 40   # the mean file size
+    host = res["png_batch"]["host_encoder_baseline"]      # the same frame through zlib on one host core, beside the device encoder's number
+    assert set(host) == {"zlib_level1", "zlib_level6"} and all(v["bytes"] > 0 and v["ms_per_frame_one_core"] >= 0 for v in host.values())
     assert calls[1][4] == np.float64 and calls[3][4] == np.uint8
     ids = calls[1][3]
     assert len(set(ids)) == 12                                   # 4 buffers x 3 contexts
