@@ -318,6 +318,40 @@ def test_render_png_batch_at_full_size(tree):
 
 
 @pytest.mark.gpu
+def test_png_entry_points_refuse_bad_arguments(tree):
+    """BS_EINVAL (-1) with a message, nothing launched, the context usable afterwards: null pointers, buffers below bs_png_bound, frames
+    the encoder's 32-bit chunk offsets cannot hold, a bloom radius of 0, a bad configuration."""
+    import blackstar_amd as bs
+    from blackstar_amd import _lib
+    L = _lib.lib()
+    img = frame_like(20, 30, 1)
+    cap = bs.png_bound(20, 30)
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(123)
+    cfg = scene("default-aa", 30, 20)
+    c = _lib.make_config(cfg.to_bs_config())
+    cases = {
+        "encode: null image": lambda: L.bs_encode_png(tree.handle, None, 30, 20, out.ctypes.data, cap, C.byref(n)),
+        "encode: null out": lambda: L.bs_encode_png(tree.handle, img.ctypes.data, 30, 20, None, cap, C.byref(n)),
+        "encode: null size": lambda: L.bs_encode_png(tree.handle, img.ctypes.data, 30, 20, out.ctypes.data, cap, None),
+        "encode: small buffer": lambda: L.bs_encode_png(tree.handle, img.ctypes.data, 30, 20, out.ctypes.data, cap - 1, C.byref(n)),
+        "encode: width 0": lambda: L.bs_encode_png(tree.handle, img.ctypes.data, 0, 20, out.ctypes.data, cap, C.byref(n)),
+        "encode: too large": lambda: L.bs_encode_png(tree.handle, img.ctypes.data, 60000, 60000, out.ctypes.data, cap, C.byref(n)),
+        "render: small buffer": lambda: L.bs_render_png(tree.handle, C.byref(c), 0.2, 5, out.ctypes.data, cap - 1, C.byref(n)),
+        "render: bloom radius 0": lambda: L.bs_render_png(tree.handle, C.byref(c), 0.2, 1000, out.ctypes.data, cap, C.byref(n)),
+        "render: null cfg": lambda: L.bs_render_png(tree.handle, None, 0.2, 5, out.ctypes.data, cap, C.byref(n)),
+        "batch: null sizes": lambda: L.bs_render_png_batch((C.c_void_p * 1)(tree.handle), 1, C.byref(c), 1, None, None, (C.c_void_p * 1)(out.ctypes.data), (C.c_size_t * 1)(cap), None),
+        "phases: small clock buffer": lambda: L.bs_debug_png_phases(tree.handle, img.ctypes.data, 30, 20, out.ctypes.data, 3),
+    }
+    for name, call in cases.items():
+        assert call() == -1 and _lib.last_error(), name
+    assert n.value == 123 and not out.any()
+    c.fov = float("nan")
+    assert L.bs_render_png(tree.handle, C.byref(c), 0.0, 5, out.ctypes.data, cap, C.byref(n)) == -1 and "fov" in _lib.last_error()
+    assert bytes(bs.encode_png(img, tree)) == png_emul.encode(img)[0]
+
+
+@pytest.mark.gpu
 def test_encode_png_device_is_enqueue_only(tree):
     """bs_encode_png_device on torch tensors and a torch stream: the file and its size appear once the stream has passed."""
     import torch
