@@ -505,3 +505,18 @@ def test_ghc_pin_kit_is_complete_and_consistent():
     stanza = open(os.path.join(root, "run.sh")).read()
     for dep in ("blackstar", "cereal", "yaml", "kdt", "massiv-io"):
         assert dep in stanza
+    # the FFI shim: INTEGRATION.md quotes tools/ghc_pin/RaytracerFFI.hs verbatim; it binds entry points the header declares, expects
+    # the header's ABI version, and run.sh type-checks it where GHC exists
+    import re
+    repo = os.path.dirname(os.path.dirname(root))
+    shim = open(os.path.join(root, "RaytracerFFI.hs")).read()
+    quoted = [m.group(1) for m in re.finditer(r"```haskell\n(.*?)```", open(os.path.join(repo, "INTEGRATION.md")).read(), re.S)]
+    assert shim in quoted
+    header = open(os.path.join(repo, "include", "blackstar_gpu.h")).read()
+    bound = re.findall(r'foreign import ccall (?:safe|unsafe)\s+"&?(bs_\w+)"', shim)
+    assert len(bound) >= 9 and all(re.search(r"\b%s\(" % b, header) for b in bound), bound
+    version = re.search(r"#define BS_ABI_VERSION (\d+)", header).group(1)
+    assert f"this shim expects {version}" in shim and "RaytracerFFI.hs" in stanza and "-fno-code" in stanza
+    verdict = os.path.join(repo, "tests", "golden", "ghc", "shim_typecheck.txt")
+    if os.path.exists(verdict):
+        assert open(verdict).read().strip() == "OK", "the shim did not type-check against the reference (tests/golden/ghc/shim_typecheck.log)"

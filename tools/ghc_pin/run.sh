@@ -29,4 +29,11 @@ for set in uniform clustered; do
   mkdir -p "$REPO/tests/golden/ghc"
   rm -rf "$REPO/tests/golden/ghc/$set" && cp -r "$REF/tools/ghc_pin/out/$set" "$REPO/tests/golden/ghc/$set"
 done
+# the FFI shim of INTEGRATION.md section 1: type-checked against the reference's own modules (no GPU, no library needed for that)
+cp "$HERE/RaytracerFFI.hs" "$REF/tools/ghc_pin/RaytracerFFI.hs"
+if (cd "$REF" && stack ghc -- -fno-code -isrc tools/ghc_pin/RaytracerFFI.hs) > "$REPO/tests/golden/ghc/shim_typecheck.log" 2>&1; then
+  echo "OK" > "$REPO/tests/golden/ghc/shim_typecheck.txt"
+else
+  echo "FAILED (see shim_typecheck.log)" > "$REPO/tests/golden/ghc/shim_typecheck.txt"
+fi
 echo "dumps are in $REPO/tests/golden/ghc/ -- now: python -m pytest tests/test_oracle.py -k reference_itself -rs"
