@@ -114,10 +114,11 @@ def _png_bound(height, width):
     return png_bound(height, width)
 
 
-def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1, basename: str = "frame") -> "list[str]":
+def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1, basename: str = "frame", pipe: int = 32) -> "list[str]":
     """app/Animate.hs + blackstar's batch mode (app/Main.hs:68-77) for one animation: frame i on rank i % world, each rendered, bloomed,
     mapped to sRGB8 and ENCODED AS A PNG FILE on the device (`bs_render_png_batch`); the host only writes the files' bytes
-    (`<basename>_<zero-padded index>.png`).  No collective, no pixels on the host.  Returns the paths this rank wrote."""
+    (`<basename>_<zero-padded index>.png`).  No collective, no pixels on the host.  `pipe` frames go through one bs_render_png_batch
+    call (the GPU idles for a moment between calls; two sets of `pipe` page-locked file buffers are kept).  Returns the paths this rank wrote."""
     import os
     from concurrent.futures import ThreadPoolExecutor
 
@@ -130,7 +131,7 @@ def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1
     width = len(str(max(len(frames) - 1, 1)))
     os.makedirs(out_dir, exist_ok=True)
     mine = shard_frames(len(frames), rank, world)
-    kPipe = 16
+    kPipe = max(1, int(pipe))
     paths, pending = [], []
 
     def write_file(path, data):

@@ -532,9 +532,9 @@ def test_render_animation_single_rank(tree, tmp_path, oracle):
 
 
 def test_write_animation_files_only(tree, tmp_path):
-    """app/Animate.hs + batch mode end to end with nothing but files leaving the GPU (bs_render_png_batch): 37 frames (more than two
-    pipeline chunks of 16, so both sets of page-locked file buffers are reused), two ranks' shares written one after the other; every
-    file decodes to the frame bs_render_rgb8 gives for that camera."""
+    """app/Animate.hs + batch mode end to end with nothing but files leaving the GPU (bs_render_png_batch): 37 frames, 5 per call (four
+    calls per rank, so both sets of page-locked file buffers are reused while the writer thread drains the other), two ranks' shares
+    written one after the other; every file decodes to the frame bs_render_rgb8 gives for that camera."""
     from blackstar_amd.distributed import shard_frames, write_animation
     from tests.ghc_pin import decode_png_rgb8
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -543,7 +543,7 @@ def test_write_animation_files_only(tree, tmp_path):
     anim.scene.resolution = (64, 36)
     paths = []
     for rank in range(2):
-        paths.append(write_animation(anim, tree, str(tmp_path), rank=rank, world=2, basename="f"))
+        paths.append(write_animation(anim, tree, str(tmp_path), rank=rank, world=2, basename="f", pipe=5))
         assert [os.path.basename(p) for p in paths[-1]] == [f"f_{i:02d}.png" for i in shard_frames(37, rank, 2)]
     assert sorted(os.listdir(tmp_path)) == [f"f_{i:02d}.png" for i in range(37)]
     cfgs = bs.generate_frames(anim)
