@@ -36,6 +36,10 @@ uint64_t png_emul_bound(int w, int h) { return file_bound(w, h); }
 
 // rgb: h * w * 3 bytes.  out: at least png_emul_bound(w, h) bytes.  filters (optional): receives the h filter types chosen.
 // stats (optional): [0] blocks, [1] blocks emitted as stored.
+// tables (optional): per block 2 * 286 words -- the literal/length frequencies, then the code lengths chosen for them
+static uint32_t *g_tables = nullptr;
+void png_emul_set_tables(uint32_t *tables) { g_tables = tables; }
+
 int png_emul_encode(const uint8_t *rgb, int w, int h, uint8_t *out, uint64_t cap, uint64_t *out_bytes, int order, uint8_t *filters, uint32_t *stats)
 {
     if (!rgb || !out || !out_bytes || w <= 0 || h <= 0 || cap < file_bound(w, h)) return -1;
@@ -59,12 +63,15 @@ int png_emul_encode(const uint8_t *rgb, int w, int h, uint8_t *out, uint64_t cap
     for (uint32_t blk = 0; blk < A.n_blocks; blk++) {
         std::memset(S.get(), 0xCD, sizeof(Block));   // LDS is not zeroed on the GPU either
         uint32_t phase = 0;
-#define RUN(f) { for (uint32_t lane : lane_order(order, blk * 64 + phase)) f(lane, *S, A, blk); phase++; }
-#define RUN_ALPHABET(f, which) { for (uint32_t lane : lane_order(order, blk * 64 + phase)) f(lane, *S, which); phase++; }
+#define RUN(f) { for (uint32_t lane : lane_order(order, blk * 64 + phase)) { f(lane, *S, A, blk); } phase++; }
+#define RUN_ALPHABET(f, which) { if (g_tables && phase == 4) { for (int i = 0; i < kLL; i++) g_tables[(size_t)blk * 2 * kLL + i] = S->freq[i]; } \
+                                 for (uint32_t lane : lane_order(order, blk * 64 + phase)) { f(lane, *S, which); } \
+                                 phase++; }
         BS_PNG_BLOCK_PROGRAM(RUN, RUN_ALPHABET)
 #undef RUN
 #undef RUN_ALPHABET
         n_stored += !S->use_dyn;
+        if (g_tables) for (int i = 0; i < kLL; i++) g_tables[(size_t)blk * 2 * kLL + kLL + i] = S->len[i];
     }
     uint64_t file_bytes = 0;
     FinishArgs FA{sizes.data(), adler.data(), offsets.data(), A.n_blocks, A.total, w, h, out, &file_bytes};
