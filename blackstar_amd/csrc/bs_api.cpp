@@ -120,7 +120,7 @@ struct bs_ctx {
     // writeImg's PNG encoder on the device (png_kernels.hip): per frame in flight its scratch (filter types, chunk sizes / offsets, staging
     // slots), a device copy of the file for callers with pageable buffers, and the file's size in page-locked memory
     static constexpr int kPngSlots = 3;
-    void *d_png_scratch[kPngSlots] = {nullptr, nullptr, nullptr};
+    unsigned char *d_png_scratch[kPngSlots] = {nullptr, nullptr, nullptr};
     size_t png_scratch_cap[kPngSlots] = {0, 0, 0};
     unsigned char *d_png_file[kPngSlots] = {nullptr, nullptr, nullptr};
     size_t png_file_cap[kPngSlots] = {0, 0, 0};
@@ -503,7 +503,7 @@ void bs_destroy(bs_ctx *ctx)
         if (ctx->d_u8b) (void)hipFree(ctx->d_u8b);
         if (ctx->d_u8c) (void)hipFree(ctx->d_u8c);
         if (ctx->d_img3) (void)hipFree(ctx->d_img3);
-        for (void *b : ctx->d_png_scratch)
+        for (unsigned char *b : ctx->d_png_scratch)
             if (b) (void)hipFree(b);
         for (unsigned char *b : ctx->d_png_file)
             if (b) (void)hipFree(b);
@@ -748,7 +748,7 @@ int bs_png_bound(int width, int height, size_t *out_bytes)
 // of the file for a caller whose buffer the GPU cannot write.
 static int ensure_png(bs_ctx *ctx, int k, int w, int h, bool device_file)
 {
-    if (!grow_device(reinterpret_cast<unsigned char *&>(ctx->d_png_scratch[k]), ctx->png_scratch_cap[k], bs::png_scratch_bytes(w, h)))
+    if (!grow_device(ctx->d_png_scratch[k], ctx->png_scratch_cap[k], bs::png_scratch_bytes(w, h)))
         return fail(BS_ENOMEM, "hipMalloc PNG scratch failed");
     if (device_file && !grow_device(ctx->d_png_file[k], ctx->png_file_cap[k], (size_t)bs::png_file_bound(w, h)))
         return fail(BS_ENOMEM, "hipMalloc PNG file failed");
