@@ -318,6 +318,43 @@ def test_render_png_batch_at_full_size(tree):
 
 
 @pytest.mark.gpu
+def test_render_scene_directory_is_the_references_batch_mode(tree, tmp_path):
+    """app/Main.hs:64-77: every *.yaml of a directory, sorted, to <out>/<name>.png; an undecodable scene is reported and skipped; preview
+    mode = prepareScene (300-px long side, no supersampling, no bloom, `prev-` prefix).  Files decode to bs_render_rgb8 of the scene."""
+    import shutil
+
+    import blackstar_amd as bs
+    from tests.ghc_pin import decode_png_rgb8
+    src = tmp_path / "scenes"
+    src.mkdir()
+    for name in ("default-aa", "lensing-disk", "closeup"):
+        text = open(os.path.join(SCENES, name + ".yaml")).read()
+        (src / (name + ".yaml")).write_text(text)
+    (src / "broken.yaml").write_text("scene: {stepSize: 'abc'}\ncamera: 3\n")
+    (src / "notes.txt").write_text("not a scene")
+    small = {}
+    for name in ("default-aa", "lensing-disk", "closeup"):   # keep the test quick: the scenes at 1/10 of their resolution
+        cfg = bs.Config.from_file(str(src / (name + ".yaml")))
+        w, h = cfg.scene.resolution
+        small[name] = cfg.with_resolution(max(w // 10, 8), max(h // 10, 8))
+        import yaml
+        d = yaml.safe_load(open(src / (name + ".yaml")))
+        d["scene"]["resolution"] = list(small[name].scene.resolution)
+        (src / (name + ".yaml")).write_text(yaml.safe_dump(d))
+        small[name] = bs.Config.from_file(str(src / (name + ".yaml")))
+    out = tmp_path / "out"
+    paths = bs.render_scene_directory(str(src), str(out), [tree])
+    assert [os.path.basename(p) for p in paths] == ["closeup.png", "default-aa.png", "lensing-disk.png"] and sorted(os.listdir(out)) == sorted(os.path.basename(p) for p in paths)
+    for name, cfg in small.items():
+        assert np.array_equal(decode_png_rgb8(open(out / (name + ".png"), "rb").read()), bs.render_rgb8(cfg, tree)), name
+    prev = bs.render_scene_directory(str(src), str(out), [tree], preview=True)
+    assert [os.path.basename(p) for p in prev] == ["prev-closeup.png", "prev-default-aa.png", "prev-lensing-disk.png"]
+    img = decode_png_rgb8(open(out / "prev-default-aa.png", "rb").read())
+    assert max(img.shape[:2]) == 300 and np.array_equal(img, bs.render_rgb8(bs.prepare_scene(small["default-aa"], True), tree))
+    shutil.rmtree(out)
+
+
+@pytest.mark.gpu
 def test_png_entry_points_refuse_bad_arguments(tree):
     """BS_EINVAL (-1) with a message, nothing launched, the context usable afterwards: null pointers, buffers below bs_png_bound, frames
     the encoder's 32-bit chunk offsets cannot hold, a bloom radius of 0, a bad configuration."""
