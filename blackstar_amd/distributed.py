@@ -138,8 +138,9 @@ def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1
         with open(path, "wb") as f:
             f.write(data)
 
-    # two sets of page-locked file buffers: while the writer thread drains one set, the GPU fills the other
-    sets = [None, None]
+    # two sets of page-locked file buffers: while the writer thread drains one set, the GPU fills the other.  Page-locking costs
+    # 1-2 ms per 6 MB buffer, so the sets stay with the tree for the next call (they are freed with it).
+    cache = tree.__dict__.setdefault("_png_file_buffers", {})
     with ThreadPoolExecutor(max_workers=1) as pool:
         for n, pos in enumerate(range(0, len(mine), kPipe)):
             chunk = mine[pos:pos + kPipe]
@@ -147,10 +148,14 @@ def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1
             k = n & 1
             if len(pending) > 1:
                 pending.pop(0).result()  # the set about to be reused has been written out (a failed write raises here)
-            need = [_png_bound(c.scene.resolution[1], c.scene.resolution[0]) for c in cfgs]
-            if sets[k] is None or len(sets[k]) < len(cfgs) or any(b.size < m for b, m in zip(sets[k], need)):
-                sets[k] = [alloc_png(tree, c.scene.resolution[1], c.scene.resolution[0]) for c in cfgs]
-            files = render_png_batch(cfgs, [tree], outs=sets[k][:len(cfgs)])
+            bufs = []
+            for slot, c in enumerate(cfgs):
+                key = (k, slot)
+                need = _png_bound(c.scene.resolution[1], c.scene.resolution[0])
+                if key not in cache or cache[key].size < need:
+                    cache[key] = alloc_png(tree, c.scene.resolution[1], c.scene.resolution[0])
+                bufs.append(cache[key])
+            files = render_png_batch(cfgs, [tree], outs=bufs)
             names = [os.path.join(out_dir, f"{basename}_{j:0{width}d}.png") for j in chunk]
             paths.extend(names)
             pending.append(pool.submit(lambda fs=files, ns=names: [write_file(p, d) for p, d in zip(ns, fs)]))
