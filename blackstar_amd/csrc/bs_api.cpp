@@ -842,7 +842,7 @@ int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int h
     if (!ctx || !rgb8 || !clocks) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     const size_t nb = bs::png_block_count(width, height);
-    if (n_clocks < nb * bs::kPngPhases) return fail(BS_EINVAL, "clocks: blocks * 22 entries are required (blocks = ceil(height * (3 width + 1) / 8192))");
+    if (n_clocks < nb * bs::kPngPhases) return fail(BS_EINVAL, "clocks: blocks * 23 entries are required (blocks = ceil(height * (3 width + 1) / 8192))");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t)width * height * 3;
     if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");

@@ -118,7 +118,7 @@ uint64_t png_file_bound(int w, int h);   // bytes a w x h RGB8 frame can take at
 size_t png_scratch_bytes(int w, int h);  // device scratch one encode needs
 double estimate_png_us(int w, int h, int cus);  // microseconds the encoder's kernels take on `cus` CUs (model; < 0: no estimate)
 size_t png_block_count(int w, int h);     // 8 KiB blocks of the filtered stream = workgroups of the encoding kernel
-constexpr int kPngPhases = 22;            // clock stamps per block of the profiling variant: before the first phase, after each of the 21
+constexpr int kPngPhases = 23;            // clock stamps per block of the profiling variant: before the first phase, after each of the 22
 int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream,
                       unsigned long long *d_clocks = nullptr);
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);

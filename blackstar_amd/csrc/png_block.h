@@ -17,8 +17,8 @@
 //   * code lengths: Shannon lengths ceil(log2(N / f)), clamped to the limit, repaired / filled to an exactly complete code in COUNT
 //     space (16 counters, one lane) and handed back to the symbols in frequency order -- everything per symbol (lengths, ranks,
 //     canonical codes) runs on all lanes;
-//   * the block header codes every code length by itself (no run symbols 16-18): about 25 bytes per block more than zlib's run-length
-//     coded header (0.3 %), and every position of the header can be costed and emitted by its own lane;
+//   * the block header is decided per POSITION: a non-zero code length is its own symbol, a run of zero lengths is found on a bit mask
+//     and coded by the run symbols 17 / 18 at its pieces' first positions -- every position is costed and emitted by its own lane;
 //   * prefix sums (bit offsets of the lanes, of the header's symbols) are each lane summing what lies before it -- sums of groups of 16
 //     (accumulated with LDS atomics where the values are produced), then its 15 neighbours: about 30 LDS reads, no log-step scans, no
 //     extra barriers; ranks among equal code lengths are counted four bytes per read;
@@ -49,6 +49,7 @@ constexpr int kStoredMax = 5 + kBlock;    // data bytes of a stored block
 constexpr int kOutWords = (kStoredMax + 3) / 4 + 2;
 constexpr int kSlot = 8224;               // staging bytes per block: 4 length + 4 type + <= 8197 data + 4 crc, rounded up to 32
 constexpr int kHdrMax = 288;              // positions of a block header: <= 286 literal/length lengths + 1 distance length
+constexpr uint32_t kHdrNone = 0xFF;
 constexpr int kGroup = 16;                // prefix sums go in two levels: sums of groups of 16, then the 15 neighbours
 constexpr uint32_t kAdlerMod = 65521;
 constexpr uint32_t kHeadBytes = 8 + 25 + 14;   // signature, IHDR chunk, IDAT chunk holding the 2-byte zlib header
@@ -83,7 +84,10 @@ struct Block {
     uint8_t cl_len0[kCLPad], cl_len[kCLPad];
     uint16_t cl_rank0[kCLPad], cl_code[kCLPad];
     uint32_t cnt0[2][16], cum0[2][17], cumf[2][17], next_code[2][17], nused[2];
-    uint8_t hdr_cost[kHdrMax];     // bits of header position i (the code of its length in the code-length code)
+    uint8_t hdr_cost[kHdrMax];     // bits header position i contributes (0: it lies inside a run of zeros another position codes)
+    uint8_t hdr_tok[kHdrMax], hdr_ext[kHdrMax];   // its code-length symbol (0..15, 17, 18; kHdrNone: none) and the run symbols' extra bits
+    uint32_t hdr_zero[kHdrMax / 32];               // bit i: the length at header position i is 0
+    uint32_t nhdr;                                 // code-length symbols in the header
     uint32_t lane_gsum[kLanes / kGroup], hdr_gsum[kHdrMax / kGroup];   // the same summed over groups of 16 lanes / positions
     uint32_t hlit_n, hclen_n;
     uint32_t out[kOutWords];
@@ -333,6 +337,7 @@ BS_HD void ph_init(uint32_t lane, Block &S, const Args &A, uint32_t blk)
     for (uint32_t i = lane; i < (uint32_t)kOutWords; i += kLanes) S.out[i] = 0;
     if (lane < (uint32_t)(kLanes / kGroup)) { S.lane_gsum[lane] = 0; S.crc_group[lane] = 0; S.crc_p[lane] = crc_seg_pow(lane); S.crc_q[lane] = crc_group_pow(lane); }
     if (lane < (uint32_t)(kHdrMax / kGroup)) S.hdr_gsum[lane] = 0;
+    if (lane < (uint32_t)(kHdrMax / 32)) S.hdr_zero[lane] = 0;
     if (lane < (uint32_t)kCLPad) {
         S.cl_freq[lane] = 0; S.cl_len0[lane] = 0; S.cl_len[lane] = 0; S.cl_rank0[lane] = 0; S.cl_code[lane] = 0;
         S.cnt0[lane >> 4][lane & 15] = 0;
@@ -342,7 +347,7 @@ BS_HD void ph_init(uint32_t lane, Block &S, const Args &A, uint32_t blk)
         const uint64_t left = A.total - first;
         S.n_bytes = left < (uint64_t)kBlock ? (uint32_t)left : (uint32_t)kBlock;
         S.ntot = 0; S.has_match = 0; S.nused[0] = 0; S.nused[1] = 0; S.crc = 0;
-        S.adler_a = 0; S.adler_b = 0; S.hlit_n = 257; S.hdr_bits = 0; S.tok_bits = 0;
+        S.adler_a = 0; S.adler_b = 0; S.hlit_n = 257; S.hdr_bits = 0; S.tok_bits = 0; S.nhdr = 0;
         S.prev0 = -1;
         if (first > 0) {
             const uint64_t p = first - 1;
@@ -523,7 +528,7 @@ struct Alphabet {
 BS_HD Alphabet alphabet(Block &S, int which)
 {
     if (which == 0) return Alphabet{S.freq, S.len0, S.len, S.rank0, S.code, (uint32_t)kLL, 15u, S.ntot + 1u};
-    return Alphabet{S.cl_freq, S.cl_len0, S.cl_len, S.cl_rank0, S.cl_code, (uint32_t)kCL, 7u, S.hlit_n + 1u};
+    return Alphabet{S.cl_freq, S.cl_len0, S.cl_len, S.cl_rank0, S.cl_code, (uint32_t)kCL, 7u, S.nhdr};
 }
 
 // (1) Shannon length of every used symbol: the smallest l with f 2^l >= N, clamped to [1, limit]
@@ -643,11 +648,64 @@ BS_HD void ph_len_codes(uint32_t lane, Block &S, int which)
 BS_HD uint32_t header_value(const Block &S, uint32_t i) { return i < S.hlit_n ? S.len[i] : (S.has_match ? 1u : 0u); }
 BS_HD uint32_t header_positions(const Block &S) { return S.hlit_n + 1; }
 
-// how often each length occurs in the header: the frequencies of the code-length alphabet (every position is its own symbol)
-BS_HD void ph_header_freq(uint32_t lane, Block &S, const Args &, uint32_t)
+// which header positions hold a zero length (runs of them are coded by the symbols 17 and 18)
+BS_HD void ph_header_zeros(uint32_t lane, Block &S, const Args &, uint32_t)
 {
     const uint32_t n = header_positions(S);
-    for (uint32_t i = lane; i < n; i += kLanes) lds_add(&S.cl_freq[header_value(S, i)], 1);
+    for (uint32_t i = lane; i < n; i += kLanes)
+        if (header_value(S, i) == 0) lds_or(&S.hdr_zero[i >> 5], 1u << (i & 31));
+}
+
+BS_HD uint32_t count_leading_zeros(uint32_t v)   // v != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clz((int)v);
+#else
+    return (uint32_t)__builtin_clz(v);
+#endif
+}
+
+// The header as code-length symbols (RFC 1951, 3.2.7), one decision per position: a non-zero length is its own symbol; a run [a, b) of
+// zero lengths is cut into pieces of 138 from its start -- a piece of 11..138 is ONE symbol 18 (7 extra bits) carried by the piece's
+// first position, 3..10 one symbol 17 (3 extra bits), 1..2 literal zeros; the other positions of a piece carry nothing.  The run
+// around a position is found on the bit mask of zero lengths, a word at a time.  (Symbol 16, "repeat the previous length", is not used.)
+BS_HD void ph_header_tokens(uint32_t lane, Block &S, const Args &, uint32_t)
+{
+    const uint32_t n = header_positions(S);
+    for (uint32_t i = lane; i < n; i += kLanes) {
+        const uint32_t v = header_value(S, i);
+        uint32_t tok = v, ext = 0;
+        if (v == 0) {
+            uint32_t a = i;                                   // the run's first position: below it a non-zero length, or nothing
+            while (a > 0) {
+                const uint32_t off = (a - 1) & 31;
+                const uint32_t m = ~S.hdr_zero[(a - 1) >> 5] << (31 - off);   // bit 31: position a - 1 is NOT zero, bit 30: a - 2, ...
+                if (m) { a -= count_leading_zeros(m); break; }
+                a -= off + 1;
+            }
+            uint32_t b = i + 1;                               // one past the run's last position (mask bits at or beyond n are 0)
+            while (b < n) {
+                const uint32_t off = b & 31;
+                const uint32_t m = ~S.hdr_zero[b >> 5] >> off;                 // bit 0: position b is NOT zero
+                if (m) { b += count_trailing_zeros(m); break; }
+                b += 32 - off;
+            }
+            if (b > n) b = n;
+            const uint32_t p0 = a + (i - a) / 138 * 138;
+            const uint32_t plen = b - p0 < 138 ? b - p0 : 138;
+            if (plen >= 3) {
+                if (i != p0) tok = kHdrNone;
+                else if (plen >= 11) { tok = 18; ext = plen - 11; }
+                else { tok = 17; ext = plen - 3; }
+            }
+        }
+        S.hdr_tok[i] = (uint8_t)tok;
+        S.hdr_ext[i] = (uint8_t)ext;
+        if (tok != kHdrNone) {
+            lds_add(&S.cl_freq[tok], 1);
+            lds_add(&S.nhdr, 1);
+        }
+    }
 }
 
 BS_HD uint32_t cl_order(uint32_t i)
@@ -676,10 +734,13 @@ BS_HD void ph_bitcount(uint32_t lane, Block &S, const Args &, uint32_t)
     }
     const uint32_t n = header_positions(S);
     for (uint32_t i = lane; i < n; i += kLanes) {
-        const uint32_t c = S.cl_len[header_value(S, i)];
+        const uint32_t t = S.hdr_tok[i];
+        const uint32_t c = t == kHdrNone ? 0u : S.cl_len[t] + (t == 17 ? 3u : t == 18 ? 7u : 0u);
         S.hdr_cost[i] = (uint8_t)c;
-        lds_add(&S.hdr_bits, c);
-        lds_add(&S.hdr_gsum[i / kGroup], c);
+        if (c) {
+            lds_add(&S.hdr_bits, c);
+            lds_add(&S.hdr_gsum[i / kGroup], c);
+        }
     }
     if (lane == 0) {
         uint32_t hc = kCL;
@@ -764,9 +825,12 @@ BS_HD void ph_emit(uint32_t lane, Block &S, const Args &, uint32_t)
         uint32_t off = 3 + 5 + 5 + 4 + 3 * S.hclen_n;
         for (uint32_t g = 0; g < i / kGroup; g++) off += S.hdr_gsum[g];
         for (uint32_t j = i / kGroup * kGroup; j < i; j++) off += S.hdr_cost[j];
-        const uint32_t v = header_value(S, i);
+        const uint32_t t = S.hdr_tok[i];
+        if (t == kHdrNone) continue;
         BitWriter bh(S.out, off);
-        bh.put(S.cl_code[v], S.cl_len[v]);
+        bh.put(S.cl_code[t], S.cl_len[t]);
+        if (t == 17) bh.put(S.hdr_ext[i], 3);
+        if (t == 18) bh.put(S.hdr_ext[i], 7);
         bh.flush();
     }
     BitWriter bw(S.out, S.lane_off[lane]);
@@ -830,7 +894,7 @@ BS_HD void ph_write(uint32_t lane, Block &S, const Args &A, uint32_t blk)
     RUN(ph_init) RUN(ph_load) RUN(ph_runs) RUN(ph_tokenize)                                                        \
     RUN_ALPHABET(ph_len_shannon, 0) RUN_ALPHABET(ph_len_rank, 0) RUN_ALPHABET(ph_len_counts, 0)       \
     RUN_ALPHABET(ph_len_assign, 0) RUN_ALPHABET(ph_len_codes, 0)                                      \
-    RUN(ph_header_freq)                                                                               \
+    RUN(ph_header_zeros) RUN(ph_header_tokens)                                                        \
     RUN_ALPHABET(ph_len_shannon, 1) RUN_ALPHABET(ph_len_rank, 1) RUN_ALPHABET(ph_len_counts, 1)       \
     RUN_ALPHABET(ph_len_assign, 1) RUN_ALPHABET(ph_len_codes, 1)                                      \
     RUN(ph_bitcount) RUN(ph_plan) RUN(ph_emit) RUN(ph_crc) RUN(ph_crc_groups) RUN(ph_write)

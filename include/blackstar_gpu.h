@@ -237,7 +237,7 @@ int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
                         const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
 
 /* Probe hook: bs_encode_png's block kernel with a shader-clock stamp (s_memtime) taken by every workgroup before its first phase and
- * after each of its 21 phases (blackstar_amd/csrc/png_block.h): clocks[b * 22 + p], b < ceil(height * (3 width + 1) / 8192).
+ * after each of its 22 phases (blackstar_amd/csrc/png_block.h): clocks[b * 23 + p], b < ceil(height * (3 width + 1) / 8192).
  * scripts/png_phase_probe.py turns them into the table in profiles/. */
 int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned long long *clocks, size_t n_clocks);
 

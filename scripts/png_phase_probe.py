@@ -7,7 +7,7 @@ import numpy as np
 import blackstar_amd as bs
 from blackstar_amd import _lib, synthetic
 
-PHASES = ["init", "load", "runs", "tokenize", "ll shannon", "ll rank", "ll counts", "ll assign", "ll codes", "header freq",
+PHASES = ["init", "load", "runs", "tokenize", "ll shannon", "ll rank", "ll counts", "ll assign", "ll codes", "header zeros", "header tokens",
           "cl shannon", "cl rank", "cl counts", "cl assign", "cl codes", "bitcount", "plan", "emit", "crc", "crc groups", "write"]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tree = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_FULL)))
