@@ -21,7 +21,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
             os.makedirs(os.path.dirname(SO), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", SRC, "-o", SO])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", SRC, "-o", SO])
         L = C.CDLL(SO)
         L.png_emul_bound.restype = C.c_uint64
         L.png_emul_bound.argtypes = [C.c_int, C.c_int]
