@@ -1228,18 +1228,22 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 }
 
 // How many CUs the post stage of a batch should own (0: none -- the shared-chip pipeline above).  With the chip partitioned a frame
-// costs about trace x n_cu / (n_cu - M) (+3 %), provided the post stage confined to M CUs keeps up; on the shared chip it costs trace +
-// post + ~0.33 ms of hand-over stalls (a blur workgroup only ever gets a CU in the drain of a later trace kernel).  Measured
-// (scripts/post_partition_ab.py, profiles/r03_post_partition_ab.txt): C3 1080p 4.38 against 4.67 ms with M = 8; 720p 2.00 against 2.25
-// with M = 16 (M = 8: the post stage becomes the bottleneck, 2.26); bloomDivider 10 (r = 192) 4.47 against 4.72 with M = 16 (M = 8: 7.1);
-// but 3840x2160 20.7-21.1 against 20.2 on the shared chip (the stall is a constant, the partition's price is proportional), and frames
-// without supersampling are too cheap to trace per pixel for any M.  Both sides are ESTIMATED per frame -- trace: rays x straight-path
+// costs trace x n_cu / (n_cu - M), provided the post stage confined to M CUs keeps up; on the shared chip it costs trace + post + a
+// hand-over stall (a blur workgroup only ever gets a CU in the drain of a later trace kernel, and delays the one behind it) that
+// grows with the post stage: 0.33 ms at 1080p, 0.46 at 1440p, 0.7-0.95 at 4K -- about 1.4 x the post stage's own time.
+// Measured (scripts/post_partition_ab.py, partition_large_ab.py, partition_more_ab.py -> profiles/r03_post_partition_ab.txt,
+// r03_partition_large_ab.jsonl, r03_partition_more_ab.jsonl), ms per frame partitioned / shared: C3 1080p 4.27-4.38 / 4.67 (M = 8); 720p
+// 2.00 / 2.25 (16; with 8 the post stage is the bottleneck: 2.26); bloomDivider 10 (r = 192) 4.47 / 4.72 (16; 8: 7.1); 1440p 7.80 /
+// 8.04 (16); 3200x1800 12.15 / 12.45 (16); 3840x2160 17.39 / 17.83 (16; 8: 18.6); lensing-disk at 4K 19.23 / 19.90 (8: the longer
+// trace hides the post stage on 8 CUs) and at 1440p 8.59 / 8.98 (8); C3 in STRICT 10.59 / 10.71 (8); frames without supersampling
+// lose with any M (1.33 -> 2.3-4.0: too cheap to trace per pixel).  Both sides are ESTIMATED per frame -- trace: rays x straight-path
 // steps / the measured FAST rate of 4.5e11 ray-steps per second and chip (STRICT: / 2.4); post: bs::estimate_post_us -- and the smallest
-// M of {8, 16} is taken for which, on EVERY frame of the share, (a) the post stage ALONE on M CUs needs at most 86 % of the trace time on the
-// rest (next to the trace kernels it runs ~20 % slower than alone: 720p on 8 CUs 1.80 ms alone, 2.25 in the pipeline) and (b) the
-// partitioned frame time undercuts the shared one by 2 %.  BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
-// png: the post stage also makes the frame's PNG file (bs_render_png_batch; bs::estimate_png_us): the C3 frame then needs M = 16 --
-// measured 4.44 ms per frame against 4.77 on the shared chip and 7.4 with M = 8 (scripts/png_probe.py, profiles/r03_png_probe.json).
+// M of {8, 16, 24} is taken for which, on EVERY frame of the share, (a) the post stage ALONE on M CUs needs at most 86 % of the trace
+// time on the rest (next to the trace kernels it runs ~20 % slower than alone: 720p on 8 CUs 1.80 ms alone, 2.25 in the pipeline) and
+// (b) the partitioned frame time undercuts the shared one by 0.5 % (a wrong call either way costs about 1 %).  BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
+// png: the post stage also makes the frame's PNG file (bs_render_png_batch; bs::estimate_png_us).  Its small workgroups slip into
+// the trace kernels' drains on the shared chip (about 45 % of their time shows: 4.73 against 4.65 ms), but confined to M CUs they count in
+// full: the C3 frame then needs M = 16 -- 4.41 ms per frame against 4.73 shared and 7.4-8.1 with M = 8 (scripts/png_partition_ab.py).
 static int post_cus_for_frame(const bs_config &cfg, double strength, int divider, int n_cu, bool fast, int m, bool png)
 {
     bs::TraceParams p;
@@ -1248,17 +1252,19 @@ static int post_cus_for_frame(const bs_config &cfg, double strength, int divider
     if ((strength == 0 && !png) || !bs::derive_params(cfg, p, err)) return 0;
     // (without bloom the pixel map alone: about 30 us on the chip, 60 on a slice of it)
     double post_m = strength != 0 ? bs::estimate_post_us(cfg.width, cfg.height, divider, m) : 60.0;
-    double post_all = strength != 0 ? bs::estimate_post_us(cfg.width, cfg.height, divider, n_cu) : 30.0;
-    if (png && post_m > 0 && post_all > 0) {
+    const double post_all = strength != 0 ? bs::estimate_post_us(cfg.width, cfg.height, divider, n_cu) : 30.0;
+    if (post_m <= 0 || post_all <= 0) return 0;
+    double shared_extra = post_all + std::max(330.0, 1.4 * post_all);   // the post stage and the stall it causes
+    if (png) {
         post_m += bs::estimate_png_us(cfg.width, cfg.height, m);
-        post_all += bs::estimate_png_us(cfg.width, cfg.height, n_cu);
+        shared_extra += 0.45 * bs::estimate_png_us(cfg.width, cfg.height, n_cu);
     }
     const double steps = (p.rcam + std::sqrt(p.safe)) / p.h;  // the longest straight path through the scene, in steps
     const double rate = 4.5e11 * n_cu / 256.0 / (fast ? 1.0 : 2.4);
     const double trace_all = (double)p.wt * p.ht * steps / rate * 1e6;
     const double trace_m = trace_all * n_cu / (n_cu - m);
     if (trace_all < 1500.0) return 0;  // small frames (below ~720p supersampled): launch overheads dominate both stages; not measured, not partitioned
-    return post_m > 0 && post_all > 0 && post_m <= 0.86 * trace_m && 1.03 * trace_m < 0.98 * (trace_all + post_all + 330.0) ? m : 0;
+    return post_m <= 0.86 * trace_m && trace_m < 0.995 * (trace_all + shared_extra) ? m : 0;
 }
 
 static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, int first, int n_frames, int step, bool png)

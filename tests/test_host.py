@@ -221,21 +221,24 @@ def test_every_shipped_scene_and_animation_frame_validates():
 
 def test_post_stage_partition_heuristic():
     """bs_render_rgb8_batch sets CUs aside for bloom + sRGB8 only where both estimates say it pays (host-only hook).  The expectations
-    are the measured winners of scripts/post_partition_ab.py (profiles/r03_post_partition_ab.txt)."""
+    are the measured winners of scripts/post_partition_ab.py, partition_large_ab.py, partition_more_ab.py (profiles/r03_post_partition_ab.txt,
+    r03_partition_large_ab.jsonl, r03_partition_more_ab.jsonl)."""
     import ctypes as C
     L = _lib.lib()
 
     def m(cfg, st=0.15, div=25, n_cu=256, mode=_lib.BS_MODE_FAST):
         return L.bs_debug_post_cus(C.byref(_lib.make_config(cfg)), st, div, n_cu, mode)
-    assert m(scenes.DEFAULT_AA) == 8                                  # C3: 4.38 against 4.67 ms
+    assert m(scenes.DEFAULT_AA) == 8                                  # C3: 4.28 against 4.67 ms
     assert m(scenes.ani_frame(300, 600), st=0.7) == 8                 # C5 frames
     assert m(scenes.LENSING_DISK) == 8                                # 1280x800 supersampled: 2.55 against 2.74 ms
     assert m(scenes.with_res(scenes.DEFAULT_AA, 1280, 720)) == 16     # 720p: on 8 CUs the post stage would be the bottleneck (2.26 vs 2.00)
     assert m(scenes.DEFAULT_AA, div=10) == 16                         # r = 192: 4.47 against 4.72 (7.1 on 8 CUs)
-    assert m(scenes.DEFAULT) == 0 and m(scenes.CLOSEUP, st=0.7) == 0  # no supersampling: too cheap to trace per pixel
-    assert m(scenes.with_res(scenes.LENSING_DISK, 3840, 2160)) == 0   # 4K: the shared chip's stall is a constant, the partition's price is not
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 2560, 1440)) == 16    # 7.80 against 8.04 (8 CUs: 7.87)
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 3840, 2160)) == 16    # 17.40 against 17.84 (8 CUs: 18.7)
+    assert m(scenes.with_res(scenes.LENSING_DISK, 3840, 2160)) == 8   # C4: 19.5 against 20.2 -- the longer trace hides the post stage on 8 CUs
+    assert m(scenes.DEFAULT) == 0 and m(scenes.CLOSEUP, st=0.7) == 0  # no supersampling: too cheap to trace per pixel (1.33 -> 2.3 .. 4.0)
     assert m(scenes.DEFAULT_AA, st=0.0) == 0                          # no bloom, no post stage worth a partition
-    assert m(scenes.DEFAULT_AA, mode=_lib.BS_MODE_STRICT) == 0       # STRICT: 3 % of a 10 ms frame is more than the stall
+    assert m(scenes.DEFAULT_AA, mode=_lib.BS_MODE_STRICT) == 8        # STRICT: 10.72 against 10.90
     assert m(scenes.with_res(scenes.DEFAULT_AA, 96, 54)) == 0 and m(scenes.with_res(scenes.DEFAULT_AA, 640, 360)) == 0  # small frames
     assert m(scenes.DEFAULT_AA, n_cu=64) == 0 and m(scenes.DEFAULT_AA, n_cu=100) == 0      # a partitioned device / odd CU counts
     assert L.bs_debug_post_cus(None, 0.1, 25, 256, 1) == -1
@@ -244,7 +247,8 @@ def test_post_stage_partition_heuristic():
     assert m(scenes.DEFAULT_AA, mode=_lib.BS_MODE_FAST | PNG) == 16                                   # C3: 4.41 against 4.74 ms (7.4 on 8 CUs)
     assert m(scenes.DEFAULT_AA, st=0.0, mode=_lib.BS_MODE_FAST | PNG) == 8                           # no bloom: 4.26 against 4.43
     assert m(scenes.with_res(scenes.DEFAULT_AA, 1280, 720), mode=_lib.BS_MODE_FAST | PNG) in (16, 24)  # 2.01 (16) / 2.06 (24) against 2.31
-    assert m(scenes.with_res(scenes.DEFAULT_AA, 2560, 1440), mode=_lib.BS_MODE_FAST | PNG) == 0       # 8.13 shared (16 CUs: 7.81 -- the model stays out)
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 2560, 1440), mode=_lib.BS_MODE_FAST | PNG) == 16      # 7.83 against 8.17
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 3840, 2160), mode=_lib.BS_MODE_FAST | PNG) == 16      # 17.47 against 18.01
     assert m(scenes.DEFAULT, mode=_lib.BS_MODE_FAST | PNG) == 0
 
 
