@@ -110,7 +110,7 @@ struct bs_ctx {
         hipStream_t trace[2] = {nullptr, nullptr};  // CU mask: every CU but the post stage's
         hipStream_t post = nullptr;                 // CU mask: the post stage's CUs
     };
-    static constexpr int kPartitions = 4;           // post stage on 8, 16, 24 or 32 CUs
+    static constexpr int kPartitions = 7;           // post stage on 8, 12, ... 32 CUs (at least one in every XCD: an XCD without a mask bit gets all its CUs)
     Partition parts[kPartitions];
     hipEvent_t ev_traced[3] = {nullptr, nullptr, nullptr}, ev_posted[3] = {nullptr, nullptr, nullptr};
     double *d_img3 = nullptr;
@@ -288,6 +288,13 @@ bool grow_device(T *&buf, size_t &cap, size_t elems)
     return true;
 }
 
+// BLACKSTAR_POST_CUS as a number: 0 = never partition, otherwise a multiple of 4 in [8, 32] (rounded down, at least 8)
+int post_cus_setting(int v)
+{
+    if (v <= 0) return 0;
+    return std::max(8, std::min(32, v) / 4 * 4);
+}
+
 int ensure_scratch(bs_ctx *ctx, size_t bytes)
 {
     if (ctx->scratch_cap >= bytes) return BS_OK;
@@ -407,7 +414,7 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
     if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));
-    if (const char *m = std::getenv("BLACKSTAR_POST_CUS")) ctx->post_cus_req = std::strcmp(m, "auto") ? std::max(0, std::min(32, std::atoi(m))) / 8 * 8 : -1;
+    if (const char *m = std::getenv("BLACKSTAR_POST_CUS")) ctx->post_cus_req = std::strcmp(m, "auto") ? post_cus_setting(std::atoi(m)) : -1;
     if (const char *m = std::getenv("BLACKSTAR_POST_PLAN_CUS")) ctx->post_plan_cus = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_BLOOM_PLAN_CUS")) ctx->bloom_plan_cus = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_MODE")) {
@@ -1290,8 +1297,8 @@ static int choose_post_cus(bs_ctx *ctx, const bs_config *cfgs, const double *str
 // false: the runtime would not make them (no CU-mask support on this device / driver) -- the caller falls back to the shared chip.
 static bool ensure_partition(bs_ctx *ctx, int post_cus)
 {
-    if (post_cus < 8 || post_cus / 8 > bs_ctx::kPartitions || hipSetDevice(ctx->device) != hipSuccess) return false;
-    bs_ctx::Partition &pt = ctx->parts[post_cus / 8 - 1];
+    if (post_cus < 8 || post_cus > 32 || post_cus % 4 != 0 || hipSetDevice(ctx->device) != hipSuccess) return false;
+    bs_ctx::Partition &pt = ctx->parts[(post_cus - 8) / 4];
     if (pt.post) return true;
     const int words = (ctx->n_cu + 31) / 32;
     std::vector<uint32_t> post(words, 0u), trace(words, 0u);
@@ -1316,7 +1323,8 @@ static bool ensure_partition(bs_ctx *ctx, int post_cus)
 // 4.13 ms per frame without the post stage).  Here the trace kernels run on streams whose CU mask leaves post_cus CUs out and the post
 // stage on a stream that owns exactly those: frame k's bloom + sRGB8 run WHILE frames k+1, k+2 are traced, at the price of post_cus /
 // n_cu of the trace rate.  Mask bit i is CU i / 8 of XCD i % 8 (scripts/cumask_probe.py, profiles/r03_cumask_probe.txt: an XCD
-// without a single bit gets ALL its CUs), so bits [0, post_cus) are post_cus / 8 CUs in every XCD.  Three images in flight.
+// without a single bit gets ALL its CUs), so bits [0, post_cus) are post_cus / 8 CUs in every XCD (for 12, 20, 28: one more in the first
+// four XCDs -- the trace kernels' tile queue and the blur sweeps' plans balance themselves).  Three images in flight.
 static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_config *cfgs, const double *strengths, const int *dividers,
                                           unsigned char *const *outs, int first, int n_frames, int step, const PngSink *png)
 {
@@ -1330,7 +1338,7 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         return fail(BS_ENOMEM, "hipMalloc image failed");
     rc = ensure_post(ctx, need);
     if (rc) return rc;
-    bs_ctx::Partition &pt = ctx->parts[post_cus / 8 - 1];  // streams made by ensure_partition
+    bs_ctx::Partition &pt = ctx->parts[(post_cus - 8) / 4];  // streams made by ensure_partition
     for (hipEvent_t &e : ctx->ev_traced)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t &e : ctx->ev_posted)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """bs_render_png_batch with the post stage (bloom + sRGB8 + PNG encoder) on its own CUs: ms per frame for BLACKSTAR_POST_CUS = 0 (shared
-chip), auto (the cost model's choice, printed) and 8 / 16 / 24 forced, on a few frame shapes; page-locked file buffers, N frames,
+chip), auto (the cost model's choice, printed) and 8 / 16 / 24 forced (AB_SETTINGS=0,auto,8,12,... for another list; AB_FORM=rgb8 for bs_render_rgb8_batch), on a few frame shapes; page-locked file buffers, N frames,
 best of 3 calls.  Usage: png_partition_ab.py [N_FRAMES]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,18 +16,20 @@ for scene, w, h, bloom in (("default-aa", 1920, 1080, 0.4), ("default-aa", 1920,
                            ("default-aa", 1280, 720, 0.0), ("default-aa", 2560, 1440, 0.4), ("lensing-disk", 1920, 1080, 0.4)):
     cfg = bs.Config.from_file(os.path.join(root, "scenes", scene + ".yaml")).with_resolution(w, h)
     cfg.scene.bloomStrength = bloom
-    rec = {"scene": scene, "frame": f"{w}x{h}", "bloom": bloom}
-    for setting in ("0", "auto", "8", "16", "24"):
+    rec = {"scene": scene, "frame": f"{w}x{h}", "bloom": bloom, "form": os.environ.get("AB_FORM", "png")}
+    for setting in os.environ.get("AB_SETTINGS", "0,auto,8,16,24").split(","):
         os.environ["BLACKSTAR_POST_CUS"] = setting
         tree = bs.StarTree(stars)
         del os.environ["BLACKSTAR_POST_CUS"]
-        bufs = [bs.alloc_png(tree, h, w) for _ in range(4)]
+        rgb8 = os.environ.get("AB_FORM", "png") == "rgb8"
+        bufs = [bs.alloc_image(tree, h, w, dtype=np.uint8) if rgb8 else bs.alloc_png(tree, h, w) for _ in range(4)]
         outs = [bufs[i % 4] for i in range(N)]
-        bs.render_png_batch([cfg] * N, [tree], outs=outs)
+        fn = bs.render_rgb8_batch if rgb8 else bs.render_png_batch
+        fn([cfg] * N, [tree], outs=outs)
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
-            bs.render_png_batch([cfg] * N, [tree], outs=outs)
+            fn([cfg] * N, [tree], outs=outs)
             best = min(best, (time.perf_counter() - t0) / N)
         rec[setting] = round(best * 1e3, 3)
         if setting == "auto":
