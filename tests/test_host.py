@@ -246,7 +246,7 @@ def test_post_stage_partition_heuristic():
     PNG = 0x100  # BS_DEBUG_POST_CUS_PNG
     assert m(scenes.DEFAULT_AA, mode=_lib.BS_MODE_FAST | PNG) == 16                                   # C3: 4.41 against 4.74 ms (7.4 on 8 CUs)
     assert m(scenes.DEFAULT_AA, st=0.0, mode=_lib.BS_MODE_FAST | PNG) == 8                           # no bloom: 4.26 against 4.43
-    assert m(scenes.with_res(scenes.DEFAULT_AA, 1280, 720), mode=_lib.BS_MODE_FAST | PNG) in (16, 24)  # 2.01 (16) / 2.06 (24) against 2.31
+    assert m(scenes.with_res(scenes.DEFAULT_AA, 1280, 720), mode=_lib.BS_MODE_FAST | PNG) == 16        # 2.01 against 2.31 (24 CUs: 2.06)
     assert m(scenes.with_res(scenes.DEFAULT_AA, 2560, 1440), mode=_lib.BS_MODE_FAST | PNG) == 16      # 7.83 against 8.17
     assert m(scenes.with_res(scenes.DEFAULT_AA, 3840, 2160), mode=_lib.BS_MODE_FAST | PNG) == 16      # 17.47 against 18.01
     assert m(scenes.DEFAULT, mode=_lib.BS_MODE_FAST | PNG) == 0
