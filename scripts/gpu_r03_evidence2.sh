@@ -23,3 +23,5 @@ for f in ("bench_default", "bench_form_png_batch", "bench_c5_animation"):
     except Exception as e:
         print(f, "FAILED", e)
 PY
+timeout 200 python scripts/soak.py 60 21 > $O/soak_auto.txt 2>&1; tail -1 $O/soak_auto.txt
+timeout 600 python scripts/configs_table.py > $O/configs_table.jsonl 2> $O/configs_table.err; tail -2 $O/configs_table.err; cat $O/configs_table.jsonl | cut -c1-400
