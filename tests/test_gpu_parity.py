@@ -1497,9 +1497,9 @@ def test_gpu_against_the_reference_itself(which, mode):
 
 # ---- bs_render_rgb8_batch with the chip partitioned between the trace kernels and the post stage (round 3) ---------------------
 
-@pytest.mark.parametrize("post", ["auto", "8", "16", "0"])
+@pytest.mark.parametrize("post", ["auto", "8", "12", "16", "0"])
 def test_rgb8_batch_on_a_partitioned_chip_is_byte_identical(post, catalogue_bytes, monkeypatch):
-    """BLACKSTAR_POST_CUS: bloom + sRGB8 of frame k on a stream that owns 8 / 16 CUs while frames k+1, k+2 are traced on the rest
+    """BLACKSTAR_POST_CUS: bloom + sRGB8 of frame k on a stream that owns 8 / 12 / 16 CUs while frames k+1, k+2 are traced on the rest
     (auto: chosen per batch; these frames are small, so auto means the shared chip).  Whatever the pipeline: the bytes of
     bs_render_rgb8 frame by frame -- frames of different cameras, a frame without bloom, page-locked and pageable outputs mixed,
     more frames than images in flight -- and a failing frame in the middle leaves nothing in flight and the context usable."""
@@ -1518,7 +1518,7 @@ def test_rgb8_batch_on_a_partitioned_chip_is_byte_identical(post, catalogue_byte
         assert L.bs_debug_last_post_cus(t.handle) == -1
         pinned = [bs.alloc_image(t, c.scene.resolution[1], c.scene.resolution[0], dtype=np.uint8) for c in cfgs]
         mixed = [p if i % 3 else np.zeros_like(p) for i, p in enumerate(pinned)]  # every third output pageable
-        for outs, want_cus in ((pinned, {"auto": 0, "0": 0, "8": 8, "16": 16}[post]), (mixed, 0)):  # pageable outputs: never partitioned
+        for outs, want_cus in ((pinned, {"auto": 0, "0": 0, "8": 8, "12": 12, "16": 16}[post]), (mixed, 0)):  # pageable outputs: never partitioned
             for rep in range(2):
                 for o in outs:
                     o[:] = 7
