@@ -41,7 +41,7 @@ SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_rende
            "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
            "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots",
            "bs_effective_mode", "bs_validate_config", "bs_debug_post_cus", "bs_debug_last_post_cus", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch",
-           "bs_png_bound", "bs_encode_png_device", "bs_encode_png", "bs_render_png", "bs_render_png_batch", "bs_debug_png_phases")
+           "bs_png_bound", "bs_encode_png_device", "bs_encode_png", "bs_render_png", "bs_render_png_batch", "bs_render_png_files", "bs_debug_png_phases")
 
 _lib = None
 
@@ -141,6 +141,7 @@ def lib() -> C.CDLL:
     L.bs_encode_png_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz, vp, vp]
     L.bs_encode_png.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz, C.POINTER(sz)]
     L.bs_render_png.argtypes = [vp, C.POINTER(BsConfig), dp, C.c_int, vp, sz, C.POINTER(sz)]
+    L.bs_render_png_files.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int]
     L.bs_debug_png_phases.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz]
     L.bs_render_png_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
     _lib = L

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence
 
 import numpy as np
@@ -92,11 +93,32 @@ def render_png_batch(cfgs: Sequence[Config], trees: Sequence[StarTree], outs: Se
     return [memoryview(o)[:sizes[i]] for i, o in enumerate(outs)]
 
 
-def render_scene_directory(in_dir: str, out_dir: str, trees: Sequence[StarTree], preview: bool = False, pipe: int = 32) -> List[str]:
+def render_png_files(cfgs: Sequence[Config], trees: Sequence[StarTree], paths: Sequence[str], pipe: int = 16) -> None:
+    """The reference's batch loop to the very end, in the library (`bs_render_png_files`): cfgs[i] rendered, bloomed, mapped to sRGB8 and
+    PNG-encoded on trees[i % len(trees)] and written to paths[i] -- frames in flight on the GPUs, files written by a native writer thread
+    from page-locked buffers while the next frames are rendered.  Raises BlackstarError (BS_EIO) if a file cannot be written."""
+    if not trees:
+        raise ValueError("need at least one StarTree")
+    if any(not isinstance(c, Config) for c in cfgs):
+        raise TypeError("render_png_files takes Config objects (the scene's bloom parameters are part of the frame)")
+    n = len(cfgs)
+    if len(paths) != n:
+        raise ValueError("one path per frame")
+    if n == 0:
+        return
+    arr = (_lib.BsConfig * n)(*[_lib.make_config(c.to_bs_config()) for c in cfgs])
+    strengths = (C.c_double * n)(*[float(c.scene.bloomStrength) for c in cfgs])
+    dividers = (C.c_int * n)(*[int(c.scene.bloomDivider) for c in cfgs])
+    cpaths = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
+    _lib.check(_lib.lib().bs_render_png_files(ctxs, len(trees), arr, n, strengths, dividers, cpaths, int(pipe)), "bs_render_png_files")
+
+
+def render_scene_directory(in_dir: str, out_dir: str, trees: Sequence[StarTree], preview: bool = False, pipe: int = 16) -> List[str]:
     """The reference's batch mode (app/Main.hs:64-77 over handleScene :80-91 and doRender :105-123) without its terminal: every `*.yaml`
     of `in_dir`, in sorted order, decoded like `decodeFileEither`, `prepareScene`d (preview: 300-px long side, no supersampling, no
-    bloom, name prefixed `prev-`), rendered / bloomed / mapped to sRGB8 / PNG-encoded on the device (`bs_render_png_batch`, scene i on
-    trees[i % len(trees)]) and written to `<out_dir>/<scene name>.png` (existing files are overwritten: the reference's --force).
+    bloom, name prefixed `prev-`), rendered / bloomed / mapped to sRGB8 / PNG-encoded on the device and written by the library
+    (`bs_render_png_files`, scene i on trees[i % len(trees)]) to `<out_dir>/<scene name>.png` (existing files are overwritten: the reference's --force).
     A scene file that does not decode is reported like the reference does -- its error is printed, the others are rendered.
     Returns the paths written."""
     import os
@@ -114,11 +136,7 @@ def render_scene_directory(in_dir: str, out_dir: str, trees: Sequence[StarTree],
         cfgs.append(prepare_scene(cfg, preview))
         outs.append(os.path.join(out_dir, ("prev-" if preview else "") + os.path.splitext(f)[0] + ".png"))
     os.makedirs(out_dir, exist_ok=True)
-    for pos in range(0, len(cfgs), max(1, int(pipe))):
-        chunk = slice(pos, pos + max(1, int(pipe)))
-        for path, data in zip(outs[chunk], render_png_batch(cfgs[chunk], trees)):
-            with open(path, "wb") as fh:
-                fh.write(data)
+    render_png_files(cfgs, trees, outs, pipe=pipe)
     return outs
 
 

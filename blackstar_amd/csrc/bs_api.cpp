@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "bs_internal.h"
@@ -128,6 +130,8 @@ struct bs_ctx {
     hipEvent_t ev_png = nullptr;       // behind the last user of PNG slot 0 (the enqueue-only entry point): see acquire_png
     hipStream_t png_stream = nullptr;
     bool png_busy = false;
+    // page-locked file buffers bs_render_png_files keeps between calls (page-locking 6 MB costs 1-2 ms): (pointer, capacity)
+    std::vector<std::pair<unsigned char *, size_t>> file_pool;
     struct VerifiedRange { const void *host = nullptr; size_t bytes = 0; };
     VerifiedRange verified[8];  // host buffers device_alias_of_pinned has walked page by page (registered memory without a queryable range)
     int verified_next = 0;
@@ -515,6 +519,8 @@ void bs_destroy(bs_ctx *ctx)
         for (unsigned char *b : ctx->d_png_file)
             if (b) (void)hipFree(b);
         if (ctx->h_png_bytes) (void)hipHostFree(ctx->h_png_bytes);
+        for (auto &b : ctx->file_pool)
+            if (b.first) (void)hipHostFree(b.first);
         if (ctx->ev_png) (void)hipEventDestroy(ctx->ev_png);
         for (bs_ctx::Partition &pt : ctx->parts)
             for (hipStream_t st : {pt.trace[0], pt.trace[1], pt.post})
@@ -1458,6 +1464,81 @@ int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
     if (n_frames > 0 && (!caps || !out_bytes)) return fail(BS_EINVAL, "null argument");
     const PngSink sink{caps, out_bytes};
     return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, &sink);
+}
+
+// One file: create / truncate, write, close.  Empty string on success, else what failed.
+static std::string write_whole_file(const char *path, const unsigned char *data, size_t n)
+{
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return std::string(path) + ": " + std::strerror(errno);
+    const size_t wrote = n ? std::fwrite(data, 1, n, f) : 0;
+    const int close_rc = std::fclose(f);
+    if (wrote != n || close_rc != 0) return std::string(path) + ": " + std::strerror(errno ? errno : EIO);
+    return std::string();
+}
+
+int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                        const char *const *paths, int pipe)
+{
+    if (!ctxs || n_ctx <= 0 || n_frames < 0 || (n_frames > 0 && (!cfgs || !paths))) return fail(BS_EINVAL, "null argument");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
+    size_t cap = 0;
+    for (int i = 0; i < n_frames; i++) {
+        if (!paths[i]) return fail(BS_EINVAL, "null path");
+        if (int rc = check_png_frame(cfgs[i].width, cfgs[i].height)) return rc;
+        cap = std::max(cap, (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height));
+    }
+    if (n_frames == 0) return BS_OK;
+    // `chunk` frames per bs_render_png_batch call into one of two sets of page-locked file buffers; a writer thread writes the set of the
+    // call before while the GPUs fill the other.  (The second set exists only if there is a second call.)
+    const int chunk = (pipe > 0 ? pipe : 16) * n_ctx;
+    const int slots = std::min(chunk, n_frames);
+    const int n_sets = n_frames > chunk ? 2 : 1;
+    // buffer k of the call lives in the pool of context k % n_ctx (entry k / n_ctx), kept for the next call and freed with the context
+    std::vector<unsigned char *> bufs((size_t)n_sets * slots, nullptr);
+    for (size_t k = 0; k < bufs.size(); k++) {
+        bs_ctx *owner = ctxs[k % n_ctx];
+        const size_t e = k / n_ctx;
+        if (owner->file_pool.size() <= e) owner->file_pool.resize(e + 1, {nullptr, 0});
+        auto &slot = owner->file_pool[e];
+        if (slot.second < cap) {
+            if (slot.first) bs_host_free(slot.first);
+            slot = {nullptr, 0};
+            slot.first = static_cast<unsigned char *>(bs_host_alloc(owner, cap));
+            if (!slot.first) return BS_ENOMEM;   // (bs_host_alloc has set the message)
+            slot.second = cap;
+        }
+        bufs[k] = slot.first;
+    }
+    std::vector<size_t> caps(slots, cap), sizes((size_t)n_sets * slots, 0);
+    std::thread writer;
+    std::string write_error;   // owned by the writer thread until it is joined
+    struct JoinWriter {
+        std::thread &t;
+        ~JoinWriter() { if (t.joinable()) t.join(); }
+    } join_writer{writer};
+    int rc = BS_OK;
+    for (int pos = 0, it = 0; pos < n_frames && rc == BS_OK; pos += chunk, it++) {
+        const int count = std::min(chunk, n_frames - pos), set = it & 1;
+        // (the set being refilled was written out by the writer of the call before the last, joined below one iteration ago;
+        //  the writer of the last call -- the other set -- may still be running: that is the overlap)
+        unsigned char *const *outs = bufs.data() + (size_t)set * slots;
+        size_t *sz = sizes.data() + (size_t)set * slots;
+        const PngSink sink{caps.data(), sz};
+        rc = render_post_batch(ctxs, n_ctx, cfgs + pos, count, bloom_strengths ? bloom_strengths + pos : nullptr, bloom_dividers ? bloom_dividers + pos : nullptr, outs, &sink);
+        if (rc) break;
+        if (writer.joinable()) {              // the call before this one: its files (the other set) must be out before a new writer starts
+            writer.join();
+            if (!write_error.empty()) return fail(BS_EIO, write_error);
+        }
+        writer = std::thread([&write_error, outs, sz, paths, pos, count]() {
+            for (int j = 0; j < count && write_error.empty(); j++) write_error = write_whole_file(paths[pos + j], outs[j], sz[j]);
+        });
+    }
+    if (writer.joinable()) writer.join();
+    if (rc) return rc;   // (the failing call has set the message)
+    if (!write_error.empty()) return fail(BS_EIO, write_error);
+    return BS_OK;
 }
 
 int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)

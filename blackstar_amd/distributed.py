@@ -114,53 +114,23 @@ def _png_bound(height, width):
     return png_bound(height, width)
 
 
-def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1, basename: str = "frame", pipe: int = 32) -> "list[str]":
+def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1, basename: str = "frame", pipe: int = 16) -> "list[str]":
     """app/Animate.hs + blackstar's batch mode (app/Main.hs:68-77) for one animation: frame i on rank i % world, each rendered, bloomed,
-    mapped to sRGB8 and ENCODED AS A PNG FILE on the device (`bs_render_png_batch`); the host only writes the files' bytes
-    (`<basename>_<zero-padded index>.png`).  No collective, no pixels on the host.  `pipe` frames go through one bs_render_png_batch
-    call (the GPU idles for a moment between calls; two sets of `pipe` page-locked file buffers are kept).  Returns the paths this rank wrote."""
+    mapped to sRGB8, ENCODED AS A PNG FILE on the device and written by the library (`bs_render_png_files`: frames in flight on the GPU,
+    a native writer thread writing `<basename>_<zero-padded index>.png` from page-locked buffers meanwhile).  No collective, no pixels on
+    the host, no Python between frames.  `pipe`: frames per internal call.  Returns the paths this rank wrote."""
     import os
-    from concurrent.futures import ThreadPoolExecutor
 
     from .animation import generate_frames, validate_keyframes
-    from .batch import render_png_batch
-    from .raytracer import alloc_png
+    from .batch import render_png_files
 
     validate_keyframes(animation.keyframes)
     frames = generate_frames(animation)
     width = len(str(max(len(frames) - 1, 1)))
     os.makedirs(out_dir, exist_ok=True)
     mine = shard_frames(len(frames), rank, world)
-    kPipe = max(1, int(pipe))
-    paths, pending = [], []
-
-    def write_file(path, data):
-        with open(path, "wb") as f:
-            f.write(data)
-
-    # two sets of page-locked file buffers: while the writer thread drains one set, the GPU fills the other.  Page-locking costs
-    # 1-2 ms per 6 MB buffer, so the sets stay with the tree for the next call (they are freed with it).
-    cache = tree.__dict__.setdefault("_png_file_buffers", {})
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        for n, pos in enumerate(range(0, len(mine), kPipe)):
-            chunk = mine[pos:pos + kPipe]
-            cfgs = [frames[j] for j in chunk]
-            k = n & 1
-            if len(pending) > 1:
-                pending.pop(0).result()  # the set about to be reused has been written out (a failed write raises here)
-            bufs = []
-            for slot, c in enumerate(cfgs):
-                key = (k, slot)
-                need = _png_bound(c.scene.resolution[1], c.scene.resolution[0])
-                if key not in cache or cache[key].size < need:
-                    cache[key] = alloc_png(tree, c.scene.resolution[1], c.scene.resolution[0])
-                bufs.append(cache[key])
-            files = render_png_batch(cfgs, [tree], outs=bufs)
-            names = [os.path.join(out_dir, f"{basename}_{j:0{width}d}.png") for j in chunk]
-            paths.extend(names)
-            pending.append(pool.submit(lambda fs=files, ns=names: [write_file(p, d) for p, d in zip(ns, fs)]))
-        for f in pending:
-            f.result()
+    paths = [os.path.join(out_dir, f"{basename}_{j:0{width}d}.png") for j in mine]
+    render_png_files([frames[j] for j in mine], [tree], paths, pipe=pipe)
     return paths
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-/* 3 (round 3): the PNG entry points (bs_png_bound, bs_encode_png[_device], bs_render_png[_batch]) -- additions only, every
+/* 3 (round 3): the PNG entry points (bs_png_bound, bs_encode_png[_device], bs_render_png[_batch], bs_render_png_files), BS_EIO -- additions only, every
  * struct and every version-2 signature is unchanged.
  * 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
  * non-finite fields, stepSize <= 0, negative radii, lookAt within 1e-6 of position).  1: rounds 1-2.  A binding should compare
@@ -45,7 +45,8 @@ enum {
     BS_EDEVICE = -2, /* no such HIP device / HIP runtime error */
     BS_ENOMEM = -3,  /* host or device allocation failed */
     BS_ECAPPED = -4, /* never returned: rays stopped by the step cap are reported through bs_stats_t.capped only */
-    BS_EINTERNAL = -5
+    BS_EINTERNAL = -5,
+    BS_EIO = -6      /* bs_render_png_files: a file could not be created or written (bs_last_error names it) */
 };
 
 /* Arithmetic mode of the trace kernel (DESIGN.md "Kernels").
@@ -235,6 +236,14 @@ int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int 
  * against 4.77 on the shared chip and 4.31 for bs_render_rgb8_batch).  Blocking; bs_stats is not updated. */
 int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                         const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
+
+/* Replaces: the reference's batch loop to the very end (app/Main.hs:68-77 mapping doRender, :105-123, over the scenes, including writeImg's
+ * write): frame i is rendered, bloomed, encoded on ctxs[i % n_ctx] and WRITTEN to paths[i] (created or truncated, like --force).  Frames go
+ * through bs_render_png_batch `pipe` per context and call (<= 0: 16) into two sets of page-locked buffers of the library's own; a
+ * writer thread writes the files of one call while the GPUs work on the next.  Blocking.  BS_EIO if a file cannot be written (the frames of
+ * later calls are not rendered); files decode to bs_render_rgb8's pixels.  C3: 4.5 ms per frame including the write to a RAM disk. */
+int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
+                        const int *bloom_dividers, const char *const *paths, int pipe);
 
 /* Probe hook: bs_encode_png's block kernel with a shader-clock stamp (s_memtime) taken by every workgroup before its first phase and
  * after each of its 22 phases (blackstar_amd/csrc/png_block.h): clocks[b * 23 + p], b < ceil(height * (3 width + 1) / 8192).

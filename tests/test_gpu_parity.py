@@ -532,9 +532,9 @@ def test_render_animation_single_rank(tree, tmp_path, oracle):
 
 
 def test_write_animation_files_only(tree, tmp_path):
-    """app/Animate.hs + batch mode end to end with nothing but files leaving the GPU (bs_render_png_batch): 37 frames, 5 per call (four
-    calls per rank, so both sets of page-locked file buffers are reused while the writer thread drains the other), two ranks' shares
-    written one after the other; every file decodes to the frame bs_render_rgb8 gives for that camera."""
+    """app/Animate.hs + batch mode end to end with nothing but files leaving the GPU (bs_render_png_files): 37 frames, 5 per internal
+    call (four calls per rank, so both sets of page-locked file buffers are reused while the writer thread drains the other), two
+    ranks' shares written one after the other; every file decodes to the frame bs_render_rgb8 gives for that camera."""
     from blackstar_amd.distributed import shard_frames, write_animation
     from tests.ghc_pin import decode_png_rgb8
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -355,6 +355,39 @@ def test_render_scene_directory_is_the_references_batch_mode(tree, tmp_path):
 
 
 @pytest.mark.gpu
+def test_render_png_files_writes_what_render_png_returns(tree, tmp_path):
+    """bs_render_png_files (the batch loop incl. the write, in the library): 11 frames, 2 per internal call (six calls: both buffer sets
+    reused, the writer thread overlapping the next call), mixed sizes and bloom; every file is bs_render_png's bytes.  A path that cannot
+    be written gives BS_EIO naming it, leaves the context usable, and the files of earlier calls are complete."""
+    import blackstar_amd as bs
+    cfgs = []
+    for k in range(11):
+        name, w, h = (("default-aa", 160, 90), ("lensing-disk", 120, 68), ("default", 96, 54))[k % 3]
+        c = scene(name, w, h, 0.0 if k == 4 else 0.3)
+        c.camera.position = (c.camera.position[0], c.camera.position[1] + 0.03 * k, c.camera.position[2])
+        cfgs.append(c)
+    want = [bytes(bs.render_png(c, tree)) for c in cfgs]
+    paths = [str(tmp_path / f"f{k}.png") for k in range(11)]
+    bs.render_png_files(cfgs, [tree], paths, pipe=2)
+    assert [open(p, "rb").read() for p in paths] == want
+    t2 = bs.StarTree(tree.stars)
+    try:
+        two = [str(tmp_path / f"g{k}.png") for k in range(11)]
+        bs.render_png_files(cfgs, [tree, t2], two, pipe=1)
+        assert [open(p, "rb").read() for p in two] == want
+    finally:
+        t2.close()
+    bad = [str(tmp_path / f"h{k}.png") for k in range(11)]
+    bad[5] = str(tmp_path / "no_such_directory" / "h5.png")
+    with pytest.raises(bs._lib.BlackstarError, match="no_such_directory"):
+        bs.render_png_files(cfgs, [tree], bad, pipe=2)
+    assert [open(p, "rb").read() for p in bad[:4]] == want[:4]          # the calls before the failing one are on disk, whole
+    bs.render_png_files(cfgs[:3], [tree], paths[:3])
+    assert [open(p, "rb").read() for p in paths[:3]] == want[:3]
+    bs.render_png_files([], [tree], [])
+
+
+@pytest.mark.gpu
 def test_png_entry_points_refuse_bad_arguments(tree):
     """BS_EINVAL (-1) with a message, nothing launched, the context usable afterwards: null pointers, buffers below bs_png_bound, frames
     the encoder's 32-bit chunk offsets cannot hold, a bloom radius of 0, a bad configuration."""
