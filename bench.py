@@ -23,6 +23,7 @@ line carries, measured after the timed region (--form all, the default):
   with_d2h.rgb8_batch  bs_render_rgb8_batch: the reference's batch loop over doRender (app/Main.hs:68-77, :105-123) -- render,
                        bloom, sRGB8 on the device, only RGB8 leaves the GPU
   with_d2h.png_batch   bs_render_png_batch: the same with writeImg's PNG encoder on the device too -- the finished FILE leaves the GPU
+  with_d2h.png_files   bs_render_png_files: ... and is written to a RAM-disk file by the library's writer thread (scene to file)
   sustained            500 more frames on one stream with per-50-frame times and sampled sclk / power (clock droop under the
                        package power cap is visible here, not in 20 launches)
 --catalogue clustered | PATH swaps the uniform synthetic sky for the non-uniform one or a real PPM catalogue file (reported as such).
@@ -242,7 +243,7 @@ def parse_args():
     ap.add_argument("--catalogue", default="synthetic",
                     help="synthetic (uniform 470k-star sky, the BASELINE input) | clustered (non-uniform: + clusters + a dense band) | "
                          "PATH of a real PPM catalogue file in the layout src/StarMap.hs:45-58 reads (reported separately)")
-    ap.add_argument("--form", choices=["all", "resident", "batch", "rgb8-batch", "png-batch"], default="all",
+    ap.add_argument("--form", choices=["all", "resident", "batch", "rgb8-batch", "png-batch", "png-files"], default="all",
                     help="`value` is the resident form (image stays in HBM) unless batch / rgb8-batch / png-batch is named here; all (default) = "
                          "resident as `value` plus the with_d2h block (bs_render_batch, bs_render_rgb8_batch and bs_render_png_batch into "
                          "page-locked host memory)")
@@ -292,6 +293,9 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                                "the finished file is all that reaches the host (bytes_to_host_per_frame = its mean size); what is left for the host is write(2)"),
     }
     for form in forms:
+        if form == "png-files":
+            res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks)
+            continue
         F = FORMS[form]
         rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
         outs = [rings[i % n_t][(i // n_t) % 4] for i in range(len(frame_objs))]
@@ -333,6 +337,34 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
             res[F["key"]]["host_encoder_baseline"] = host
         del rings, outs, got
     return res
+
+
+def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks):
+    """The reference's batch loop to the very end: every frame rendered, bloomed, encoded AND written to a file by ONE bs_render_png_files
+    call (frames in flight on the GPUs, a native writer thread on page-locked buffers), into a fresh directory on the RAM disk (or the
+    temp directory) that is removed afterwards.  One untimed call first, like the other delivered forms."""
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="blackstar_bench_", dir=base)
+    try:
+        paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
+        bs.render_png_files(frame_objs, trees, paths)
+        fence()
+        t0 = time.perf_counter()
+        bs.render_png_files(frame_objs, trees, paths)
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        size = sum(os.path.getsize(p) for p in paths)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    frames = len(frame_objs) * world
+    per_gpu = len(frame_objs) / len(trees)
+    return {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
+            "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
+            "directory": "RAM disk (/dev/shm)" if base else "temp directory",
+            "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device, write(2) by a native writer thread while the next frames render "
+                    "(app/Main.hs:68-77 incl. writeImg's write)"}
 
 
 def sustained_leg(bs, torch, np, trees, cfgs, outs, streams, devs, n_frames):
@@ -661,7 +693,7 @@ def run_ranks(args):
         t_gather = None
 
     d2h = None
-    want = {"all": ["batch", "rgb8-batch", "png-batch"], "resident": []}.get(args.form, [args.form])
+    want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"], "resident": []}.get(args.form, [args.form])
     if want:
         d2h = optional_leg("with_d2h", world == 1 and resident,
                            lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x))))
@@ -842,7 +874,7 @@ def run_single_process(args):
     st = trees[0].stats()
 
     d2h = None
-    want = {"all": ["batch", "rgb8-batch", "png-batch"], "resident": []}.get(args.form, [args.form])
+    want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"], "resident": []}.get(args.form, [args.form])
     if want:  # frame i on context i % world, args.steps frames per context, ONE call over all contexts
         n = args.steps * world
         objs = [cfg_obj] * n if frames_obj is None else [frames_obj[i % len(frames_obj)] for i in range(n)]

@@ -86,6 +86,13 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
             return (np.arange(8 * 16 * 3) % 7).astype(np.uint8).reshape(8, 16, 3)
 
         @staticmethod
+        def render_png_files(cfgs, trees, paths, pipe=16):
+            calls.append(("files", len(cfgs), len(trees), [], None))
+            for p in paths:
+                with open(p, "wb") as f:
+                    f.write(b"x" * 77)
+
+        @staticmethod
         def alloc_png(tree, h, w):
             return np.zeros(h * w * 3 + 100, np.uint8)
 
@@ -97,9 +104,12 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     trees = ["t0", "t1", "t2"]
     frames = [f"cfg{i}" for i in range(30)]
     fences = []
-    res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch", "png-batch"], lambda: fences.append(1), lambda x: x)
-    assert set(res) == {"batch", "rgb8_batch", "png_batch"} and len(fences) == 6
-    assert [c[:3] for c in calls] == [("batch", 30, 3), ("batch", 30, 3), ("rgb8", 30, 3), ("rgb8", 30, 3), ("png", 30, 3), ("png", 30, 3)]  # warm-up call, timed call
+    res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch", "png-batch", "png-files"], lambda: fences.append(1), lambda x: x)
+    assert set(res) == {"batch", "rgb8_batch", "png_batch", "png_files"} and len(fences) == 8
+    assert [c[:3] for c in calls] == [("batch", 30, 3), ("batch", 30, 3), ("rgb8", 30, 3), ("rgb8", 30, 3), ("png", 30, 3), ("png", 30, 3),
+                                      ("files", 30, 3), ("files", 30, 3)]  # warm-up call, timed call
+    assert res["png_files"]["bytes_written_per_frame"] == 77 and res["png_files"]["frames"] == 30 and res["png_files"]["entry_point"] == "bs_render_png_files"
+    del calls[6:]
     assert res["png_batch"]["entry_point"] == "bs_render_png_batch" and res["png_batch"]["bytes_to_host_per_frame"] == 40   # the mean file size
     host = res["png_batch"]["host_encoder_baseline"]      # the same frame through zlib on one host core, beside the device encoder's number
     assert set(host) == {"zlib_level1", "zlib_level6"} and all(v["bytes"] > 0 and v["ms_per_frame_one_core"] >= 0 for v in host.values())
