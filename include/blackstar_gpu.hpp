@@ -207,4 +207,25 @@ inline std::vector<unsigned char> renderPng(const Config &cfg, const StarTree &t
     return file;
 }
 
+// doStart's loop over doRender (app/Main.hs:68-77, :105-123) including writeImg's write: scene i is rendered on trees[i % trees.size()]
+// and its PNG file written to paths[i] by the library (frames in flight, a writer thread) -- one call for a directory of scenes
+inline void renderToFiles(const std::vector<Config> &cfgs, const std::vector<const StarTree *> &trees, const std::vector<std::string> &paths)
+{
+    if (cfgs.size() != paths.size()) throw std::runtime_error("renderToFiles: one path per scene");
+    std::vector<bs_ctx *> ctxs;
+    for (const StarTree *t : trees) ctxs.push_back(t->handle());
+    std::vector<bs_config> cs;
+    std::vector<double> strengths;
+    std::vector<int> dividers;
+    std::vector<const char *> ps;
+    for (size_t i = 0; i < cfgs.size(); i++) {
+        cs.push_back(cfgs[i].to_bs_config());
+        strengths.push_back(cfgs[i].scene.bloomStrength);
+        dividers.push_back(cfgs[i].scene.bloomDivider);
+        ps.push_back(paths[i].c_str());
+    }
+    if (bs_render_png_files(ctxs.data(), (int)ctxs.size(), cs.data(), (int)cs.size(), strengths.data(), dividers.data(), ps.data(), 0))
+        throw std::runtime_error(std::string("bs_render_png_files: ") + bs_last_error());
+}
+
 }  // namespace blackstar

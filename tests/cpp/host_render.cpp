@@ -43,6 +43,19 @@ int main(int argc, char **argv)
             if (!g) return 3;
             std::fwrite(file.data(), 1, file.size(), g);
             std::fclose(g);
+            // ... and the batch loop that writes the files itself: three scenes -> OUT.f64.0.png .. .2.png, each the same bytes
+            std::vector<std::string> paths;
+            for (int k = 0; k < 3; k++) paths.push_back(std::string(argv[2]) + "." + std::to_string(k) + ".png");
+            renderToFiles({cfg, cfg, cfg}, {&tree}, paths);
+            for (const std::string &p : paths) {
+                FILE *r = std::fopen(p.c_str(), "rb");
+                if (!r) return 9;
+                std::vector<unsigned char> back(file.size() + 1);
+                const size_t n = std::fread(back.data(), 1, back.size(), r);
+                std::fclose(r);
+                back.resize(n);
+                if (back != file) return 10;
+            }
         }
         FILE *f = std::fopen(argv[2], "wb");
         if (!f) return 3;
