@@ -345,24 +345,47 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks):
     temp directory) that is removed afterwards.  One untimed call first, like the other delivered forms."""
     import shutil
     import tempfile
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    # A directory with room for the files (a container's /dev/shm can be 64 MB): RAM disk if it has 4x what the frames need, else the temp
+    # directory, else the leg is skipped -- on EVERY rank (the decision is a collective), so nobody waits in a fence for a rank that left.
+    need = 4 * len(frame_objs) * (W * H * 3 + 4096)
+    base = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free >= need:
+                base = cand
+                break
+        except OSError:
+            pass
+    if max_over_ranks(0.0 if base else 1.0) > 0:
+        return {"skipped": f"no directory with {need >> 20} MiB free on some rank (/dev/shm, {tempfile.gettempdir()})"}
     d = tempfile.mkdtemp(prefix="blackstar_bench_", dir=base)
+    err, dt_local, size = None, float("inf"), 0
     try:
         paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
-        bs.render_png_files(frame_objs, trees, paths)
+        try:
+            bs.render_png_files(frame_objs, trees, paths)
+        except Exception as e:  # a failing rank still goes through the same fences and collectives as the others
+            err = f"{type(e).__name__}: {e}"
         fence()
         t0 = time.perf_counter()
-        bs.render_png_files(frame_objs, trees, paths)
+        if err is None:
+            try:
+                bs.render_png_files(frame_objs, trees, paths)
+                dt_local = time.perf_counter() - t0
+                size = sum(os.path.getsize(p) for p in paths)
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
         fence()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        size = sum(os.path.getsize(p) for p in paths)
     finally:
         shutil.rmtree(d, ignore_errors=True)
+    dt = max_over_ranks(dt_local)
+    if err is not None or dt == float("inf"):
+        return {"error": err or "another rank failed"}
     frames = len(frame_objs) * world
     per_gpu = len(frame_objs) / len(trees)
     return {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
             "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
-            "directory": "RAM disk (/dev/shm)" if base else "temp directory",
+            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base,
             "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device, write(2) by a native writer thread while the next frames render "
                     "(app/Main.hs:68-77 incl. writeImg's write)"}
 
@@ -736,6 +759,8 @@ def run_ranks(args):
             value = frames * W * H / dt / 1e6
         else:  # the named d2h form is the result
             key = args.form.replace("-", "_")
+            if "Mpixel_s" not in d2h[key]:
+                raise SystemExit(f"bench.py --form {args.form}: {d2h[key]}")
             value, dt = d2h[key]["Mpixel_s"], d2h[key]["seconds"]
             kernel_ms = dt / args.steps * 1e3
             extra["image"] = d2h[key]["note"]
@@ -899,6 +924,8 @@ def run_single_process(args):
              "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])]}
     if not resident:
         key = args.form.replace("-", "_")
+        if "Mpixel_s" not in d2h[key]:
+            raise SystemExit(f"bench.py --form {args.form}: {d2h[key]}")
         value, dt = d2h[key]["Mpixel_s"], d2h[key]["seconds"]
         kernel_ms = dt / args.steps * 1e3
         per_rank_ms, kms = [kernel_ms] * world, None
