@@ -130,6 +130,18 @@ def test_emulated_encoder_seeded_fuzz():
         assert len(data) <= png_emul.bound(*img.shape[:2])
 
 
+def test_encoder_format_is_pinned_by_a_digest():
+    """The file of a fixed integer-built image, byte for byte (SHA-256): any change of the encoder's decisions (filter rule, tokeniser,
+    code lengths, header coding, chunking) shows up here and has to be made on purpose -- update the digest together with
+    profiles/EXPERIMENTS.md section 4.  (Validity is what the other tests check; this one pins the format.)"""
+    import hashlib
+    y, x = np.mgrid[0:120, 0:200]
+    img = np.stack([(x * 7 + y * 13) % 251, np.where((x // 16 + y // 8) % 3 == 0, 0, (x * y) % 256), (x // 5) * 5 % 256], -1).astype(np.uint8)
+    data, stats, _ = png_emul.encode(img)
+    png_emul.check_file(data, img)
+    assert (len(data), hashlib.sha256(data).hexdigest()) == (29154, "aa04158d0c3080d0bb7dd73882f634da126c36e34c6aa499261d0cc303c6e76d")
+
+
 def test_noise_falls_back_to_stored_blocks_within_bound():
     img = RNG.integers(0, 256, (128, 256, 3)).astype(np.uint8)
     data, stats, _ = png_emul.encode(img)
