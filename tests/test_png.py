@@ -130,6 +130,24 @@ def test_emulated_encoder_seeded_fuzz():
         assert len(data) <= png_emul.bound(*img.shape[:2])
 
 
+def test_emulated_encoder_property_any_image_round_trips():
+    """hypothesis: ANY (h, w, 3) byte image -- drawn from a small alphabet so that runs, repeats and block-long constants are common --
+    becomes a file the strict reader and Pillow accept as exactly that image, within bs_png_bound."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 12).flatmap(lambda h: st.integers(1, 500).flatmap(lambda w: hnp.arrays(
+        np.uint8, (h, w, 3), elements=st.sampled_from([0, 0, 0, 1, 2, 127, 128, 254, 255]) | st.integers(0, 255)))), st.integers(0, 3))
+    def check(img, order):
+        data, _, _ = png_emul.encode(img, order=order)
+        png_emul.check_file(data, img)
+        assert len(data) <= png_emul.bound(*img.shape[:2])
+
+    check()
+
+
 def test_encoder_format_is_pinned_by_a_digest():
     """The file of a fixed integer-built image, byte for byte (SHA-256): any change of the encoder's decisions (filter rule, tokeniser,
     code lengths, header coding, chunking) shows up here and has to be made on purpose -- update the digest together with
