@@ -127,6 +127,34 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     assert res["rgb8_batch"]["bytes_to_host_per_frame"] == 16 * 8 * 3
 
 
+def test_png_files_leg_skips_on_every_rank_when_there_is_no_room(monkeypatch):
+    """A container's /dev/shm can be 64 MB: without room for the files the leg is skipped -- after the collective that makes the decision
+    the same on every rank, before any fence -- and a write that fails later is reported, not raised (ranks would wait for each other)."""
+    import collections
+    import shutil
+    collectives, fences = [], []
+    usage = collections.namedtuple("usage", "total used free")
+    monkeypatch.setattr(shutil, "disk_usage", lambda p: usage(1 << 30, 1 << 30, 1 << 20))
+
+    class Bs:
+        @staticmethod
+        def render_png_files(cfgs, trees, paths, pipe=16):
+            raise AssertionError("must not render")
+
+    r = bench.png_files_leg(Bs, ["t"], ["c"] * 20, 1920, 1080, 2, lambda: fences.append(1), lambda x: (collectives.append(x), x)[1])
+    assert "skipped" in r and collectives == [1.0] and fences == []
+    monkeypatch.setattr(shutil, "disk_usage", lambda p: usage(1 << 40, 0, 1 << 40))
+
+    class Failing:
+        @staticmethod
+        def render_png_files(cfgs, trees, paths, pipe=16):
+            raise OSError("disk full")
+
+    collectives.clear()
+    r = bench.png_files_leg(Failing, ["t"], ["c"] * 4, 16, 8, 2, lambda: fences.append(1), lambda x: (collectives.append(x), x)[1])
+    assert "disk full" in r["error"] and len(fences) == 2 and collectives == [0.0, float("inf")]   # same fences and collectives as a healthy rank
+
+
 def test_device_sampler_reads_only_the_devices_it_was_given(tmp_path):
     """The box's sysfs lists every GPU of the host (other tenants' too): devices are matched by PCI bus, unmatched ones are not reported."""
     for card, bus, clk, pw in ((0, "75", 2403000000, 300000000), (24, "26", 2100000000, 1250000000)):
