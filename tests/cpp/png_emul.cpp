@@ -39,6 +39,9 @@ uint64_t png_emul_bound(int w, int h) { return file_bound(w, h); }
 // tables (optional): per block 2 * 286 words -- the literal/length frequencies, then the code lengths chosen for them
 static uint32_t *g_tables = nullptr;
 void png_emul_set_tables(uint32_t *tables) { g_tables = tables; }
+// forced (optional): h filter types to use instead of the encoder's own choice (experiments with other selection rules)
+static const uint8_t *g_forced_filters = nullptr;
+void png_emul_force_filters(const uint8_t *forced) { g_forced_filters = forced; }
 
 int png_emul_encode(const uint8_t *rgb, int w, int h, uint8_t *out, uint64_t cap, uint64_t *out_bytes, int order, uint8_t *filters, uint32_t *stats)
 {
@@ -47,7 +50,7 @@ int png_emul_encode(const uint8_t *rgb, int w, int h, uint8_t *out, uint64_t cap
     for (int row = 0; row < h; row++) {   // png_choose_filter: one wavefront per row, lanes stride over the bytes, costs summed
         uint32_t cost[5] = {0, 0, 0, 0, 0};
         for (int x = 0; x < 3 * w; x++) filter_cost(rgb, w, row, x, cost);
-        filt[row] = (uint8_t)best_filter(cost);
+        filt[row] = g_forced_filters ? g_forced_filters[row] : (uint8_t)best_filter(cost);
     }
     if (filters) std::memcpy(filters, filt.data(), h);
     Args A{};
