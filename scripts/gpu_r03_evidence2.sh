@@ -19,7 +19,7 @@ import json
 for f in ("bench_default", "bench_form_png_batch", "bench_c5_animation"):
     try:
         d = json.loads(open(f"gpurun_out/r03e2/{f}.json").read().strip().splitlines()[-1])
-        print(f, round(d["value"], 1), round(d["ms_per_step"], 3), {k: (round(v["Mpixel_s"], 1), v["bytes_to_host_per_frame"]) for k, v in d.get("with_d2h", {}).items()}, d.get("roofline", {}).get("frac"))
+        print(f, round(d["value"], 1), round(d["ms_per_step"], 3), {k: (round(v["Mpixel_s"], 1), v["bytes_to_host_per_frame"]) for k, v in d.get("with_d2h", {}).items() if "bytes_to_host_per_frame" in v}, d.get("roofline", {}).get("frac"))
     except Exception as e:
         print(f, "FAILED", e)
 PY
