@@ -215,7 +215,7 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
  * choice, deflate with per-block dynamic Huffman codes, CRCs, Adler-32: blackstar_amd/csrc/png_block.h), so a frame crosses PCIe as
  * about 1 MB of file and the caller only has to write(2) it.  What the format guarantees is the DECODED image: every file decodes
  * (zlib, libpng, Pillow) to exactly the RGB8 frame bs_render_rgb8 returns; its bytes differ from JuicyPixels' like any two zlib versions'.
- * Files are about 4 % larger than libpng's at zlib level 1 and 14 % larger than at level 6 on rendered frames (distance-1 matches
+ * Files are about 1.5 % larger than libpng's at zlib level 1 and 12 % larger than at level 6 on rendered frames (distance-1 matches
  * only), never larger than bs_png_bound. */
 
 /* Bytes a width x height RGB8 frame needs at most as a PNG file of this encoder (about 0.2 % above the pixels): the capacity every
