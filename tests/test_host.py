@@ -402,3 +402,31 @@ def test_bench_cli_contract_without_a_gpu():
         r = subprocess.run([sys.executable, bench] + args, capture_output=True, text=True, timeout=300,
                            env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
         assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout) and "{" not in r.stdout
+
+
+def test_batch_wrappers_check_their_arguments_before_the_library():
+    """The Python mirrors of the batch entry points refuse malformed calls on the host (no device needed): no trees, dict configs where
+    the scene's bloom parameters are needed, buffers of the wrong shape / count, a path list of the wrong length."""
+    import numpy as np
+
+    import blackstar_amd as bs
+    cfg = bs.Config.from_file(os.path.join(ROOT, "scenes", "default-aa.yaml")).with_resolution(16, 8)
+    fake_tree = object()
+    for fn in (bs.render_rgb8_batch, bs.render_png_batch):
+        with pytest.raises(ValueError):
+            fn([cfg], [])
+        with pytest.raises(TypeError):
+            fn([cfg.to_bs_config()], [fake_tree])
+    with pytest.raises(ValueError):
+        bs.render_rgb8_batch([cfg], [fake_tree], outs=[np.zeros((8, 16, 4), np.uint8)])
+    with pytest.raises(ValueError):
+        bs.render_png_batch([cfg, cfg], [fake_tree], outs=[np.zeros(10000, np.uint8)])
+    with pytest.raises(ValueError):
+        bs.render_png_batch([cfg], [fake_tree], outs=[np.zeros((10, 1000), np.uint8)])
+    with pytest.raises(ValueError):
+        bs.render_png_files([cfg, cfg], [fake_tree], ["only-one.png"])
+    with pytest.raises(TypeError):
+        bs.render_png_files([cfg.to_bs_config()], [fake_tree], ["a.png"])
+    with pytest.raises(ValueError):
+        bs.render_png_files([cfg], [], ["a.png"])
+    assert bs.png_bound(8, 16) == 8 * (3 * 16 + 1) + 47 + 33 + 17   # pixels + filter bytes + fixed chunks + one block's stored-header and chunk framing
