@@ -430,3 +430,37 @@ def test_batch_wrappers_check_their_arguments_before_the_library():
     with pytest.raises(ValueError):
         bs.render_png_files([cfg], [], ["a.png"])
     assert bs.png_bound(8, 16) == 8 * (3 * 16 + 1) + 47 + 33 + 17   # pixels + filter bytes + fixed chunks + one block's stored-header and chunk framing
+
+
+def test_validate_config_property():
+    """hypothesis: bs_validate_config on arbitrary bit patterns of every double and int field never crashes, and says OK only for
+    configurations the kernels terminate on -- every double finite, stepSize > 0, radii >= 0, lookAt away from position, a positive
+    resolution that fits, hue inside [0, 1)."""
+    import ctypes as C
+    import math
+
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    L = _lib.lib()
+    doubles = st.one_of(st.floats(allow_nan=True, allow_infinity=True), st.sampled_from([0.0, -0.0, 0.3, 1.0, 1e-320, 1e300, -1.0, 12.0]))
+    ints = st.one_of(st.integers(-2**31, 2**31 - 1), st.sampled_from([0, 1, 2, 96, 1920, 1080, 65536]))
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(doubles, min_size=19, max_size=19), st.lists(ints, min_size=3, max_size=3))
+    def check(d, i):
+        c = _lib.BsConfig()
+        c.cam_pos[:] = d[0:3]; c.cam_lookat[:] = d[3:6]; c.cam_up[:] = d[6:9]
+        c.fov, c.step_size, c.star_intensity, c.star_saturation = d[9:13]
+        c.disk_hsi[:] = d[13:16]
+        c.disk_opacity, c.disk_inner, c.disk_outer = d[16:19]
+        c.width, c.height, c.supersampling = i
+        rc = L.bs_validate_config(C.byref(c))
+        assert rc in (0, -1)
+        if rc == 0:
+            assert all(math.isfinite(x) for x in d) and d[10] > 0 and d[17] >= 0 and d[18] >= 0
+            assert c.width > 0 and c.height > 0 and 0 <= d[13] < 1
+            assert sum((a - b) * (a - b) for a, b in zip(d[0:3], d[3:6])) > 1e-12
+        else:
+            assert _lib.last_error()
+
+    check()
