@@ -50,6 +50,26 @@ WORKLOAD_C3 = ("scenes/default-aa.yaml 1920x1080, 4x supersample (8,294,400 rays
                "direction-grid star lookup (BASELINE configs[2])")
 WORKLOAD_C5 = ("animations/default-ani.yaml, nFrames=600, 1920x1080, 4x supersample, {cat}, "
                "frame i on rank i % N (BASELINE configs[4]); roofline figures refer to the LAST frame rendered")
+# The single-frame BASELINE configs that fit one GPU: scene file, resolution override, whether the star map is part of the config.
+WORKLOADS = {
+    "default-aa": {"scene": "default-aa.yaml", "resolution": None, "stars": True, "baseline": "configs[2]", "label": WORKLOAD_C3,
+                   "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml"},
+    "default": {"scene": "default.yaml", "resolution": None, "stars": False, "baseline": "configs[1]",
+                "label": "scenes/default.yaml 1920x1080, no supersampling (2,073,600 rays/frame), NO star map: disk + horizon only (BASELINE configs[1])",
+                "metric": "Mpixel/s (geodesic rays/s) on default.yaml, no star map"},
+    "lensing-4k": {"scene": "lensing-disk.yaml", "resolution": (3840, 2160), "stars": True, "baseline": "configs[3]",
+                   "label": "scenes/lensing-disk.yaml at 3840x2160, 4x supersample (33,177,600 rays/frame), {cat}, direction-grid star lookup "
+                            "(BASELINE configs[3]: close-orbit long geodesics)",
+                   "metric": "Mpixel/s (geodesic rays/s) on lensing-disk.yaml at 3840x2160"},
+    "animation": {"label": WORKLOAD_C5, "baseline": "configs[4]", "stars": True, "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml"},
+}
+
+
+def workload_config(bs, name):
+    """The Config of a single-frame workload: the scene file as the reference ships it, with BASELINE's resolution override."""
+    w = WORKLOADS[name]
+    cfg = bs.Config.from_file(os.path.join(ROOT, "scenes", w["scene"]))
+    return cfg.with_resolution(*w["resolution"]) if w["resolution"] else cfg
 CATALOGUES = {"synthetic": "470k-star synthetic PPM-layout catalogue (uniform sky, SURVEY 8d recipe)",
               "clustered": "686k-star NON-uniform synthetic PPM-layout catalogue (the 470k uniform stars + 3000 clusters of 6..40 stars "
                            "inside 0.001 rad + a band at 10x the mean density; blackstar_amd/synthetic.py)"}
@@ -140,12 +160,13 @@ def cpu_baseline(cfg, star_bytes, budget_s):
             threads = max(1, min(threads, int(round(int(quota) / int(period)))))
     except (OSError, ValueError):
         pass
-    ix = c_oracle.Index(c_oracle.read_ppm(star_bytes))
+    ix = c_oracle.Index(c_oracle.read_ppm(star_bytes) if star_bytes else None)
     probe = scenes.with_res(cfg, 96, 54)
     _, st = c_oracle.render(probe, ix, threads=threads)
     rate = st["rays"] / max(st["seconds"], 1e-6)  # rays/s
-    rays = min(rate * budget_s, 4.0 * cfg["width"] * cfg["height"])
-    scale = (rays / (4.0 * cfg["width"] * cfg["height"])) ** 0.5
+    ss = 4.0 if cfg["supersampling"] else 1.0
+    rays = min(rate * budget_s, ss * cfg["width"] * cfg["height"])
+    scale = (rays / (ss * cfg["width"] * cfg["height"])) ** 0.5
     w = max(16, int(cfg["width"] * scale) // 16 * 16)
     h = max(9, w * cfg["height"] // cfg["width"])
     sample = scenes.with_res(cfg, w, h)
@@ -160,7 +181,8 @@ def cpu_baseline(cfg, star_bytes, budget_s):
           "config": "scenes/default.yaml 1920x1080, no supersampling, no star map (BASELINE configs[1]), the whole frame"}
     return {"value": w * h / st["seconds"] / 1e6, "unit": "Mpixel/s", "cores": int(st["threads"]), "kind": "port", "configs0": c1, "configs1": c2,
             "rays_per_s": st["rays"] / st["seconds"], "seconds": st["seconds"],
-            "sample": f"default-aa.yaml camera at {w}x{h} output px (4x supersampled = {st['rays']} rays), same {len(ix.stars)}-star catalogue, "
+            "sample": f"the workload's camera and scene at {w}x{h} output px ({'4x supersampled = ' if ss > 1 else ''}{st['rays']} rays), "
+                      f"{'same %d-star catalogue' % len(ix.stars) if star_bytes else 'no star map'}, "
                       f"C restatement of the reference CPU path (oracle/blackstar_oracle.c, -O2, pthreads over rows)"}
 
 
@@ -227,9 +249,10 @@ def parse_args():
                          "the first launches after an idle spell run 5.3, 5.0, 4.8, 4.65, 4.5, 4.4 ms before the clocks settle at 4.3 (kernel_ms_each), "
                          "so the default gives that ramp ten launches")
     ap.add_argument("--mode", choices=["strict", "fast"], default=os.environ.get("BLACKSTAR_BENCH_MODE", "fast"))
-    ap.add_argument("--workload", choices=["default-aa", "animation"], default="default-aa",
-                    help="default-aa = BASELINE configs[2] (the headline metric); animation = configs[4]: frames of "
-                         "animations/default-ani.yaml (nFrames overridden to 600), frame i on rank i %% N")
+    ap.add_argument("--workload", choices=["default-aa", "default", "lensing-4k", "animation"], default="default-aa",
+                    help="default-aa = BASELINE configs[2] (the headline metric); default = configs[1]: scenes/default.yaml 1920x1080, no "
+                         "supersampling, no star map; lensing-4k = configs[3]: scenes/lensing-disk.yaml at 3840x2160, 4x supersample; "
+                         "animation = configs[4]: frames of animations/default-ani.yaml (nFrames overridden to 600), frame i on rank i %% N")
     ap.add_argument("--launcher", choices=["auto", "single-process", "torchrun"], default="auto",
                     help="how --gpus N > 1 runs when no torch.distributed launcher started this process "
                          "(auto = single-process: N contexts, one per device, in this process)")
@@ -243,10 +266,15 @@ def parse_args():
     ap.add_argument("--catalogue", default="synthetic",
                     help="synthetic (uniform 470k-star sky, the BASELINE input) | clustered (non-uniform: + clusters + a dense band) | "
                          "PATH of a real PPM catalogue file in the layout src/StarMap.hs:45-58 reads (reported separately)")
-    ap.add_argument("--form", choices=["all", "resident", "batch", "rgb8-batch", "png-batch", "png-files"], default="all",
-                    help="`value` is the resident form (image stays in HBM) unless batch / rgb8-batch / png-batch is named here; all (default) = "
-                         "resident as `value` plus the with_d2h block (bs_render_batch, bs_render_rgb8_batch and bs_render_png_batch into "
-                         "page-locked host memory)")
+    ap.add_argument("--form", choices=["all", "resident", "batch", "rgb8-batch", "png-batch", "png-files", "split"], default="all",
+                    help="`value` is the resident form (image stays in HBM) unless batch / rgb8-batch / png-batch / png-files / split is named here; "
+                         "all (default) = resident as `value` plus the with_d2h block (bs_render_batch, bs_render_rgb8_batch, bs_render_png_batch, "
+                         "bs_render_png_files into page-locked host memory, and `split`).  split = ONE frame of BASELINE configs[3] (lensing-disk at "
+                         "3840x2160) cut into row bands over all N GPUs (bs_render_split / bs_render_rows, SURVEY 8e's fallback for a single huge "
+                         "frame): total work is fixed, so the line says \"scaling\": \"strong\"")
+    ap.add_argument("--no-validate", action="store_true",
+                    help="skip the untimed validation after the timed region (every device renders the same frame once more; the frames must be "
+                         "bit-identical and the step counters equal)")
     ap.add_argument("--sustained-frames", type=int, default=500, help="frames of the `sustained` leg after the timed region (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bs_render / bs_render_rgb8 / STRICT / ubench legs at N=1")
@@ -259,7 +287,7 @@ def parse_args():
 
 
 def load_workload(args, bs):
-    cfg_obj = bs.Config.from_file(os.path.join(ROOT, "scenes", "default-aa.yaml"))
+    cfg_obj = workload_config(bs, "default-aa" if args.workload == "animation" else args.workload)
     cfg = cfg_obj.to_bs_config()
     frames_cfg = frames_obj = None
     if args.workload == "animation":
@@ -272,14 +300,30 @@ def load_workload(args, bs):
     return cfg_obj, cfg, frames_cfg, frames_obj
 
 
-def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ranks):
+def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ranks, same_frames=False, all_ranks=None, split=None):
     """The product's own batch entry points with every frame DELIVERED to the host (SURVEY 8d/7.6 "with and without D2H"):
     frame_objs[i] (a Config; its scene carries bloomStrength / bloomDivider) goes to trees[i % len(trees)].  Output buffers are
     page-locked (bs_host_alloc), a ring of 4 per context: two frames are in flight per context, so frame k's buffer is free again
     by the time frame k + 4 is enqueued -- the consumer (the reference writes each frame to a PNG file, app/Main.hs:121-123) is
-    NOT part of the timed region.  Timed like the headline: fence, one blocking call, fence; max over ranks."""
+    NOT part of the timed region.  Timed like the headline: fence, one blocking call, fence; max over ranks.
+    same_frames: every frame_objs[i] is the same scene, so after the timed call (untimed) every delivered frame -- whichever context, device
+    or rank made it -- must be byte-identical to the first: `frames_identical` (None when the frames differ by design: the animation).
+    all_ranks(x) -> every rank's x; split() -> the `split` block (split_leg), supplied by the caller who knows the ranks."""
     n_t = len(trees)
     res = {}
+
+    def identical_everywhere(blobs):
+        """blobs: this process's delivered frames (arrays or bytes).  All equal here, and -- through 48 bits of a digest -- on every rank.
+        With ranks this is a collective: every rank calls it, also one that has nothing to show (which makes the answer False)."""
+        if not same_frames:
+            return None
+        arrs = [np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray, memoryview)) else np.asarray(b) for b in blobs]
+        here = bool(arrs) and all(np.array_equal(a, arrs[0]) for a in arrs[1:])
+        if all_ranks is None:
+            return here if arrs else None
+        marks = all_ranks(digest_as_float(frame_digest(np, arrs[0])) if here else -1.0)
+        return bool(min(marks) >= 0 and len(set(marks)) == 1)
+
     FORMS = {
         "batch": dict(key="batch", entry="bs_render_batch", call=lambda fo, o: bs.render_batch(fo, trees, outs=o),
                       alloc=lambda t: bs.alloc_image(t, H, W, dtype=np.float64), nbytes=lambda r: W * H * 3 * 8,
@@ -293,8 +337,12 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                                "the finished file is all that reaches the host (bytes_to_host_per_frame = its mean size); what is left for the host is write(2)"),
     }
     for form in forms:
+        if form == "split":
+            if split is not None:
+                res["split"] = split()
+            continue
         if form == "png-files":
-            res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks)
+            res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere)
             continue
         F = FORMS[form]
         rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
@@ -320,7 +368,9 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
         per_gpu = len(frame_objs) / n_t
         res[F["key"]] = {
             "Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
-            "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"]}
+            "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"],
+            # (ring buffers: the distinct ones hold the last frame written into each; PNG: every file of the call)
+            "frames_identical": identical_everywhere([bytes(g) for g in got] if form == "png-batch" else list({id(o): o for o in outs}.values()))}
         if form == "png-batch" and hasattr(bs, "render_rgb8"):
             # what the same file costs the way the reference makes it (JuicyPixels over zlib, one core): this frame's pixels through zlib
             # on ONE host core, the Sub-filtered scanlines at levels 1 and 6 -- a reported baseline like cpu_baseline, outside every timed region
@@ -339,7 +389,7 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
     return res
 
 
-def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks):
+def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere=None):
     """The reference's batch loop to the very end: every frame rendered, bloomed, encoded AND written to a file by ONE bs_render_png_files
     call (frames in flight on the GPUs, a native writer thread on page-locked buffers), into a fresh directory on the RAM disk (or the
     temp directory) that is removed afterwards.  One untimed call first, like the other delivered forms."""
@@ -359,7 +409,7 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks):
     if max_over_ranks(0.0 if base else 1.0) > 0:
         return {"skipped": f"no directory with {need >> 20} MiB free on some rank (/dev/shm, {tempfile.gettempdir()})"}
     d = tempfile.mkdtemp(prefix="blackstar_bench_", dir=base)
-    err, dt_local, size = None, float("inf"), 0
+    err, dt_local, size, files = None, float("inf"), 0, None
     try:
         paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
         try:
@@ -373,19 +423,25 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks):
                 bs.render_png_files(frame_objs, trees, paths)
                 dt_local = time.perf_counter() - t0
                 size = sum(os.path.getsize(p) for p in paths)
+                if identical_everywhere is not None:  # read back before the directory goes (untimed; a few distinct files would do, all is simplest)
+                    files = []
+                    for p in paths:
+                        with open(p, "rb") as f:
+                            files.append(f.read())
             except Exception as e:
                 err = f"{type(e).__name__}: {e}"
         fence()
     finally:
         shutil.rmtree(d, ignore_errors=True)
     dt = max_over_ranks(dt_local)
+    same = identical_everywhere(files or []) if identical_everywhere is not None else None   # (a collective when there are ranks: every rank calls it)
     if err is not None or dt == float("inf"):
         return {"error": err or "another rank failed"}
     frames = len(frame_objs) * world
     per_gpu = len(frame_objs) / len(trees)
     return {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
             "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
-            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base,
+            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same,
             "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device, write(2) by a native writer thread while the next frames render "
                     "(app/Main.hs:68-77 incl. writeImg's write)"}
 
@@ -418,6 +474,141 @@ def sustained_leg(bs, torch, np, trees, cfgs, outs, streams, devs, n_frames):
         per_dev.append({"ms_per_frame": marks[k][0].elapsed_time(marks[k][-1]) / n_frames, "ms_first_50": seg[0], "ms_last_50": seg[-1],
                         "ms_slowest_50": max(seg)})
     return wall, per_dev
+
+
+def frame_digest(np, frame):
+    """sha256 of a frame's bytes (a torch tensor resident on any device, or a numpy array).  Untimed: the image crosses PCIe once."""
+    import hashlib
+    a = frame.detach().cpu().numpy() if hasattr(frame, "detach") else np.asarray(frame)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def digest_as_float(hexdigest):
+    """48 bits of a digest as a float (exact in binary64): lets equality of frames be decided through the float collectives."""
+    return float(int(hexdigest[:12], 16))
+
+
+COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
+
+
+def validation_block(per_device, what, repeat_digest=None):
+    """What makes an N > 1 line prove itself: per_device = one (sha256 of the frame, bs_stats dict) per device /
+    rank, all of the SAME frame rendered once more after the timed region.  The arithmetic is deterministic, so the frames must be
+    bit-identical and every counter equal; a mismatch makes the line "valid": false (the measurement is still printed)."""
+    digests = [d for d, _ in per_device]
+    identical = len(set(digests)) == 1
+    counters = {k: [int(st[k]) for _, st in per_device] for k in COUNTERS}
+    counters_equal = all(len(set(v)) == 1 for v in counters.values())
+    out = {"frame": what, "devices_compared": len(per_device), "frames_identical_across_devices": identical,
+           "frame_sha256_per_device": [d[:16] for d in digests], "steps_per_device": counters["steps"],
+           "counters_identical_across_devices": counters_equal,
+           "counters_device0": {k: v[0] for k, v in counters.items()}}
+    if not counters_equal:
+        out["counters_per_device"] = counters
+    valid = identical and counters_equal and all(v > 0 for v in counters["steps"])
+    if repeat_digest is not None:  # the same frame twice on device 0: the kernel is deterministic run to run
+        out["repeat_identical_on_device0"] = repeat_digest == digests[0]
+        valid = valid and out["repeat_identical_on_device0"]
+    out["valid"] = bool(valid)
+    return out
+
+
+def per_config_block(bs, torch, np, _lib, tree, args, device):
+    """BASELINE configs[1] and configs[3] in the default line: per config, two untimed launches, then three launches
+    each bracketed by HIP events on the launch stream, image resident in HBM like the headline.  frac = 145 flop x executed RK4 steps /
+    mean launch time / the FP64 vector peak, exactly like roofline.frac.  About 0.15 s in all; runs right after the timed region, while
+    the clocks are up."""
+    res = {}
+    for name in ("default", "lensing-4k"):
+        wl = WORKLOADS[name]
+        cfg = workload_config(bs, name).to_bs_config()
+        W, H = cfg["width"], cfg["height"]
+        t = tree
+        if not wl["stars"]:  # configs[1] has no star map: its own context, built from an empty star set
+            t = bs.StarTree(None, device=device)
+            t.set_mode(_lib.BS_MODE_FAST if args.mode == "fast" else _lib.BS_MODE_STRICT)
+        try:
+            img = torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
+            stream = torch.cuda.current_stream()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            for _ in range(2):
+                bs.render_device(cfg, t, img.data_ptr(), img.numel(), stream.cuda_stream)
+            for a, b in ev:
+                a.record(stream)
+                bs.render_device(cfg, t, img.data_ptr(), img.numel(), stream.cuda_stream)
+                b.record(stream)
+            torch.cuda.synchronize()
+            st = t.stats()
+            each = [float(a.elapsed_time(b)) for a, b in ev]
+            ms = float(np.mean(each))
+            executed = int(st["steps"]) - int(st["rays"])
+            tf = FLOP_PER_STEP * executed / (ms * 1e-3) / 1e12
+            res[name] = {"workload": wl["label"].format(cat="same catalogue as the headline"), "baseline_config": wl["baseline"],
+                         "ms": ms, "ms_each": [round(x, 4) for x in each], "Mpixel_s": W * H / ms / 1e3, "rays": int(st["rays"]),
+                         "steps": int(st["steps"]), "rk4_steps_executed": executed, "achieved_TFLOPs": tf, "frac": tf / PEAK_FP64_VALU_TFLOPS,
+                         "lane_efficiency": st["steps"] / (64.0 * st["wave_iters"]), "effective_mode": ["strict", "fast"][int(st["effective_mode"])],
+                         "frame_sha256": frame_digest(np, img)[:16]}
+            del img
+        finally:
+            if t is not tree:
+                t.close()
+    return res
+
+
+def split_leg(bs, np, trees, rank, world, fence, max_over_ranks, gather_objs, reps=3):
+    """ONE frame of BASELINE configs[3] (lensing-disk at 3840x2160, 4x supersample) cut into row bands over all GPUs -- SURVEY 8e's
+    fallback for a single huge frame.  One process with N contexts: bs_render_split (one host thread per context, every GPU writes its
+    band straight into the caller's page-locked frame).  One process per GPU: each rank renders band `rank` with bs_render_rows.  Either
+    way the bands are compared byte for byte with the whole frame rendered by ONE device (untimed), and the one-device time of the
+    same call is reported beside it: total work is fixed, so this is the strong-scaling figure."""
+    from blackstar_amd.distributed import shard_rows
+    cfg_obj = workload_config(bs, "lensing-4k")
+    cfg = cfg_obj.to_bs_config()
+    W, H = cfg["width"], cfg["height"]
+    n_t = len(trees)
+    n_parts = n_t * world
+    ref = bs.alloc_image(trees[0], H, W)
+
+    def timed(fn):
+        fn()  # untimed: buffers touched, streams made
+        ts = []
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            fence()
+            ts.append(max_over_ranks(time.perf_counter() - t0))
+        return ts
+
+    one = timed(lambda: bs.render(cfg, trees[0], out=ref))   # the whole frame on one device (every rank does this: its own reference)
+    st1 = trees[0].stats()
+    ref_steps = int(st1["steps"])
+    if world == 1:
+        full = bs.alloc_image(trees[0], H, W)
+        full[:] = 0
+        ts = timed(lambda: bs.render_split(cfg, trees, out=full))
+        identical = bool(np.array_equal(full, ref))
+        bands = [shard_rows(H, k, n_t) for k in range(n_t)]
+        entry = "bs_render_split"
+    else:
+        row0, row1 = shard_rows(H, rank, world)
+        band = bs.alloc_image(trees[0], row1 - row0, W)
+        band[:] = 0
+        ts = timed(lambda: bs.render_rows(cfg, trees[0], row0, row1, out=band))
+        mine = bool(np.array_equal(band, ref[row0:row1]))   # this rank's band against this rank's own whole frame ...
+        got = gather_objs((mine, frame_digest(np, ref), (row0, row1)))
+        identical = all(g[0] for g in got) and len({g[1] for g in got}) == 1   # ... and every rank's whole frame is the same frame
+        bands = [g[2] for g in got]
+        entry = "bs_render_rows (one band per rank)"
+    dt, dt_one = float(np.mean(ts)), float(np.mean(one))
+    return {"Mpixel_s": W * H / dt / 1e6, "ms_per_frame": dt * 1e3, "ms_each": [round(t * 1e3, 4) for t in ts], "seconds": dt, "frames": 1,
+            "parts": n_parts, "bands": [list(b) for b in bands], "entry_point": entry,
+            "one_device_ms_per_frame": dt_one * 1e3, "one_device_Mpixel_s": W * H / dt_one / 1e6, "speedup_vs_one_device": dt_one / dt,
+            "identical_to_one_device": identical, "one_device_steps": ref_steps, "bytes_to_host_per_frame": W * H * 24,
+            "one_device_stats": {k: (float(st1[k]) if k == "kernel_ms" else int(st1[k])) for k in ("rays", "steps", "wave_iters", "kernel_ms")},
+            "workload": WORKLOADS["lensing-4k"]["label"].format(cat="same catalogue as the headline"),
+            "note": "ONE frame, row bands over all GPUs, RGB f64 written into page-locked host memory by the kernels themselves; blocking call, "
+                    f"mean of {reps}; strong scaling: speedup_vs_one_device is the figure for a single huge frame (SURVEY 8e)"}
 
 
 def optional_leg(name, safe, fn):
@@ -553,16 +744,38 @@ def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
     return res, strict
 
 
+def forms_valid(d2h):
+    """False if any delivered form of this line found frames that should be identical and are not."""
+    if not isinstance(d2h, dict):
+        return True
+    return all(v.get("frames_identical") is not False and v.get("identical_to_one_device") is not False for v in d2h.values() if isinstance(v, dict))
+
+
+def split_headline(args, res, blk, world):
+    """--form split: ONE frame over all GPUs is the result.  The line keeps the contract's keys, read for one frame: steps = 1 frame,
+    ms_per_step = its wall time, scaling = strong (total work fixed as N grows)."""
+    wl = WORKLOADS["lensing-4k"]
+    res.update({"metric": wl["metric"] + ", ONE frame split by rows over all GPUs", "scaling": "strong", "steps": 1, "ms_per_step": blk["ms_per_frame"]})
+    res["config"].update({"workload": blk["workload"], "baseline_config": wl["baseline"], "parallelism": f"row bands x{blk['parts']}",
+                          "frames_per_step_per_gpu": f"1/{blk['parts']}", "image": blk["note"]})
+    res["split"] = {k: blk[k] for k in ("speedup_vs_one_device", "one_device_ms_per_frame", "identical_to_one_device", "bands", "entry_point")}
+    for k in ("rays_per_s", "steps_per_ray", "lane_efficiency", "kernel_ms", "kernel_ms_last_hipevent"):
+        res.pop(k, None)   # they describe the warm-up launches' statistics, not the split frame
+    st1 = blk["one_device_stats"]   # the roofline of this frame: its kernel on ONE device, whole frame (hipEvent time from bs_stats)
+    res["roofline"] = dict(roofline_block(args, st1, st1["kernel_ms"], 3840, 2160), time_basis="the whole frame's kernel on one device (bs_stats.kernel_ms, HIP events)")
+
+
 def result_line(args, world, launcher, value, dt, W, H, frames_cfg, st, kernel_ms, extra_cfg=None, peak_measured=None, cat_note=CATALOGUES["synthetic"]):
     overlapped = bool(extra_cfg) and extra_cfg.get("launches_in_flight_per_gpu", 1) > 1
-    cfgd = {"workload": (WORKLOAD_C3 if frames_cfg is None else WORKLOAD_C5).format(cat=cat_note), "mode": args.mode, "frames_per_step_per_gpu": 1,
+    wl = WORKLOADS[getattr(args, "workload", "default-aa") if frames_cfg is None else "animation"]
+    cfgd = {"workload": wl["label"].format(cat=cat_note), "baseline_config": wl["baseline"], "mode": args.mode, "frames_per_step_per_gpu": 1,
             "parallelism": f"frame-sharded x{world}", "launcher": launcher,
             "image": "RGB f64 resident in HBM (no D2H in the timed region)"}
     if extra_cfg:
         cfgd.update(extra_cfg)
     frames = args.steps * world
     return {
-        "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml", "value": value, "unit": "Mpixel/s",
+        "metric": wl["metric"], "value": value, "unit": "Mpixel/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if args.catalogue in CATALOGUES else "synthetic scene + real catalogue file",
@@ -620,9 +833,13 @@ def run_ranks(args):
                 "version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None}
 
     cfg_obj, cfg, frames_cfg, frames_obj = load_workload(args, bs)
+    if args.form == "split":  # the split form has its own frame (configs[3]); the warm-up launches use it too
+        cfg_obj = workload_config(bs, "lensing-4k")
+        cfg = cfg_obj.to_bs_config()
     W, H = cfg["width"], cfg["height"]
-    star_bytes = synthetic.catalogue_bytes(args.catalogue)
-    stars = bs.read_map(star_bytes)
+    with_stars = WORKLOADS[args.workload]["stars"] or args.form == "split"   # configs[1] is "no starmap": an empty star set
+    star_bytes = synthetic.catalogue_bytes(args.catalogue) if with_stars else None
+    stars = bs.read_map(star_bytes) if with_stars else bs.read_map(bytes(28))   # (28 header bytes, no records)
     if world > ndev:  # smoke mode: ranks share a device, and every context would set the SAME few CUs aside for its post stage
         os.environ.setdefault("BLACKSTAR_POST_CUS", "0")
     tree = bs.StarTree(stars, device=local_rank)
@@ -660,6 +877,13 @@ def run_ranks(args):
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         return [float(v.item()) for v in allt]
+
+    def gather_objs(o):  # every rank's (small, picklable) object, in rank order -- validation only, never inside a timed region
+        if world == 1:
+            return [o]
+        objs = [None] * world
+        dist.all_gather_object(objs, o)
+        return objs
 
     def gather_to_root():  # optional (--gather): each rank's finished frame goes to rank 0 over xGMI
         src = out if backend == "nccl" else out.cpu()
@@ -708,18 +932,42 @@ def run_ranks(args):
         allt = all_ranks(dt_local)
         per_rank_ms = [t / args.steps * 1e3 for t in allt]
         dt = max(allt)  # MAX over ranks
-    else:  # --form batch | rgb8-batch | png-batch: that form IS the timed region (warm-up inside d2h_forms, same fence discipline)
+    else:  # --form batch | rgb8-batch | png-batch | png-files | split: that form IS the timed region (warm-up inside d2h_forms, same fence discipline)
         for _ in range(max(1, args.warmup)):
             step()
         fence()
         st = tree.stats()
         t_gather = None
 
+    # BASELINE configs[1] and configs[3] beside the headline, while the clocks are still up (N = 1, the default workload)
+    per_config = None
+    if world == 1 and resident and args.workload == "default-aa" and not args.no_boundary:
+        per_config = optional_leg("per_config", True, lambda: per_config_block(bs, torch, np, _lib, tree, args, local_rank))
+
+    # Untimed validation: every rank renders the SAME frame once more (the animation: its frame 0); the frames must be bit-identical
+    validation = None
+    if not args.no_validate:
+        def validate():
+            vcfg = cfg if frames_cfg is None else frames_cfg[0]
+            digests = []
+            for _ in range(2 if rank == 0 else 1):   # rank 0 twice: run-to-run determinism
+                out.zero_()
+                bs.render_device(vcfg, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                digests.append(frame_digest(np, out))
+            vst = tree.stats()
+            got = gather_objs((digests[0], {k: int(vst[k]) for k in COUNTERS}))
+            what = "the workload's frame" if frames_cfg is None else "frame 0 of the animation"
+            return validation_block(got, what + ", rendered once more on every rank after the timed region (untimed)", digests[1] if rank == 0 else None)
+        validation = optional_leg("validation", world == 1, validate)
+
     d2h = None
-    want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"], "resident": []}.get(args.form, [args.form])
+    want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"] + (["split"] if with_stars else []), "resident": []}.get(args.form, [args.form])
     if want:
         d2h = optional_leg("with_d2h", world == 1 and resident,
-                           lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x))))
+                           lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x)),
+                                             same_frames=frames_obj is None, all_ranks=all_ranks if world > 1 else None,
+                                             split=lambda: split_leg(bs, np, [tree], rank, world, fence, lambda x: max(all_ranks(x)), gather_objs)))
 
     def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
@@ -766,7 +1014,14 @@ def run_ranks(args):
             extra["image"] = d2h[key]["note"]
             per_rank_ms = [kernel_ms] * world
         res = result_line(args, world, launcher, value, dt, W, H, frames_cfg, st, kernel_ms, extra, peak, catalogue_note(args, len(stars)))
+        if args.form == "split":
+            split_headline(args, res, d2h["split"], world)
         res["per_rank_ms_per_step"] = per_rank_ms
+        if validation is not None:
+            res["validation"] = validation
+            res["valid"] = bool(validation.get("valid", False)) and forms_valid(d2h)
+        if per_config is not None:
+            res["per_config"] = per_config
         if resident and n_streams == 1:
             res["kernel_ms_each"] = [round(x, 4) for x in kernel_each]  # the timed launches one by one (rank 0): a clock ramp after the idle start-up shows here
         if rccl is not None:
@@ -783,7 +1038,7 @@ def run_ranks(args):
             res["boundary"], res["strict"] = both if isinstance(both, tuple) else (both, both)
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds))
-        if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and frames_cfg is None:
+        if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and args.workload == "default-aa":
             # LAST: the profiler's child processes run after every timed leg of this process (a PMC session may leave the device in
             # another clock state for a while), and only the counter values are taken from them
             try:
@@ -814,9 +1069,12 @@ def run_single_process(args):
     ndev = torch.cuda.device_count()
     devs = [i % ndev for i in range(world)]
     cfg_obj, cfg, frames_cfg, frames_obj = load_workload(args, bs)
+    if args.form == "split":  # the split form has its own frame (configs[3]); the warm-up launches use it too
+        cfg_obj = workload_config(bs, "lensing-4k")
+        cfg = cfg_obj.to_bs_config()
     W, H = cfg["width"], cfg["height"]
-    star_bytes = synthetic.catalogue_bytes(args.catalogue)
-    stars = bs.read_map(star_bytes)
+    with_stars = WORKLOADS[args.workload]["stars"] or args.form == "split"   # configs[1] is "no starmap": an empty star set
+    stars = bs.read_map(synthetic.catalogue_bytes(args.catalogue)) if with_stars else bs.read_map(bytes(28))
     n_streams = args.streams or (2 if frames_cfg is not None else 1)
     trees, outs, streams, lanes = [], [], [], []
     if world > ndev:  # smoke mode: contexts share a device, and every one of them would set the SAME few CUs aside for its post stage
@@ -898,12 +1156,33 @@ def run_single_process(args):
         value = args.steps * world * W * H / dt / 1e6
     st = trees[0].stats()
 
+    # Untimed validation: every device renders the SAME frame once more (the animation: its frame 0); the frames must be bit-identical
+    validation = None
+    if not args.no_validate:
+        def validate():
+            vcfg = cfg if frames_cfg is None else frames_cfg[0]
+            got, repeat = [], None
+            for k in range(world):
+                for rep in range(2 if k == 0 else 1):   # device 0 twice: run-to-run determinism
+                    outs[k].zero_()
+                    bs.render_device(vcfg, trees[k], outs[k].data_ptr(), outs[k].numel(), streams[k].cuda_stream)
+                    torch.cuda.synchronize(devs[k])
+                    d = frame_digest(np, outs[k])
+                    if rep == 0:
+                        got.append((d, {c: int(v) for c, v in trees[k].stats().items() if c in COUNTERS}))
+                    else:
+                        repeat = d
+            what = "the workload's frame" if frames_cfg is None else "frame 0 of the animation"
+            return validation_block(got, what + ", rendered once more on every context after the timed region (untimed)", repeat)
+        validation = optional_leg("validation", True, validate)
+
     d2h = None
-    want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"], "resident": []}.get(args.form, [args.form])
+    want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"] + (["split"] if with_stars else []), "resident": []}.get(args.form, [args.form])
     if want:  # frame i on context i % world, args.steps frames per context, ONE call over all contexts
         n = args.steps * world
         objs = [cfg_obj] * n if frames_obj is None else [frames_obj[i % len(frames_obj)] for i in range(n)]
-        d2h = optional_leg("with_d2h", resident, lambda: d2h_forms(bs, np, trees, objs, W, H, 1, want, fence, lambda x: x))
+        d2h = optional_leg("with_d2h", resident, lambda: d2h_forms(bs, np, trees, objs, W, H, 1, want, fence, lambda x: x, same_frames=frames_obj is None,
+                                                                   split=lambda: split_leg(bs, np, trees, 0, 1, fence, lambda x: x, lambda o: [o])))
 
     def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
@@ -931,7 +1210,12 @@ def run_single_process(args):
         per_rank_ms, kms = [kernel_ms] * world, None
         extra["image"] = d2h[key]["note"]
     res = result_line(args, world, "single-process (N contexts)", value, dt, W, H, frames_cfg, st, kernel_ms, extra, None, catalogue_note(args, len(stars)))
+    if args.form == "split":
+        split_headline(args, res, d2h["split"], world)
     res["per_rank_ms_per_step"] = per_rank_ms
+    if validation is not None:
+        res["validation"] = validation
+        res["valid"] = bool(validation.get("valid", False)) and forms_valid(d2h)
     if kms:
         res["per_rank_kernel_ms"] = [float(np.mean(x)) for x in kms]
     if t_gather is not None:

@@ -567,6 +567,8 @@ int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg)
 int bs_set_max_steps(bs_ctx *ctx, int max_steps)
 {
     if (!ctx || max_steps <= 0) return fail(BS_EINVAL, "bad max_steps");
+    // the kernel counts a ray's steps in an int and the frame's in 64 bits: 2^30 rays (the largest frame) x 2^30 steps = 2^60
+    if (max_steps > BS_MAX_STEPS_LIMIT) return fail(BS_EINVAL, "max_steps above BS_MAX_STEPS_LIMIT (2^30): the step counters could not hold a frame of capped rays");
     ctx->max_steps = max_steps;
     return BS_OK;
 }

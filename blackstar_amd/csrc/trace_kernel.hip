@@ -718,10 +718,14 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
     wave_iters = (unsigned)it + 1u;  // iterations entered, including the one in which the last guards fired
 }
 
-__device__ __forceinline__ unsigned wave_sum(unsigned v)
+// 64-bit: a wavefront's step total passes 2^32 as soon as 64 lanes x tiles x steps does (a raised step cap on capped rays)
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
     return v;
 }
 
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 {
     __shared__ double s_lane[kLaneLdsDoubles];
     __shared__ int s_ints[3 * kBlock];
-    __shared__ unsigned s_stats[6 * kBlock];
+    __shared__ unsigned long long s_stats[6 * kBlock];
     const LaneLds lds(s_lane, s_ints);
 
     const int lane = threadIdx.x & 63;
@@ -778,10 +782,12 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         for (int c = 0; c < slot * P.stagger_cycles; c += 64 * 100) __builtin_amdgcn_s_sleep(100);
     }
 
-    // per-lane statistics summed over this wave's tiles live in LDS (six more registers held across trace_ray spill)
-    unsigned *stat = reinterpret_cast<unsigned *>(s_stats) + threadIdx.x;
+    // per-lane statistics summed over this wave's tiles live in LDS (six more registers held across trace_ray spill), as 64-bit
+    // words: touched once per tile, never in the stepping loop, and a lane's step total is unbounded in the tiles it traces
+    // (bs_set_max_steps x tiles per lane passes 2^32 on large frames of capped rays)
+    unsigned long long *stat = s_stats + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 6; k++) stat[k * kBlock] = 0u;
+    for (int k = 0; k < 6; k++) stat[k * kBlock] = 0ull;
     unsigned long long a_iters = 0;  // wave-uniform
     // The queue pop for tile t+1 is issued BEFORE tile t is traced (the returned index is not needed until the next
     // trip), so the ~1-2 us round trip of the device-scope atomic never stalls the wavefront.  Over-fetching past
@@ -828,28 +834,28 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
             double *dst = P.out + ((size_t)yb * P.out_w + xi) * 3;
             dst[0] = res.rgba[0]; dst[1] = res.rgba[1]; dst[2] = res.rgba[2];  // dropAlpha
         }
-        stat[0 * kBlock] += (unsigned)res.steps;
-        stat[1 * kBlock] += res.fate == 2 ? 1u : 0u;
-        stat[2 * kBlock] += res.fate == 0 ? 1u : 0u;
-        stat[3 * kBlock] += res.fate == 1 ? 1u : 0u;
-        stat[4 * kBlock] += (unsigned)res.disk_hits;
-        stat[5 * kBlock] += (unsigned)res.star_hits;
+        stat[0 * kBlock] += (unsigned long long)(unsigned)res.steps;
+        stat[1 * kBlock] += res.fate == 2 ? 1ull : 0ull;
+        stat[2 * kBlock] += res.fate == 0 ? 1ull : 0ull;
+        stat[3 * kBlock] += res.fate == 1 ? 1ull : 0ull;
+        stat[4 * kBlock] += (unsigned long long)(unsigned)res.disk_hits;
+        stat[5 * kBlock] += (unsigned long long)(unsigned)res.star_hits;
         a_iters += w_iters;
 #ifdef BS_TRACE_PROBE
         probe_t2 = wall_clock64();
         probe_tiles++;
 #endif
     }
-    const unsigned s_steps = wave_sum(stat[0 * kBlock]), s_cap = wave_sum(stat[1 * kBlock]), s_hor = wave_sum(stat[2 * kBlock]),
-                   s_esc = wave_sum(stat[3 * kBlock]), s_disk = wave_sum(stat[4 * kBlock]), s_star = wave_sum(stat[5 * kBlock]);
+    const unsigned long long s_steps = wave_sum(stat[0 * kBlock]), s_cap = wave_sum(stat[1 * kBlock]), s_hor = wave_sum(stat[2 * kBlock]),
+                             s_esc = wave_sum(stat[3 * kBlock]), s_disk = wave_sum(stat[4 * kBlock]), s_star = wave_sum(stat[5 * kBlock]);
     if (lane == 0) {
         atomicAdd(&P.counters[6], a_iters);
-        atomicAdd(&P.counters[0], (unsigned long long)s_steps);
-        if (s_cap) atomicAdd(&P.counters[1], (unsigned long long)s_cap);
-        if (s_hor) atomicAdd(&P.counters[2], (unsigned long long)s_hor);
-        if (s_esc) atomicAdd(&P.counters[3], (unsigned long long)s_esc);
-        if (s_disk) atomicAdd(&P.counters[4], (unsigned long long)s_disk);
-        if (s_star) atomicAdd(&P.counters[5], (unsigned long long)s_star);
+        atomicAdd(&P.counters[0], s_steps);
+        if (s_cap) atomicAdd(&P.counters[1], s_cap);
+        if (s_hor) atomicAdd(&P.counters[2], s_hor);
+        if (s_esc) atomicAdd(&P.counters[3], s_esc);
+        if (s_disk) atomicAdd(&P.counters[4], s_disk);
+        if (s_star) atomicAdd(&P.counters[5], s_star);
     }
 #ifdef BS_TRACE_PROBE
     const unsigned gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);

@@ -49,13 +49,17 @@ def render(cfg, startree: StarTree, out: np.ndarray = None) -> np.ndarray:
     return out
 
 
-def render_rows(cfg, startree: StarTree, row0: int, row1: int) -> np.ndarray:
+def render_rows(cfg, startree: StarTree, row0: int, row1: int, out: np.ndarray = None) -> np.ndarray:
     """Output rows [row0, row1) of the frame `cfg` describes, (row1-row0, width, 3): one band of a frame sharded by rows
-    over several GPUs.  Bands concatenated are bit-identical to render(cfg)."""
+    over several GPUs.  Bands concatenated are bit-identical to render(cfg).  `out`: the band's buffer (a page-locked
+    one from alloc_image is written by the kernel itself)."""
     c = _bs_config(cfg)
     if not (0 <= row0 < row1 <= c.height):
         raise ValueError(f"row band [{row0}, {row1}) outside the frame's {c.height} rows")
-    out = np.empty((row1 - row0, c.width, 3), np.float64)
+    if out is None:
+        out = np.empty((row1 - row0, c.width, 3), np.float64)
+    elif out.shape != (row1 - row0, c.width, 3) or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous float64 array of shape {(row1 - row0, c.width, 3)}")
     _lib.check(_lib.lib().bs_render_rows(startree.handle, C.byref(c), row0, row1, out.ctypes.data, out.size), "bs_render_rows")
     return out
 

@@ -287,7 +287,11 @@ int bs_get_mode(const bs_ctx *ctx);
  * with stepSize > 0.5 in STRICT (see BS_MODE_FAST above).  Returns BS_MODE_* or BS_EINVAL.  For batch frames (whose statistics
  * are not kept) this is the only way to know; perf numbers and A/B comparisons should record it. */
 int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg);
-int bs_set_max_steps(bs_ctx *ctx, int max_steps); /* safety cap; the reference has none (src/Raytracer.hs:80-86). default 100000 */
+/* Safety cap on colorize' iterations per ray; the reference has none (src/Raytracer.hs:80-86).  Default 100000.  1 <= max_steps <=
+ * BS_MAX_STEPS_LIMIT, BS_EINVAL otherwise: a ray's steps are an int in the kernel and bs_stats_t.steps a 64-bit sum (per lane, per
+ * wavefront and per frame), so the largest frame (2^30 traced rays) of capped rays still counts exactly: 2^30 x 2^30 = 2^60. */
+#define BS_MAX_STEPS_LIMIT (1 << 30)
+int bs_set_max_steps(bs_ctx *ctx, int max_steps);
 int bs_stats(bs_ctx *ctx, bs_stats_t *out);       /* synchronises the context's last render first */
 const char *bs_last_error(void);
 int bs_abi_version(void);

@@ -188,3 +188,155 @@ def test_catalogue_option_reads_a_real_ppm_file(tmp_path):
     assert len(synthetic.catalogue_bytes("clustered")) > len(synthetic.catalogue_bytes("synthetic"))
     args = types.SimpleNamespace(catalogue=str(path))
     assert "REAL catalogue file PPM (300 stars" in bench.catalogue_note(args, 300)
+
+
+def test_workloads_cover_every_single_gpu_baseline_config():
+    """--workload names BASELINE configs[1], [2], [3] (and [4], the animation); each resolves to the reference's scene file with BASELINE's
+    resolution override, and the result line names the config it measured."""
+    import blackstar_amd as bs
+    from oracle import scenes
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    for w in ("default-aa", "default", "lensing-4k", "animation", "split", "--no-validate"):
+        assert w in r.stdout, w
+    want = {"default": scenes.DEFAULT, "default-aa": scenes.DEFAULT_AA, "lensing-4k": scenes.with_res(scenes.LENSING_DISK, 3840, 2160)}
+    for name, ref in want.items():
+        got = bench.workload_config(bs, name).to_bs_config()
+        for k, v in ref.items():
+            assert np.allclose(got[k], v, rtol=0, atol=1e-15), (name, k, got[k], v)
+    assert [bench.WORKLOADS[w]["baseline"] for w in ("default", "default-aa", "lensing-4k", "animation")] == ["configs[1]", "configs[2]", "configs[3]", "configs[4]"]
+    assert not bench.WORKLOADS["default"]["stars"] and bench.WORKLOADS["lensing-4k"]["stars"]
+    st = {"steps": 1854063332, "rays": 8294400, "wave_iters": 29008800, "kernel_ms": 4.4}
+    for name in ("default", "lensing-4k"):
+        args = types.SimpleNamespace(steps=20, warmup=3, mode="fast", traffic_bytes=None, catalogue="synthetic", workload=name)
+        res = bench.result_line(args, 1, "single-process", 470.0, 0.0882, 1920, 1080, None, st, 4.41)
+        assert res["config"]["baseline_config"] == bench.WORKLOADS[name]["baseline"] and bench.WORKLOADS[name]["baseline"] in res["config"]["workload"]
+        assert res["metric"] == bench.WORKLOADS[name]["metric"] and "default-aa" not in res["metric"]
+
+
+def test_validation_block_tells_a_right_answer_from_a_wrong_one():
+    """The N > 1 line proves itself: same frame on every device -> same sha256, same counters; anything else is "valid": false."""
+    st = {"rays": 8294400, "steps": 1854063332, "capped": 0, "horizon": 350000, "escaped": 7944400, "disk_hits": 1700000, "star_hits": 9000000}
+    good = bench.validation_block([("ab" * 32, dict(st))] * 8, "frame", repeat_digest="ab" * 32)
+    assert good["valid"] and good["frames_identical_across_devices"] and good["devices_compared"] == 8 and good["steps_per_device"] == [st["steps"]] * 8
+    assert good["repeat_identical_on_device0"] and good["counters_identical_across_devices"] and "counters_per_device" not in good
+    bad_frame = bench.validation_block([("ab" * 32, dict(st))] * 7 + [("cd" * 32, dict(st))], "frame")
+    assert not bad_frame["valid"] and not bad_frame["frames_identical_across_devices"] and bad_frame["counters_identical_across_devices"]
+    bad_steps = bench.validation_block([("ab" * 32, dict(st)), ("ab" * 32, dict(st, steps=st["steps"] - 1))], "frame")
+    assert not bad_steps["valid"] and bad_steps["frames_identical_across_devices"] and not bad_steps["counters_identical_across_devices"]
+    assert bad_steps["counters_per_device"]["steps"] == [st["steps"], st["steps"] - 1]
+    idle = bench.validation_block([("ab" * 32, dict(st, steps=0))] * 2, "frame")      # a device that rendered nothing is not a right answer
+    assert not idle["valid"]
+    flaky = bench.validation_block([("ab" * 32, dict(st))] * 2, "frame", repeat_digest="ee" * 32)
+    assert not flaky["valid"] and not flaky["repeat_identical_on_device0"]
+    json.dumps(good)
+    assert bench.forms_valid(None) and bench.forms_valid({"batch": {"frames_identical": True}, "rgb8_batch": {"frames_identical": None}, "png_files": {"skipped": "x"}})
+    assert not bench.forms_valid({"batch": {"frames_identical": False}}) and not bench.forms_valid({"split": {"identical_to_one_device": False}})
+    # frames as numpy arrays or torch tensors hash by their bytes
+    a = np.arange(24, dtype=np.float64).reshape(2, 4, 3)
+    import torch
+    assert bench.frame_digest(np, a) == bench.frame_digest(np, torch.from_numpy(a.copy())) != bench.frame_digest(np, a + 1)
+    assert bench.digest_as_float("f" * 64) == float(0xFFFFFFFFFFFF)
+
+
+def test_d2h_forms_compare_delivered_frames_when_the_frames_are_the_same_scene():
+    """same_frames: after the timed call every delivered frame must equal the first -- on this rank and (48 bits of a digest through the
+    float collective) on every other; one differing frame, or one rank with another frame, makes frames_identical False."""
+    state = {"poison": None}
+
+    class Bs:
+        @staticmethod
+        def alloc_image(tree, h, w, dtype=np.float64):
+            return np.zeros((h, w, 3), dtype)
+
+        @staticmethod
+        def render_batch(cfgs, trees, outs=None):
+            for i, o in enumerate(outs):
+                o[:] = 7
+            if state["poison"] is not None:
+                outs[state["poison"]][0, 0, 0] = 8
+            return outs
+
+    common = (Bs, np, ["t0", "t1"], ["same"] * 12, 16, 8, 1, ["batch"], lambda: None, lambda x: x)
+    assert bench.d2h_forms(*common)["batch"]["frames_identical"] is None                      # frames differ by design (animation): not compared
+    assert bench.d2h_forms(*common, same_frames=True)["batch"]["frames_identical"] is True
+    state["poison"] = 5
+    assert bench.d2h_forms(*common, same_frames=True)["batch"]["frames_identical"] is False
+    state["poison"] = None
+    seen = []
+    r = bench.d2h_forms(*common, same_frames=True, all_ranks=lambda x: (seen.append(x), [x, x])[1])
+    assert r["batch"]["frames_identical"] is True and len(seen) == 1 and seen[0] >= 0
+    r = bench.d2h_forms(*common, same_frames=True, all_ranks=lambda x: [x, x + 1.0])          # the other rank delivered another frame
+    assert r["batch"]["frames_identical"] is False
+    state["poison"] = 0
+    seen.clear()
+    r = bench.d2h_forms(*common, same_frames=True, all_ranks=lambda x: (seen.append(x), [x, 5.0])[1])
+    assert r["batch"]["frames_identical"] is False and seen == [-1.0]                        # still a collective: every rank takes part
+    # the split leg is supplied by the caller
+    r = bench.d2h_forms(*common[:7], ["split"], *common[8:], split=lambda: {"Mpixel_s": 1.0, "identical_to_one_device": True})
+    assert r == {"split": {"Mpixel_s": 1.0, "identical_to_one_device": True}}
+
+
+def test_split_leg_single_process_and_per_rank():
+    """--form split: bs_render_split over N contexts in one process, or band `rank` of world per process; both compared with ONE device's
+    whole frame byte for byte, with the one-device time of the same blocking call beside it."""
+    H, W = 2160, 3840
+    calls = []
+
+    def pixel(rows):   # a frame whose content depends on the absolute row only
+        return np.broadcast_to(np.arange(rows.start, rows.stop, dtype=np.float64)[:, None, None], (len(rows), W, 3))
+
+    class Tree:
+        def stats(self):
+            return {"rays": 4 * H * W, "steps": 123456789, "wave_iters": 1000, "kernel_ms": 19.0}
+
+    class Bs:
+        Config = None
+
+        @staticmethod
+        def alloc_image(tree, h, w, dtype=np.float64):
+            return np.zeros((h, w, 3), dtype)
+
+        @staticmethod
+        def render(cfg, tree, out=None):
+            calls.append("render")
+            out[:] = pixel(range(0, H))
+            return out
+
+        @staticmethod
+        def render_split(cfg, trees, out=None):
+            calls.append(("split", len(trees)))
+            out[:] = pixel(range(0, H))
+            return out
+
+        @staticmethod
+        def render_rows(cfg, tree, row0, row1, out=None):
+            calls.append(("rows", row0, row1))
+            out[:] = pixel(range(row0, row1))
+            return out
+
+    import blackstar_amd as real
+    Bs.Config = real.Config
+    r = bench.split_leg(Bs, np, [Tree(), Tree(), Tree()], 0, 1, lambda: None, lambda x: x, lambda o: [o], reps=2)
+    assert r["identical_to_one_device"] and r["parts"] == 3 and r["entry_point"] == "bs_render_split" and r["bands"] == [[0, 720], [720, 1440], [1440, 2160]]
+    assert ("split", 3) in calls and r["one_device_steps"] == 123456789 and abs(r["speedup_vs_one_device"] - r["one_device_ms_per_frame"] / r["ms_per_frame"]) < 1e-9
+    assert r["frames"] == 1 and abs(r["Mpixel_s"] - W * H / r["seconds"] / 1e6) < 1e-6
+    calls.clear()
+    # rank 1 of 4: its band against its own whole frame, and every rank's whole frame is the same frame
+    gathered = []
+
+    def gather(o):
+        gathered.append(o)
+        return [(True, o[1], (0, 540)), o, (True, o[1], (1080, 1620)), (True, o[1], (1620, 2160))]
+
+    r = bench.split_leg(Bs, np, [Tree()], 1, 4, lambda: None, lambda x: x, gather, reps=1)
+    assert ("rows", 540, 1080) in calls and r["identical_to_one_device"] and r["parts"] == 4 and r["bands"][1] == [540, 1080]
+    r = bench.split_leg(Bs, np, [Tree()], 1, 4, lambda: None, lambda x: x, lambda o: [(True, "other frame", (0, 540)), o], reps=1)
+    assert not r["identical_to_one_device"]
+    # the headline built from it: strong scaling, one frame
+    args = types.SimpleNamespace(steps=20, warmup=3, mode="fast", traffic_bytes=None, catalogue="synthetic", workload="default-aa")
+    st = {"steps": 1854063332, "rays": 8294400, "wave_iters": 29008800, "kernel_ms": 4.4}
+    res = bench.result_line(args, 4, "x", r["Mpixel_s"], r["seconds"], W, H, None, st, 1.0)
+    bench.split_headline(args, res, r, 4)
+    assert res["scaling"] == "strong" and res["steps"] == 1 and res["config"]["baseline_config"] == "configs[3]" and "split" in res and "roofline" in res
+    assert res["config"]["parallelism"] == "row bands x4" and "lensing-disk" in res["metric"]
+    json.dumps(res)

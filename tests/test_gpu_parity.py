@@ -218,6 +218,38 @@ def test_step_cap_reports_capped_rays(tree_empty):
     assert st["capped"] == 144 and st["steps"] == 50 * 144
 
 
+def test_max_steps_limit_is_enforced(tree_empty):
+    L = _lib.lib()
+    assert L.bs_set_max_steps(tree_empty.handle, (1 << 30) + 1) == -1 and b"BS_MAX_STEPS_LIMIT" in L.bs_last_error()
+    assert L.bs_set_max_steps(tree_empty.handle, 0) == -1
+    assert L.bs_set_max_steps(tree_empty.handle, 1 << 30) == 0
+    assert L.bs_set_max_steps(tree_empty.handle, 100000) == 0
+
+
+@pytest.mark.timeout(600, method="thread")
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_statistics_do_not_wrap_at_2_pow_32(mode):
+    """the per-lane and per-wavefront step counters were 32-bit.  A frame of rays that NEVER terminate (stepSize
+    1e-9: 7e7 steps move a ray 0.07 Schwarzschild radii) with the cap raised to 2^26 + 11: every wavefront's step total is
+    64 x (2^26 + 11) > 2^32, so a 32-bit wave sum wraps; bs_stats.steps must equal rays x cap exactly."""
+    t = bs.StarTree(None, device=0)
+    try:
+        t.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+        cap = (1 << 26) + 11
+        t.set_max_steps(cap)
+        cfg = scenes.with_res(scenes.DEFAULT, 32, 16)   # 512 rays = 8 tiles = 8 wavefronts, one tile each
+        cfg["step_size"] = 1e-9
+        bs.render(cfg, t)
+        st = t.stats()
+        assert st["rays"] == 512 and st["capped"] == 512 and st["horizon"] == 0 and st["escaped"] == 0
+        assert st["steps"] == 512 * cap, (st["steps"], 512 * cap, st["steps"] - 512 * cap)
+        assert st["steps"] // 8 > 1 << 32           # the point of the test: one wavefront's total does not fit 32 bits
+        assert st["wave_iters"] == 8 * (cap + 1)
+        print(f"{mode}: {st['steps']} steps in {st['kernel_ms']:.0f} ms")
+    finally:
+        t.close()
+
+
 def test_error_behaviour(tree, catalogue_bytes):
     L = _lib.lib()
     cfg = _lib.make_config(scenes.with_res(scenes.DEFAULT, 8, 8))
