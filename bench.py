@@ -24,9 +24,18 @@ line carries, measured after the timed region (--form all, the default):
                        bloom, sRGB8 on the device, only RGB8 leaves the GPU
   with_d2h.png_batch   bs_render_png_batch: the same with writeImg's PNG encoder on the device too -- the finished FILE leaves the GPU
   with_d2h.png_files   bs_render_png_files: ... and is written to a RAM-disk file by the library's writer thread (scene to file)
+  with_d2h.split       ONE frame of BASELINE configs[3] (lensing-disk at 3840x2160) cut into row bands over all GPUs (bs_render_split, or
+                       bs_render_rows per rank), compared byte for byte with one device's frame; speedup_vs_one_device = strong scaling
+  per_config           N = 1: BASELINE configs[1] (default.yaml, no star map) and configs[3] (lensing-disk at 4K) -- hipEvent ms, Mpixel/s,
+                       steps, roofline frac of three launches each; --workload default | lensing-4k makes either the timed workload
+  validation / valid   after the timed region every device renders the same frame once more: the frames must be BIT-IDENTICAL across
+                       devices (sha256) and the step counters equal; every delivered form compares its frames too (frames_identical).
+                       A mismatch makes the line "valid": false -- a speed-up is only a result if the other GPUs rendered the scene
   sustained            500 more frames on one stream with per-50-frame times and sampled sclk / power (clock droop under the
                        package power cap is visible here, not in 20 launches)
 --catalogue clustered | PATH swaps the uniform synthetic sky for the non-uniform one or a real PPM catalogue file (reported as such).
+Which key answers BASELINE's ">= 6x at 8 GPUs": for frames (configs[4], and the headline) value(N=8) / value(N=1) of the driver's own runs
+-- weak scaling, "valid" must be true; for one huge frame with_d2h.split.speedup_vs_one_device of the N = 8 line (or --form split).
 """
 import argparse
 import gc
@@ -666,7 +675,7 @@ def measure_peak(tree, _lib):
     ms, gi = C.c_double(), C.c_double()
     best = 0.0
     for _ in range(3):
-        _lib.check(L.bs_debug_ubench(tree.handle, 0, 256 * 8, 20000, C.byref(ms), C.byref(gi)), "bs_debug_ubench")
+        _lib.check(_lib.debug_lib().bs_debug_ubench(tree.handle, 0, 256 * 8, 20000, C.byref(ms), C.byref(gi)), "bs_debug_ubench")
         best = max(best, gi.value / ms.value * 1e3)
     return {"Ginstr_per_s": best, "TFLOPs": best * 2 / 1e3, "detail": "v_fma_f64, 8 chains/lane, best of 3 (bs_debug_ubench)"}
 
@@ -1164,7 +1173,8 @@ def run_single_process(args):
             got, repeat = [], None
             for k in range(world):
                 for rep in range(2 if k == 0 else 1):   # device 0 twice: run-to-run determinism
-                    outs[k].zero_()
+                    with torch.cuda.device(devs[k]), torch.cuda.stream(streams[k]):   # (the clear on the stream the render is enqueued on)
+                        outs[k].zero_()
                     bs.render_device(vcfg, trees[k], outs[k].data_ptr(), outs[k].numel(), streams[k].cuda_stream)
                     torch.cuda.synchronize(devs[k])
                     d = frame_digest(np, outs[k])

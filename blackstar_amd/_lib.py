@@ -14,7 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BLACKSTAR_LIB") or os.path.join(_HERE, "libblackstar_gpu.so")  # BLACKSTAR_LIB: A/B builds of the same ABI
 
 BS_MODE_STRICT, BS_MODE_FAST = 0, 1
-BS_ABI_VERSION = 3  # include/blackstar_gpu.h
+BS_ABI_VERSION = 4  # include/blackstar_gpu.h
+BS_MAX_STEPS_LIMIT = 1 << 30
+# The test hooks (include/blackstar_gpu_debug.h) live in a library of their own, next to the product it was built with; only tests,
+# scripts/ and bench.py's issue-rate probe load it (debug_lib()).
+DEBUG_SO_PATH = SO_PATH[:-3] + "_debug.so" if SO_PATH.endswith(".so") else SO_PATH + "_debug"
 
 
 class BsConfig(C.Structure):
@@ -36,14 +40,19 @@ STAR_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("hue", "<f8"),
 RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4), ("steps", "<i4"), ("fate", "<i4"),
                          ("disk_hits", "<i4"), ("star_hits", "<i4")])
 
-# every symbol include/blackstar_gpu.h declares
-SYMBOLS = ("bs_create", "bs_destroy", "bs_render", "bs_render_device", "bs_render_batch", "bs_trace_rays",
-           "bs_debug_sqrt_div", "bs_set_mode", "bs_get_mode", "bs_set_max_steps", "bs_stats", "bs_last_error",
-           "bs_abi_version", "bs_read_ppm", "bs_hsi_to_rgb", "bs_star_lookup", "bs_debug_ubench", "bs_debug_set_disk_slots",
-           "bs_effective_mode", "bs_validate_config", "bs_debug_post_cus", "bs_debug_last_post_cus", "bs_bloom_device", "bs_bloom", "bs_srgb8_device", "bs_srgb8", "bs_render_rgb8", "bs_supersample", "bs_debug_star_grid", "bs_render_rows", "bs_render_rows_device", "bs_render_split", "bs_host_alloc", "bs_host_free", "bs_device_count", "bs_debug_srgb8_table", "bs_render_rgb8_batch",
-           "bs_png_bound", "bs_encode_png_device", "bs_encode_png", "bs_render_png", "bs_render_png_batch", "bs_render_png_files", "bs_debug_png_phases")
+# every symbol include/blackstar_gpu.h declares (the product ABI)
+SYMBOLS = ("bs_create", "bs_destroy", "bs_device_count", "bs_render", "bs_render_device", "bs_host_alloc", "bs_host_free", "bs_render_rows",
+           "bs_render_rows_device", "bs_render_split", "bs_render_batch", "bs_bloom_device", "bs_bloom", "bs_supersample", "bs_srgb8_device",
+           "bs_srgb8", "bs_render_rgb8", "bs_render_rgb8_batch", "bs_png_bound", "bs_encode_png_device", "bs_encode_png", "bs_render_png",
+           "bs_render_png_batch", "bs_render_png_files", "bs_star_lookup", "bs_set_mode", "bs_get_mode", "bs_effective_mode",
+           "bs_set_max_steps", "bs_stats", "bs_last_error", "bs_abi_version", "bs_read_ppm", "bs_validate_config", "bs_hsi_to_rgb")
+# every symbol include/blackstar_gpu_debug.h declares (libblackstar_gpu_debug.so)
+DEBUG_SYMBOLS = ("bs_debug_abi_check", "bs_trace_rays", "bs_debug_sqrt_div", "bs_debug_set_disk_slots", "bs_debug_ubench", "bs_debug_png_phases",
+                 "bs_debug_last_post_cus", "bs_debug_last_trial", "bs_debug_partition_choice", "bs_debug_pick_partition",
+                 "bs_debug_forget_partitions", "bs_debug_star_grid", "bs_debug_srgb8_table")
 
 _lib = None
+_debug = None
 
 
 class BlackstarError(RuntimeError):
@@ -105,24 +114,14 @@ def lib() -> C.CDLL:
     if hasattr(L, "bs_render_split"):
         L.bs_render_split.argtypes = [vp, C.c_int, C.POINTER(BsConfig), vp, sz]
     L.bs_render_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp]
-    L.bs_trace_rays.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
-    L.bs_debug_sqrt_div.argtypes = [vp, vp, vp, sz, vp, vp, C.c_int]
-    if hasattr(L, "bs_debug_set_disk_slots"):  # absent in older A/B builds loaded through BLACKSTAR_LIB
-        L.bs_debug_set_disk_slots.argtypes = [vp, C.c_int]
-    L.bs_debug_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.bs_star_lookup.argtypes = [vp, dp, dp, vp, sz, vp, vp]
     L.bs_set_mode.argtypes = [vp, C.c_int]
     L.bs_get_mode.argtypes = [vp]
     L.bs_effective_mode.argtypes = [vp, C.POINTER(BsConfig)]
     L.bs_validate_config.argtypes = [C.POINTER(BsConfig)]
-    L.bs_debug_post_cus.argtypes = [C.POINTER(BsConfig), dp, C.c_int, C.c_int, C.c_int]
-    L.bs_debug_last_post_cus.argtypes = [vp]
     L.bs_set_max_steps.argtypes = [vp, C.c_int]
     L.bs_stats.argtypes = [vp, C.POINTER(BsStats)]
     L.bs_last_error.restype = C.c_char_p
-    if hasattr(L, "bs_debug_star_grid"):
-        L.bs_debug_star_grid.restype = C.c_long
-        L.bs_debug_star_grid.argtypes = [vp, sz, vp, vp, sz]
     L.bs_read_ppm.restype = C.c_long
     L.bs_read_ppm.argtypes = [vp, sz, vp, sz]
     L.bs_hsi_to_rgb.argtypes = [dp, dp, dp, vp]
@@ -142,10 +141,40 @@ def lib() -> C.CDLL:
     L.bs_encode_png.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz, C.POINTER(sz)]
     L.bs_render_png.argtypes = [vp, C.POINTER(BsConfig), dp, C.c_int, vp, sz, C.POINTER(sz)]
     L.bs_render_png_files.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int]
-    L.bs_debug_png_phases.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz]
     L.bs_render_png_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
     _lib = L
     return L
+
+
+def debug_lib() -> C.CDLL:
+    """libblackstar_gpu_debug.so: the test hooks.  Loads the product first (the debug library's NEEDED libblackstar_gpu.so then resolves to
+    that very object) and refuses a pair that was not built together."""
+    global _debug
+    if _debug is not None:
+        return _debug
+    lib()
+    if not os.path.exists(DEBUG_SO_PATH):
+        raise BlackstarError(f"{DEBUG_SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    D = C.CDLL(DEBUG_SO_PATH)
+    vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
+    D.bs_debug_abi_check.restype = C.c_int
+    if D.bs_debug_abi_check() != 0:
+        raise BlackstarError(f"{DEBUG_SO_PATH}: {last_error()}")
+    D.bs_trace_rays.argtypes = [vp, C.POINTER(BsConfig), vp, sz, vp]
+    D.bs_debug_sqrt_div.argtypes = [vp, vp, vp, sz, vp, vp, C.c_int]
+    D.bs_debug_set_disk_slots.argtypes = [vp, C.c_int]
+    D.bs_debug_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    D.bs_debug_png_phases.argtypes = [vp, vp, C.c_int, C.c_int, vp, sz]
+    D.bs_debug_last_post_cus.argtypes = [vp]
+    D.bs_debug_last_trial.argtypes = [vp]
+    D.bs_debug_partition_choice.argtypes = [vp, C.POINTER(BsConfig), dp, C.c_int, C.c_int, vp]
+    D.bs_debug_pick_partition.argtypes = [vp, vp, C.c_int]
+    D.bs_debug_forget_partitions.argtypes = [vp]
+    D.bs_debug_star_grid.restype = C.c_long
+    D.bs_debug_star_grid.argtypes = [vp, sz, vp, vp, sz]
+    D.bs_debug_srgb8_table.argtypes = [vp]
+    _debug = D
+    return D
 
 
 def last_error() -> str:

@@ -1,0 +1,628 @@
+// batch.cpp -- many frames and many contexts: the reference's batch loop (app/Main.hs:68-77) as pipelines of frames in flight per
+// context, one host thread per context, frame i on context i % n_ctx; the post stage on its own CUs where that measures faster; files
+// written by a writer thread; one huge frame split into row bands.  No data-path collective anywhere: frames and bands are independent.
+#include <algorithm>
+#include <cerrno>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "bs_context.h"
+
+using namespace bs;
+
+// (the bs_* entry points get C linkage from their declarations in include/blackstar_gpu.h)
+
+// Frames first, first+step, ... on one context, double-buffered: while frame k's image is copied to the host (copy
+// stream), frame k+1's kernel already runs (compute stream).  Pageable host buffers: the copy itself is the runtime's
+// staged D2H (about 19 GB/s), but it no longer sits between two kernels.
+static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *const *outs, int first, int n_frames, int step)
+{
+    if (first >= n_frames) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t need = 0;
+    for (int i = first; i < n_frames; i += step) {
+        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
+        need = std::max(need, (size_t)cfgs[i].width * cfgs[i].height * 3);
+    }
+    {   // every frame's buffer page-locked: the kernels write them directly, two frames in flight on two streams, no copies
+        std::vector<double *> alias;
+        bool all = true;
+        for (int i = first; i < n_frames; i += step) {  // (every buffer is looked at: one that straddles fails the call before any launch)
+            bool straddles = false;
+            double *a = device_alias_of_pinned(ctx, outs[i], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double), &straddles);
+            if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+            all = all && a != nullptr;
+            alias.push_back(a);
+        }
+        if (all) {
+            if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->ev_frame)
+                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+            StreamDrain drain(ctx);
+            int k = 0;
+            for (int i = first; i < n_frames; i += step, k++) {
+                if (k >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_frame[k & 1]));  // at most two frames in flight
+                int rc = enqueue_render(ctx, &cfgs[i], alias[k], (size_t)cfgs[i].width * cfgs[i].height * 3, cs[k & 1], 0, -1, true, true, /*quiet=*/true);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(ctx->ev_frame[k & 1], cs[k & 1]));
+            }
+            HIP_TRY(hipStreamSynchronize(cs[0]));
+            HIP_TRY(hipStreamSynchronize(cs[1]));
+            return BS_OK;
+        }
+    }
+    auto grow = [&](double *&buf, size_t &cap) {
+        if (cap >= need) return true;
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipMalloc((void **)&buf, need * sizeof(double)) != hipSuccess) return false;
+        cap = need;
+        return true;
+    };
+    if (!grow(ctx->d_img, ctx->img_cap) || !grow(ctx->d_img2, ctx->img2_cap)) return fail(BS_ENOMEM, "hipMalloc image failed");
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->ev_frame)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // Frame k: image buf[k&1], compute stream cs[k&1], its own launch slot -- two frames can be in flight, and the persistent
+    // wavefronts of frame k+1 take over the slots frame k's wavefronts leave as its tile queue runs dry (the end-of-frame
+    // tail and the copy both disappear behind the neighbouring frame).
+    double *buf[2] = {ctx->d_img, ctx->d_img2};
+    hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+    // From here on work is in flight whose DMA targets are the caller's outs[]: every return path drains the streams first.
+    StreamDrain drain(ctx);
+    int k = 0;
+    int rc = enqueue_render(ctx, &cfgs[first], buf[0], need, cs[0], 0, -1, true, true, /*quiet=*/true);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_frame[0], cs[0]));
+    for (int i = first; i < n_frames; i += step, k++) {
+        const int nxt = i + step;
+        if (nxt < n_frames) {  // buf[(k+1)&1] is free: its previous copy was waited for before this point
+            rc = enqueue_render(ctx, &cfgs[nxt], buf[(k + 1) & 1], need, cs[(k + 1) & 1], 0, -1, true, true, /*quiet=*/true);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_frame[(k + 1) & 1], cs[(k + 1) & 1]));
+        }
+        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_frame[k & 1], 0));
+        HIP_TRY(hipMemcpyAsync(outs[i], buf[k & 1], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    }
+    return BS_OK;
+}
+
+// every context of a batch / split call is driven by its own host thread: the same context twice would be driven by two
+static int distinct_contexts(bs_ctx *const *ctxs, int n_ctx)
+{
+    for (int c = 0; c < n_ctx; c++) {
+        if (!ctxs[c]) return fail(BS_EINVAL, "null context");
+        for (int d = 0; d < c; d++)
+            if (ctxs[d] == ctxs[c]) return fail(BS_EINVAL, "the same context appears twice (one context per device, each named once)");
+    }
+    return BS_OK;
+}
+
+int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs)
+{
+    if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
+    // One host thread per context (= per device); frame i goes to context i % n_ctx.  No data-path
+    // collective: frames are independent (app/Main.hs:72-77 renders them one after another).
+    std::vector<int> rcs(n_ctx, BS_OK);
+    std::vector<std::string> errs(n_ctx);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n_ctx; c++) {
+        th.emplace_back([&, c]() {
+            rcs[c] = render_frames_pipelined(ctxs[c], cfgs, outs, c, n_frames, n_ctx);
+            if (rcs[c]) errs[c] = bs::error_message();
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n_ctx; c++)
+        if (rcs[c]) return fail(rcs[c], errs[c]);
+    return BS_OK;
+}
+
+// Where a batch's frames go: RGB8 pixels (png == nullptr) or finished PNG files (bs_render_png_batch).
+struct PngSink {
+    const size_t *caps;   // capacity of outs[i]
+    size_t *sizes;        // receives the size of file i
+};
+
+// What every frame of a context's share must satisfy before anything is launched; returns the largest frame (values) in *need.
+static int check_rgb8_share(const bs_config *cfgs, const double *strengths, const int *dividers, unsigned char *const *outs, const PngSink *png,
+                            int first, int n_frames, int step, size_t *need)
+{
+    *need = 0;
+    for (int i = first; i < n_frames; i += step) {
+        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
+        const double st = strengths ? strengths[i] : 0.0;
+        if (st != 0 && !dividers) return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
+        if (int rc = check_bloom_args(cfgs[i].width, st, st != 0 ? dividers[i] : 1)) return rc;
+        if (png) {
+            if (int rc = check_png_frame(cfgs[i].width, cfgs[i].height)) return rc;
+            if (png->caps[i] < bs::png_file_bound(cfgs[i].width, cfgs[i].height))
+                return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
+        }
+        *need = std::max(*need, (size_t)cfgs[i].width * cfgs[i].height * 3);
+    }
+    return BS_OK;
+}
+
+// The PNG files of a batch in flight: frame `frame` was encoded into slot k (its scratch, its size word), into the caller's page-locked
+// buffer or -- staged -- into the slot's device copy of the file.  retire() is called once everything enqueued for the slot has
+// finished: it reports the size and, for a staged file, copies exactly its bytes (a copy of unknown length cannot be enqueued ahead).
+struct PngSlots {
+    int frame[3] = {-1, -1, -1};   // (the context's PNG slots 0..2; slot bs_ctx::kPngSingle belongs to the single-frame entry points)
+    bool staged[3] = {false, false, false};
+
+    int enqueue(bs_ctx *ctx, int k, int i, const unsigned char *d_u8, const bs_config &cfg, unsigned char *out, hipStream_t s)
+    {
+        bool straddles = false;
+        double *alias = device_alias_of_pinned(ctx, out, (size_t)bs::png_file_bound(cfg.width, cfg.height), &straddles);
+        if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        int rc = ensure_png(ctx, k, cfg.width, cfg.height, alias == nullptr);
+        if (rc) return rc;
+        uint64_t *d_bytes = png_bytes_slot(ctx, k);
+        if (!d_bytes) return fail(BS_EDEVICE, "hipHostGetDevicePointer failed");
+        unsigned char *target = alias ? reinterpret_cast<unsigned char *>(alias) : ctx->d_png_file[k];
+        if (bs::launch_png_encode(d_u8, cfg.width, cfg.height, ctx->d_png_scratch[k], target, d_bytes, s)) return fail(BS_EDEVICE, "PNG encoder launch failed");
+        frame[k] = i;
+        staged[k] = alias == nullptr;
+        return BS_OK;
+    }
+
+    int retire(bs_ctx *ctx, int k, unsigned char *const *outs, const PngSink &png, hipStream_t s)
+    {
+        if (frame[k] < 0) return BS_OK;
+        const size_t bytes = (size_t)ctx->h_png_bytes[k];
+        png.sizes[frame[k]] = bytes;
+        if (staged[k]) {
+            HIP_TRY(hipMemcpyAsync(outs[frame[k]], ctx->d_png_file[k], bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        frame[k] = -1;
+        return BS_OK;
+    }
+};
+
+// doRender (app/Main.hs:105-123) for frames first, first+step, ... on one context, two frames in flight: frame k runs render ->
+// bloom -> sRGB8 (-> PNG) on compute stream k & 1 with its own f64 image, so frame k+1's trace kernel fills the SIMDs frame k's last
+// tiles leave (the fixed ~0.25 ms of a launch) and frame k's bloom runs on the CUs the next trace kernel frees
+// first.  The blur scratch is one pair per context: the bloom of frame k+1 is ordered behind frame k's by acquire/release_post.
+static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, unsigned char *const *outs,
+                                        int first, int n_frames, int step, const PngSink *png)
+{
+    if (first >= n_frames) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t need = 0;
+    int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, first, n_frames, step, &need);
+    if (rc) return rc;
+    if (!grow_device(ctx->d_img, ctx->img_cap, need) || !grow_device(ctx->d_img2, ctx->img2_cap, need) || !grow_device(ctx->d_u8, ctx->u8_cap, need) ||
+        !grow_device(ctx->d_u8b, ctx->u8b_cap, need))
+        return fail(BS_ENOMEM, "hipMalloc image failed");
+    rc = ensure_post(ctx, need);
+    if (rc) return rc;
+    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->ev_frame)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double *img[2] = {ctx->d_img, ctx->d_img2};
+    unsigned char *stage[2] = {ctx->d_u8, ctx->d_u8b};
+    hipStream_t cs[2] = {ctx->stream, ctx->stream2};
+    PngSlots files;
+    StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
+    int k = 0;
+    for (int i = first; i < n_frames; i += step, k++) {
+        const int b = k & 1;
+        if (k >= 2) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
+            if (png && (rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
+        }
+        const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
+        unsigned char *target = stage[b];
+        if (!png) {
+            bool straddles = false;
+            if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
+            if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        }
+        rc = enqueue_render(ctx, &cfgs[i], img[b], n, cs[b], 0, -1, true, true, /*quiet=*/true);
+        if (rc) return rc;
+        rc = enqueue_post_rgb8(ctx, img[b], cfgs[i].width, cfgs[i].height, strengths ? strengths[i] : 0.0, dividers ? dividers[i] : 1, target, ctx->n_cu, cs[b]);
+        if (rc) return rc;
+        if (png) {
+            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], cs[b]);
+            if (rc) return rc;
+        } else if (target == stage[b]) {
+            HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, cs[b]));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_frame[b], cs[b]));
+    }
+    HIP_TRY(hipStreamSynchronize(cs[0]));
+    HIP_TRY(hipStreamSynchronize(cs[1]));
+    for (int b = 0; png && b < 2; b++)
+        if ((rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
+    return BS_OK;
+}
+// ---- the CU partition: measured, not modelled -----------------------------------------------------------------------------------
+// With the chip partitioned a frame costs trace x n_cu / (n_cu - M), provided the post stage (bloom + sRGB8, + the PNG encoder) confined
+// to M CUs keeps up; on the shared chip it costs trace + post + a hand-over stall (a blur workgroup only ever gets a CU in the drain of a
+// later trace kernel, and delays the one behind it).  Which side wins depends on the frame's shape, the scene, the arithmetic mode and the
+// chip's clocks -- rounds 2-3 measured 26 combinations (profiles/r03_post_partition_ab.txt, r03_partition_large_ab.jsonl,
+// r03_partition_more_ab.jsonl, r03_png_partition_ab.jsonl: C3 at 1080p 4.27 partitioned on 8 CUs / 4.67 ms shared, 720p wants 16, frames
+// without supersampling lose with any M, ...) and fitted a model with five constants to them.  Round 4 replaced the model with the
+// measurement itself: the first share of a context that holds at least kTrialFrames frames of ONE shape renders its first frames as a
+// TRIAL -- kTrialWarm frames on the shared chip (they also bring the clocks up: the first launches after an idle spell run up to 20 %
+// slow), then kTrialSegment frames each shared / with 8 / with 16 post-stage CUs, each segment a self-contained blocking pipeline timed
+// with the host clock -- and remembers the fastest for that shape (PartitionKey) for the life of the context.  Every trial frame is a
+// frame of the batch, delivered like any other (byte-identical whichever way it was made); what the trial costs is the difference
+// between the segments, a few per cent of twenty frames, once.  Shares that are too short, or mix shapes of which one has not been
+// measured, run on the shared chip (the safe side: a partition that is too small for its post stage costs 50-70 %, none costs <= 9 %).
+// BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
+constexpr int kTrialWarm = 8, kTrialSegment = 4;
+static_assert(kTrialWarm + 3 * kTrialSegment == bs::kTrialFrames, "the trial's segments");
+static const int kTrialCus[3] = {0, 8, 16};
+
+int bs::pick_partition(const double *ms, const int *cus, int n)
+{
+    int best = -1, shared = -1;
+    for (int i = 0; i < n; i++) {
+        if (!(ms[i] > 0)) continue;   // not run
+        if (cus[i] == 0) shared = i;
+        if (best < 0 || ms[i] < ms[best]) best = i;
+    }
+    if (best < 0) return 0;
+    if (cus[best] != 0 && shared >= 0 && !(ms[best] < (1.0 - bs::kTrialMargin) * ms[shared])) return 0;   // not clearly better than doing nothing
+    return cus[best];
+}
+
+static bool partition_key(const bs_ctx *ctx, const bs_config &cfg, double strength, int divider, bool png, bs_ctx::PartitionKey *key)
+{
+    if (cfg.width <= 0 || cfg.height <= 0) return false;
+    *key = {cfg.width, cfg.height, cfg.supersampling ? 1 : 0, strength != 0 ? divider : 0, png ? 1 : 0, effective_mode(ctx, &cfg)};
+    return true;
+}
+
+static const bs_ctx::PartitionChoice *find_choice(const bs_ctx *ctx, const bs_ctx::PartitionKey &key)
+{
+    for (const auto &c : ctx->partition_cache)
+        if (c.key == key) return &c;
+    return nullptr;
+}
+
+// What this context's share of a batch does about the partition: *post_cus = the CUs to set aside (0: shared chip), *trial = measure now.
+static void plan_share(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, int first, int n_frames, int step, bool png,
+                       int *post_cus, bool *trial, bs_ctx::PartitionKey *trial_key)
+{
+    *post_cus = 0;
+    *trial = false;
+    if (ctx->post_cus_req == 0 || ctx->n_cu < 128 || ctx->n_cu % 8 != 0) return;
+    if (first + 2 * step >= n_frames) return;  // fewer than three frames for this context: nothing to hide the post stage behind (1 frame: 5.38 against 5.22 ms)
+    if (ctx->post_cus_req > 0) { *post_cus = ctx->post_cus_req; return; }
+    bool one_shape = true, all_known = true, with_post = false;
+    int count = 0, widest = 0;
+    bs_ctx::PartitionKey k0{};
+    for (int i = first; i < n_frames; i += step, count++) {
+        const double st = strengths ? strengths[i] : 0.0;
+        bs_ctx::PartitionKey k;
+        if ((st != 0 && !dividers) || !partition_key(ctx, cfgs[i], st, st != 0 ? dividers[i] : 0, png, &k)) return;  // (the pipeline will refuse the frame)
+        with_post = with_post || st != 0 || png;
+        if (count == 0) k0 = k;
+        one_shape = one_shape && k == k0;
+        if (const bs_ctx::PartitionChoice *c = find_choice(ctx, k)) {
+            if (c->post_cus == 0) widest = -1;              // a shape that measured faster on the shared chip: the whole share stays there
+            else if (widest >= 0) widest = std::max(widest, c->post_cus);
+        } else {
+            all_known = false;
+        }
+    }
+    if (!with_post) return;          // no bloom and no file anywhere: the post stage is one 30-us pixel map, nothing to set CUs aside for
+    if (all_known) { *post_cus = std::max(widest, 0); return; }
+    if (one_shape && count >= bs::kTrialFrames) { *trial = true; *trial_key = k0; }
+}
+
+// The CU-masked streams of a partition (post stage on bits [0, post_cus), trace kernels on the rest), made once per context and M.
+// (hipExtStreamCreateWithCUMask takes no flags: unlike the context's other streams these synchronise with the NULL stream -- only a
+// matter of overlap, and only if another thread of the caller keeps the NULL stream busy during a bs_render_rgb8_batch call.)
+// false: the runtime would not make them (no CU-mask support on this device / driver) -- the caller falls back to the shared chip.
+static bool ensure_partition(bs_ctx *ctx, int post_cus)
+{
+    if (post_cus < 8 || post_cus > 32 || post_cus % 4 != 0 || hipSetDevice(ctx->device) != hipSuccess) return false;
+    bs_ctx::Partition &pt = ctx->parts[(post_cus - 8) / 4];
+    if (pt.post) return true;
+    const int words = (ctx->n_cu + 31) / 32;
+    std::vector<uint32_t> post(words, 0u), trace(words, 0u);
+    for (int b = 0; b < ctx->n_cu; b++) (b < post_cus ? post : trace)[b / 32] |= 1u << (b % 32);
+    hipStream_t sp = nullptr, st0 = nullptr, st1 = nullptr;
+    const bool ok = hipExtStreamCreateWithCUMask(&sp, (uint32_t)words, post.data()) == hipSuccess &&
+                    hipExtStreamCreateWithCUMask(&st0, (uint32_t)words, trace.data()) == hipSuccess &&
+                    hipExtStreamCreateWithCUMask(&st1, (uint32_t)words, trace.data()) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (hipStream_t s : {sp, st0, st1})
+            if (s) (void)hipStreamDestroy(s);
+        return false;
+    }
+    pt.post = sp; pt.trace[0] = st0; pt.trace[1] = st1;
+    return true;
+}
+
+// The same with the chip PARTITIONED between the two stages (ctx->post_cus > 0).  A blur workgroup needs a whole CU (152 KiB of LDS,
+// 8 wavefronts of 202 VGPRs) and the trace kernels' persistent workgroups hold every CU until their tile queue runs dry, so on shared
+// streams the post stage of frame k only ever runs in the drain of a later trace kernel, and delays the one behind it (4.67 against
+// 4.13 ms per frame without the post stage).  Here the trace kernels run on streams whose CU mask leaves post_cus CUs out and the post
+// stage on a stream that owns exactly those: frame k's bloom + sRGB8 run WHILE frames k+1, k+2 are traced, at the price of post_cus /
+// n_cu of the trace rate.  Mask bit i is CU i / 8 of XCD i % 8 (scripts/cumask_probe.py, profiles/r03_cumask_probe.txt: an XCD
+// without a single bit gets ALL its CUs), so bits [0, post_cus) are post_cus / 8 CUs in every XCD (for 12, 20, 28: one more in the first
+// four XCDs -- the trace kernels' tile queue and the blur sweeps' plans balance themselves).  Three images in flight.
+static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_config *cfgs, const double *strengths, const int *dividers,
+                                          unsigned char *const *outs, int first, int n_frames, int step, const PngSink *png)
+{
+    if (first >= n_frames) return BS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t need = 0;
+    int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, first, n_frames, step, &need);
+    if (rc) return rc;
+    if (!grow_device(ctx->d_img, ctx->img_cap, need) || !grow_device(ctx->d_img2, ctx->img2_cap, need) || !grow_device(ctx->d_img3, ctx->img3_cap, need) ||
+        !grow_device(ctx->d_u8, ctx->u8_cap, need) || !grow_device(ctx->d_u8b, ctx->u8b_cap, need) || !grow_device(ctx->d_u8c, ctx->u8c_cap, need))
+        return fail(BS_ENOMEM, "hipMalloc image failed");
+    rc = ensure_post(ctx, need);
+    if (rc) return rc;
+    bs_ctx::Partition &pt = ctx->parts[(post_cus - 8) / 4];  // streams made by ensure_partition
+    for (hipEvent_t &e : ctx->ev_traced)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t &e : ctx->ev_posted)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double *img[3] = {ctx->d_img, ctx->d_img2, ctx->d_img3};
+    unsigned char *stage[3] = {ctx->d_u8, ctx->d_u8b, ctx->d_u8c};
+    const int plan_cus = ctx->post_plan_cus > 0 ? ctx->post_plan_cus : post_cus;
+    struct LaunchCus {  // the trace launches of this call size their persistent grids for the CUs their streams may use
+        bs_ctx *c;
+        LaunchCus(bs_ctx *c_, int n) : c(c_) { c->launch_cus = n; }
+        ~LaunchCus() { c->launch_cus = 0; }
+    } cus(ctx, ctx->n_cu - post_cus);
+    PngSlots files;
+    hipStream_t posted_on[3] = {pt.post, pt.post, pt.post};
+    StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
+    int k = 0;
+    for (int i = first; i < n_frames; i += step, k++) {
+        const int b = k % 3;
+        hipStream_t ts = pt.trace[k & 1];
+        if (k >= 3) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));  // frame k-3 (same image, same staging) has left the device
+            if (png && (rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
+        }
+        const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
+        unsigned char *target = stage[b];
+        if (!png) {
+            bool straddles = false;
+            if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);
+            if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        }
+        rc = enqueue_render(ctx, &cfgs[i], img[b], n, ts, 0, -1, true, true, /*quiet=*/true);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev_traced[b], ts));
+        // The LAST frame of the share has no tracing left to hide behind: its post stage takes the whole chip (ctx->stream, sweeps
+        // planned for all CUs: 0.2 instead of 3.8 ms for a 1080p frame -- on a 20-frame batch that tail alone was 0.19 ms per frame).
+        const bool last = i + step >= n_frames;
+        hipStream_t ps = last ? ctx->stream : pt.post;
+        posted_on[b] = ps;
+        HIP_TRY(hipStreamWaitEvent(ps, ctx->ev_traced[b], 0));
+        rc = enqueue_post_rgb8(ctx, img[b], cfgs[i].width, cfgs[i].height, strengths ? strengths[i] : 0.0, dividers ? dividers[i] : 1, target,
+                               last ? ctx->n_cu : plan_cus, ps);
+        if (rc) return rc;
+        if (png) {
+            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], ps);
+            if (rc) return rc;
+        } else if (target == stage[b]) {
+            HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, ps));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_posted[b], ps));
+    }
+    HIP_TRY(hipStreamSynchronize(pt.trace[0]));
+    HIP_TRY(hipStreamSynchronize(pt.trace[1]));
+    HIP_TRY(hipStreamSynchronize(pt.post));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; png && b < 3; b++)
+        if ((rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
+    return BS_OK;
+}
+// One context's share of bs_render_rgb8_batch / bs_render_png_batch: frames c, c + step, ... -- shared chip, partitioned, or the trial.
+static int run_share(bs_ctx *x, const bs_config *cfgs, int n_frames, const double *strengths, const int *dividers, unsigned char *const *outs,
+                     const PngSink *png, int c, int step)
+{
+    int post_cus = 0;
+    bool trial = false;
+    bs_ctx::PartitionKey key{};
+    plan_share(x, cfgs, strengths, dividers, c, n_frames, step, png != nullptr, &post_cus, &trial, &key);
+    // Only with page-locked outputs, which the last kernel of a frame writes itself: a copy into PAGEABLE memory blocks the
+    // host thread until the frame's post stage has finished -- 3.8 ms on 8 CUs instead of 0.2 ms on the whole chip -- and the
+    // next trace kernel is not enqueued meanwhile (measured 9.1 against 4.8 ms per frame: scripts/post_partition_pageable_ab.py)
+    for (int i = c; (post_cus || trial) && i < n_frames; i += step) {
+        if (!outs[i] || cfgs[i].width <= 0 || cfgs[i].height <= 0 || hipSetDevice(x->device) != hipSuccess ||
+            !device_alias_of_pinned(x, outs[i], png ? (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height) : (size_t)cfgs[i].width * cfgs[i].height * 3)) {
+            post_cus = 0;
+            trial = false;
+        }
+    }
+    if (post_cus && !ensure_partition(x, post_cus)) post_cus = 0;
+    x->last_trial = 0;
+    auto run = [&](int m, int a, int b) {  // frames a .. b-1 OF THE SHARE, with m post-stage CUs
+        const int first = c + a * step, bound = (int)std::min<long>(n_frames, (long)c + (long)b * step);
+        return m ? render_rgb8_frames_partitioned(x, m, cfgs, strengths, dividers, outs, first, bound, step, png)
+                 : render_rgb8_frames_pipelined(x, cfgs, strengths, dividers, outs, first, bound, step, png);
+    };
+    const int count = (n_frames - c + step - 1) / step;
+    if (!trial) {
+        x->last_post_cus = post_cus;
+        return run(post_cus, 0, count);
+    }
+    // The trial (see "the CU partition: measured, not modelled" above).  A chip without CU-mask support measures nothing and stays shared.
+    bs_ctx::PartitionChoice ch{key, 0, {0, 0, 0}};
+    const bool masks = ensure_partition(x, kTrialCus[1]) && ensure_partition(x, kTrialCus[2]);
+    int done = 0;
+    if (masks) {
+        {   // every buffer either pipeline needs exists before anything is timed (the first segment would otherwise pay the allocations)
+            size_t need = 0;
+            if (int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, c, n_frames, step, &need)) return rc;
+            if (!grow_device(x->d_img, x->img_cap, need) || !grow_device(x->d_img2, x->img2_cap, need) || !grow_device(x->d_img3, x->img3_cap, need) ||
+                !grow_device(x->d_u8, x->u8_cap, need) || !grow_device(x->d_u8b, x->u8b_cap, need) || !grow_device(x->d_u8c, x->u8c_cap, need))
+                return fail(BS_ENOMEM, "hipMalloc image failed");
+            if (int rc = ensure_post(x, need)) return rc;
+        }
+        if (int rc = run(0, 0, kTrialWarm)) return rc;
+        done = kTrialWarm;
+        for (int v = 0; v < 3; v++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (int rc = run(kTrialCus[v], done, done + kTrialSegment)) return rc;
+            ch.ms[v] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / kTrialSegment;
+            done += kTrialSegment;
+        }
+        ch.post_cus = pick_partition(ch.ms, kTrialCus, 3);
+    }
+    x->partition_cache.push_back(ch);
+    x->last_trial = 1;
+    x->last_post_cus = ch.post_cus;
+    return done < count ? run(ch.post_cus, done, count) : BS_OK;
+}
+
+// bs_render_rgb8_batch / bs_render_png_batch: one host thread per context, frame i on context i % n_ctx.
+static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                             unsigned char *const *outs, const PngSink *png)
+{
+    if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
+    std::vector<int> rcs(n_ctx, BS_OK);
+    std::vector<std::string> errs(n_ctx);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n_ctx; c++) {
+        th.emplace_back([&, c]() {
+            rcs[c] = run_share(ctxs[c], cfgs, n_frames, bloom_strengths, bloom_dividers, outs, png, c, n_ctx);
+            if (rcs[c]) errs[c] = bs::error_message();
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n_ctx; c++)
+        if (rcs[c]) return fail(rcs[c], errs[c]);
+    return BS_OK;
+}
+
+int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                         unsigned char *const *outs)
+{
+    return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, nullptr);
+}
+
+int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                        unsigned char *const *outs, const size_t *caps, size_t *out_bytes)
+{
+    if (n_frames > 0 && (!caps || !out_bytes)) return fail(BS_EINVAL, "null argument");
+    const PngSink sink{caps, out_bytes};
+    return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, &sink);
+}
+
+// One file: create / truncate, write, close.  Empty string on success, else what failed.
+static std::string write_whole_file(const char *path, const unsigned char *data, size_t n)
+{
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return std::string(path) + ": " + std::strerror(errno);
+    const size_t wrote = n ? std::fwrite(data, 1, n, f) : 0;
+    const int close_rc = std::fclose(f);
+    if (wrote != n || close_rc != 0) return std::string(path) + ": " + std::strerror(errno ? errno : EIO);
+    return std::string();
+}
+
+int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
+                        const char *const *paths, int pipe)
+{
+    if (!ctxs || n_ctx <= 0 || n_frames < 0 || (n_frames > 0 && (!cfgs || !paths))) return fail(BS_EINVAL, "null argument");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
+    size_t cap = 0;
+    for (int i = 0; i < n_frames; i++) {
+        if (!paths[i]) return fail(BS_EINVAL, "null path");
+        if (int rc = check_png_frame(cfgs[i].width, cfgs[i].height)) return rc;
+        cap = std::max(cap, (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height));
+    }
+    if (n_frames == 0) return BS_OK;
+    // `chunk` frames per bs_render_png_batch call into one of two sets of page-locked file buffers; a writer thread writes the set of the
+    // call before while the GPUs fill the other.  (The second set exists only if there is a second call.)
+    const int chunk = (pipe > 0 ? pipe : 16) * n_ctx;
+    const int slots = std::min(chunk, n_frames);
+    const int n_sets = n_frames > chunk ? 2 : 1;
+    // buffer k of the call lives in the pool of context k % n_ctx (entry k / n_ctx), kept for the next call and freed with the context
+    std::vector<unsigned char *> bufs((size_t)n_sets * slots, nullptr);
+    for (size_t k = 0; k < bufs.size(); k++) {
+        bs_ctx *owner = ctxs[k % n_ctx];
+        const size_t e = k / n_ctx;
+        if (owner->file_pool.size() <= e) owner->file_pool.resize(e + 1, {nullptr, 0});
+        auto &slot = owner->file_pool[e];
+        if (slot.second < cap) {
+            if (slot.first) bs_host_free(slot.first);
+            slot = {nullptr, 0};
+            slot.first = static_cast<unsigned char *>(bs_host_alloc(owner, cap));
+            if (!slot.first) return BS_ENOMEM;   // (bs_host_alloc has set the message)
+            slot.second = cap;
+        }
+        bufs[k] = slot.first;
+    }
+    std::vector<size_t> caps(slots, cap), sizes((size_t)n_sets * slots, 0);
+    std::thread writer;
+    std::string write_error;   // owned by the writer thread until it is joined
+    struct JoinWriter {
+        std::thread &t;
+        ~JoinWriter() { if (t.joinable()) t.join(); }
+    } join_writer{writer};
+    int rc = BS_OK;
+    for (int pos = 0, it = 0; pos < n_frames && rc == BS_OK; pos += chunk, it++) {
+        const int count = std::min(chunk, n_frames - pos), set = it & 1;
+        // (the set being refilled was written out by the writer of the call before the last, joined below one iteration ago;
+        //  the writer of the last call -- the other set -- may still be running: that is the overlap)
+        unsigned char *const *outs = bufs.data() + (size_t)set * slots;
+        size_t *sz = sizes.data() + (size_t)set * slots;
+        const PngSink sink{caps.data(), sz};
+        rc = render_post_batch(ctxs, n_ctx, cfgs + pos, count, bloom_strengths ? bloom_strengths + pos : nullptr, bloom_dividers ? bloom_dividers + pos : nullptr, outs, &sink);
+        if (rc) break;
+        if (writer.joinable()) {              // the call before this one: its files (the other set) must be out before a new writer starts
+            writer.join();
+            if (!write_error.empty()) return fail(BS_EIO, write_error);
+        }
+        writer = std::thread([&write_error, outs, sz, paths, pos, count]() {
+            for (int j = 0; j < count && write_error.empty(); j++) write_error = write_whole_file(paths[pos + j], outs[j], sz[j]);
+        });
+    }
+    if (writer.joinable()) writer.join();
+    if (rc) return rc;   // (the failing call has set the message)
+    if (!write_error.empty()) return fail(BS_EIO, write_error);
+    return BS_OK;
+}
+
+int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
+{
+    if (!ctxs || n_ctx <= 0 || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
+    if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
+    if (out_doubles < (size_t)cfg->width * cfg->height * 3) return fail(BS_EINVAL, "output buffer too small");
+    // Context c renders the c-th of n contiguous row bands (sizes differ by at most one row; contexts beyond the number
+    // of rows stay idle), one host thread per context, each copying its band straight into its place in out_rgb.
+    const int n = std::min(n_ctx, cfg->height);
+    const int base = cfg->height / n, extra = cfg->height % n;
+    std::vector<int> rcs(n, BS_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    for (int c = 0; c < n; c++) {
+        const int row0 = c * base + std::min(c, extra), row1 = row0 + base + (c < extra ? 1 : 0);
+        th.emplace_back([&, c, row0, row1]() {
+            rcs[c] = bs_render_rows(ctxs[c], cfg, row0, row1, out_rgb + (size_t)row0 * cfg->width * 3, (size_t)(row1 - row0) * cfg->width * 3);
+            if (rcs[c]) errs[c] = bs::error_message();
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n; c++)
+        if (rcs[c]) return fail(rcs[c], errs[c]);
+    return BS_OK;
+}

@@ -1,5 +1,5 @@
-// Internal types shared by the host side (bs_api.cpp, star_index.cpp) and the gfx950 kernels
-// (trace_kernel.hip).  Not part of the ABI.
+// Internal types shared by the host side (context.cpp, render.cpp, post.cpp, batch.cpp, star_index.cpp) and the gfx950 kernels
+// (trace_device.h / trace_kernel.hip, post_kernels.hip, png_kernels.hip).  Not part of the ABI.
 #pragma once
 
 #include <cstddef>
@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/blackstar_gpu.h"
+
+struct bs_ray_record;  // include/blackstar_gpu_debug.h (test hook)
 
 namespace bs {
 
@@ -102,26 +104,24 @@ inline int grid_cell(double t)
 
 // trace_kernel.hip launchers (enqueue on `stream`, no sync).
 int launch_trace(const TraceParams &p, int mode, void *stream);
-int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, size_t n_rays, bs_ray_record *d_out, void *stream);
 int launch_star_lookup(const TraceParams &p, const double *d_dirs, size_t n, double *d_rgb, int32_t *d_hits, void *stream);
+// debug_kernels.hip (libblackstar_gpu_debug.so only)
+int launch_trace_records(const TraceParams &p, int mode, const int32_t *d_yx, size_t n_rays, bs_ray_record *d_out, void *stream);
+int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
+int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);
 // post_kernels.hip
 int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu, void *stream);
 // bloom + writeImg's pixel map in one go: only RGB8 is written (d_table: the 257 sRGB8 thresholds, srgb8_thresholds)
 int launch_bloom_srgb8(const double *d_in, unsigned char *d_out_u8, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu,
                        const double *d_table, void *stream);
-// microseconds bloom + sRGB8 of a w x h frame would take on `cus` CUs of the chip (model; < 0: no estimate) -- see post_kernels.hip
-double estimate_post_us(int w, int h, int divider, int cus);
 int launch_supersample(const double *d_in, double *d_out, int w2, int h2, void *stream);
 int launch_srgb8(const double *d_in, unsigned char *d_out, size_t n, const double *d_table, void *stream);
 // png_kernels.hip: writeImg's file format on the device (algorithm: png_block.h)
 uint64_t png_file_bound(int w, int h);   // bytes a w x h RGB8 frame can take at most as a file of this encoder
 size_t png_scratch_bytes(int w, int h);  // device scratch one encode needs
-double estimate_png_us(int w, int h, int cus);  // microseconds the encoder's kernels take on `cus` CUs (model; < 0: no estimate)
 size_t png_block_count(int w, int h);     // 8 KiB blocks of the filtered stream = workgroups of the encoding kernel
 constexpr int kPngPhases = 23;            // clock stamps per block of the profiling variant: before the first phase, after each of the 22
 int launch_png_encode(const unsigned char *d_rgb8, int w, int h, void *d_scratch, unsigned char *d_out, uint64_t *d_file_bytes, void *stream,
                       unsigned long long *d_clocks = nullptr);
-int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream);
-int launch_sqrt_div(const double *d_a, const double *d_b, size_t n, double *d_sqrt, double *d_div, int bare, void *stream);
 
 }  // namespace bs

@@ -1,0 +1,354 @@
+// context.cpp -- the context behind the C ABI of include/blackstar_gpu.h: lifetime, settings, the thread-local error message, page-locked
+// caller buffers (zero copy) and device scratch.  No CPU rendering path exists in this library: without a HIP device every render
+// entry point fails with BS_EDEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bs_context.h"
+
+namespace bs {
+
+namespace {
+thread_local std::string g_err;
+}
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+const std::string &error_message() { return g_err; }
+
+size_t ctx_layout_bytes() { return sizeof(bs_ctx); }
+
+StreamDrain::~StreamDrain()
+{
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+    for (hipStream_t s : {ctx->stream, ctx->stream2, ctx->copy_stream})
+        if (s) (void)hipStreamSynchronize(s);
+    for (const bs_ctx::Partition &pt : ctx->parts)
+        for (hipStream_t s : {pt.trace[0], pt.trace[1], pt.post})
+            if (s) (void)hipStreamSynchronize(s);
+}
+
+// Zero copy: if a caller's HOST buffer is page-locked (bs_host_alloc, hipHostMalloc, hipHostRegister) the device can write it
+// directly over PCIe, so the kernel's own image stores deliver the frame -- no device image, no copy, and the transfer is
+// spread over the whole kernel instead of trailing it.  Measured (scripts/zero_copy_probe.py, profiles/r02_zero_copy.txt):
+// bs_render of the C3 frame 5.45 -> 4.57 ms (kernel 4.38), C2 2.14 -> 1.49 ms (49.8 MB in 1.47 ms = 34 GB/s while tracing), C4
+// 21.6 -> 18.7 ms; the kernel time itself does not change (11 GB/s average is far below what PCIe takes in 96-B segments).
+// Returns the device alias of `host`, or nullptr for pageable memory (which takes the staged path).  BLACKSTAR_ZERO_COPY=0: off.
+// *straddles (optional): set when `host` STARTS in page-locked memory but [host, host + bytes) is not contained in it -- a buffer
+// no path can deliver into: the kernel's stores would fault, and the runtime's own hipMemcpyAsync refuses it ("invalid argument":
+// it finds the registered range the pointer starts in and the size does not fit).  Callers turn that into BS_EINVAL.
+double *device_alias_of_pinned(bs_ctx *ctx, const void *host, size_t bytes, bool *straddles)
+{
+    if (straddles) *straddles = false;
+    if (!host || bytes == 0) return nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer) {
+        (void)hipGetLastError();  // pageable memory is reported as an error: not one of ours
+        return nullptr;
+    }
+    // [host, host + bytes) must lie inside page-locked memory from end to end.  Probing the two ends is not enough: a buffer that
+    // starts in one hipHostRegister range and ends in another, with pageable memory in between, passes that test, and the kernel's
+    // stores through base alias + offset then fault on the GPU -- which ends the process instead of returning an error.
+    const char *hp = static_cast<const char *>(host);
+    bool covered = false, known = false;
+    void *base = nullptr;
+    size_t size = 0;
+    // (1) the range the pointer belongs to, as the driver-style attributes report it: exact for hipHostMalloc (bs_host_alloc,
+    //     torch's pinned allocator) AND for hipHostRegister'ed memory -- for which hipMemGetAddressRange on ROCm 7.2 returns the
+    //     size but a NULL base (scripts/pinned_probe.py -> profiles/r03_pinned_probe.txt)
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, const_cast<void *>(host)) == hipSuccess && base &&
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, const_cast<void *>(host)) == hipSuccess && size) {
+        const char *hb = static_cast<const char *>(base);
+        known = true;
+        covered = hp >= hb && bytes <= size && static_cast<size_t>(hp - hb) <= size - bytes;
+    } else {
+        (void)hipGetLastError();
+        base = nullptr;
+        size = 0;
+        if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, a.devicePointer) == hipSuccess && base) {
+            const char *db = static_cast<const char *>(base), *dp = static_cast<const char *>(a.devicePointer);
+            known = true;
+            covered = dp >= db && bytes <= size && static_cast<size_t>(dp - db) <= size - bytes;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (!known) {
+        // (2) no range to be had: walk the buffer page by page (every page page-locked, the device alias contiguous).  The walk costs a
+        //     runtime query per 4 KiB page, so the last few (pointer, size) pairs that passed are remembered -- callers reuse their frame
+        //     buffers -- and a remembered pair is only trusted after its LAST page has been looked at again: memory that was unregistered
+        //     and re-registered shorter at the same address (the entry would otherwise vouch for pages that are pageable now) fails there.
+        const char *dp = static_cast<const char *>(a.devicePointer);
+        const uintptr_t page = 4096;
+        auto page_ok = [&](uintptr_t q) {
+            hipPointerAttribute_t b;
+            if (hipPointerGetAttributes(&b, reinterpret_cast<const void *>(q)) == hipSuccess && b.type == hipMemoryTypeHost &&
+                static_cast<const char *>(b.devicePointer) - reinterpret_cast<const char *>(q) == dp - hp)
+                return true;
+            (void)hipGetLastError();
+            return false;
+        };
+        const uintptr_t last = (reinterpret_cast<uintptr_t>(hp) + bytes - 1) & ~(page - 1);
+        for (auto &v : ctx->verified) {
+            if (v.host != host || v.bytes != bytes) continue;
+            if (last <= reinterpret_cast<uintptr_t>(hp) || page_ok(last)) covered = true;
+            else v = {};  // stale: forget it, walk again below
+        }
+        if (!covered) {
+            covered = true;
+            for (uintptr_t q = (reinterpret_cast<uintptr_t>(hp) & ~(page - 1)) + page; covered && q < reinterpret_cast<uintptr_t>(hp) + bytes; q += page)
+                covered = page_ok(q);
+            if (covered) {
+                ctx->verified[ctx->verified_next] = {host, bytes};
+                ctx->verified_next = (ctx->verified_next + 1) % (int)(sizeof ctx->verified / sizeof ctx->verified[0]);
+            }
+        }
+    }
+    if (!covered) {
+        if (straddles) *straddles = true;
+        return nullptr;
+    }
+    if (!ctx->zero_copy) return nullptr;  // BLACKSTAR_ZERO_COPY=0: stage + copy (the runtime copies into page-locked memory directly)
+    // page-locked for ANOTHER device only (hipHostMalloc / hipHostRegister there without the Portable flag): not ours to write
+    if (a.device != ctx->device && !(a.allocationFlags & hipHostMallocPortable)) return nullptr;
+    return static_cast<double *>(a.devicePointer);
+}
+
+const char *const kStraddleMsg = "output buffer starts in page-locked memory but is not contained in it (it runs past the end of its hipHostMalloc / "
+                                 "hipHostRegister range, e.g. into pageable memory between two registered ranges): neither the kernel nor the runtime's copy can deliver into it";
+
+// BLACKSTAR_POST_CUS as a number: 0 = never partition, otherwise a multiple of 4 in [8, 32] (rounded down, at least 8)
+int post_cus_setting(int v)
+{
+    if (v <= 0) return 0;
+    return std::max(8, std::min(32, v) / 4 * 4);
+}
+
+int ensure_scratch(bs_ctx *ctx, size_t bytes)
+{
+    if (ctx->scratch_cap >= bytes) return BS_OK;
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr;
+    ctx->scratch_cap = 0;
+    const size_t cap = std::max<size_t>(bytes, size_t(1) << 20);
+    if (hipMalloc(&ctx->d_scratch, cap) != hipSuccess) return fail(BS_ENOMEM, "hipMalloc scratch failed");
+    ctx->scratch_cap = cap;
+    return BS_OK;
+}
+// The arithmetic a frame is traced with.  FAST's error model (rounding differences of ~1 ulp per right-hand side, amplified by
+// the discrete map) needs the RK4 step to resolve the field: with stepSize above 0.5 Schwarzschild radii a single step past the
+// hole amplifies a perturbation by >10x and FAST and STRICT trajectories part ways (scripts/fuzz_worst.py: terminal directions
+// 4e-3 apart at stepSize 1.0, all of the fuzz's largest colour deviations), so such frames are traced with STRICT arithmetic even
+// in FAST mode -- the reference's default is 0.3 and every scene file it ships uses that.  (BLACKSTAR_FAST_GUARD=0: off, for A/B.)
+int effective_mode(const bs_ctx *ctx, const bs_config *cfg)
+{
+    if (ctx->mode == BS_MODE_FAST && ctx->fast_guard && !(cfg->step_size <= 0.5)) return BS_MODE_STRICT;
+    return ctx->mode;
+}
+}  // namespace bs
+
+using bs::fail;
+
+extern "C" {
+
+int bs_abi_version(void) { return BS_ABI_VERSION; }
+
+const char *bs_last_error(void) { return bs::error_message().c_str(); }
+
+bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
+{
+    if (device < 0) { fail(BS_EDEVICE, "this library has no CPU backend: device must be a HIP device ordinal >= 0"); return nullptr; }
+    if (n_stars && !stars) { fail(BS_EINVAL, "stars is null"); return nullptr; }
+    if (n_stars >= (size_t(1) << 30)) { fail(BS_EINVAL, "too many stars"); return nullptr; }
+    for (size_t i = 0; i < n_stars; i++) {
+        double h = stars[i].hue * 2 * 3.141592653589793;
+        if (!(h >= 0 && h < 2 * 3.141592653589793)) { fail(BS_EINVAL, "HSI pixel is not properly scaled (star hue outside [0,1))"); return nullptr; }
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device >= count) {
+        fail(BS_EDEVICE, e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no such HIP device");
+        return nullptr;
+    }
+    bs_ctx *ctx = new (std::nothrow) bs_ctx();
+    if (!ctx) { fail(BS_ENOMEM, "out of host memory"); return nullptr; }
+    ctx->device = device;
+    ctx->n_stars = n_stars;
+    if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
+    if (const char *m = std::getenv("BLACKSTAR_STAGGER_MIN_TILES")) ctx->stagger_min_tiles = std::max(0, std::atoi(m));
+    if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
+    if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;
+    if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
+    if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));
+    if (const char *m = std::getenv("BLACKSTAR_POST_CUS")) ctx->post_cus_req = std::strcmp(m, "auto") ? bs::post_cus_setting(std::atoi(m)) : -1;
+    if (const char *m = std::getenv("BLACKSTAR_POST_PLAN_CUS")) ctx->post_plan_cus = std::max(0, std::atoi(m));
+    if (const char *m = std::getenv("BLACKSTAR_BLOOM_PLAN_CUS")) ctx->bloom_plan_cus = std::max(0, std::atoi(m));
+    if (const char *m = std::getenv("BLACKSTAR_MODE")) {
+        if (!std::strcmp(m, "fast")) ctx->mode = BS_MODE_FAST;
+        else if (!std::strcmp(m, "strict")) ctx->mode = BS_MODE_STRICT;
+    }
+    std::vector<bs::StarNode> nodes;
+    std::vector<bs::StarColor> colors;
+    std::vector<uint32_t> cell_start;
+    bs::build_star_index(stars, n_stars, nodes, colors, cell_start);
+    ctx->n_entries = nodes.size();
+    auto ok = [&](hipError_t r, const char *what) {
+        if (r == hipSuccess) return true;
+        fail(BS_EDEVICE, std::string(what) + ": " + hipGetErrorString(r));
+        return false;
+    };
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    }
+    bool good = ok(hipSetDevice(device), "hipSetDevice") &&
+                ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+                ok(hipEventCreate(&ctx->ev_u0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev_u1), "hipEventCreate") &&
+                ok(hipMalloc((void **)&ctx->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(bs::StarNode)), "hipMalloc nodes") &&
+                ok(hipMalloc((void **)&ctx->d_colors, std::max<size_t>(1, colors.size()) * sizeof(bs::StarColor)), "hipMalloc colors") &&
+                ok(hipMalloc((void **)&ctx->d_cell_start, cell_start.size() * sizeof(uint32_t)), "hipMalloc cell_start") &&
+                ok(hipMemcpy(ctx->d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "upload cell_start") &&
+                ok(hipMalloc((void **)&ctx->d_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
+                ok(hipHostMalloc((void **)&ctx->h_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
+                ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
+                ok(hipMemcpy(ctx->d_colors, colors.data(), colors.size() * sizeof(bs::StarColor), hipMemcpyHostToDevice), "upload colors");
+    if (good) {
+        static const std::vector<double> table = [] { std::vector<double> t(257); bs::srgb8_thresholds(t.data()); return t; }();
+        good = ok(hipMalloc((void **)&ctx->d_srgb_table, 257 * sizeof(double)), "hipMalloc srgb table") &&
+               ok(hipMemcpy(ctx->d_srgb_table, table.data(), 257 * sizeof(double), hipMemcpyHostToDevice), "upload srgb table");
+    }
+    for (int k = 0; good && k < bs_ctx::kSlots; k++) {
+        bs_ctx::LaunchSlot &sl = ctx->slots[k];
+        sl.d_counters = ctx->d_counters + (size_t)k * bs::kCounters;
+        sl.h_counters = ctx->h_counters + (size_t)k * bs::kCounters;
+        good = ok(hipEventCreate(&sl.ev0), "hipEventCreate") && ok(hipEventCreate(&sl.ev1), "hipEventCreate") &&
+               ok(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (!good) {
+        const std::string keep = bs::error_message();
+        bs_destroy(ctx);
+        (void)fail(BS_EDEVICE, keep);
+        return nullptr;
+    }
+    return ctx;
+}
+int bs_device_count(void)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return count;
+}
+
+void bs_destroy(bs_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->device >= 0 && hipSetDevice(ctx->device) == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+        if (ctx->d_colors) (void)hipFree(ctx->d_colors);
+        if (ctx->d_cell_start) (void)hipFree(ctx->d_cell_start);
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_img) (void)hipFree(ctx->d_img);
+        if (ctx->d_img2) (void)hipFree(ctx->d_img2);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        for (bs_ctx::LaunchSlot &sl : ctx->slots)
+            for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev_done})
+                if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->ev_frame)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->ev_band)
+            if (e) (void)hipEventDestroy(e);
+        for (double *b : ctx->d_post)
+            if (b) (void)hipFree(b);
+        if (ctx->d_u8) (void)hipFree(ctx->d_u8);
+        if (ctx->d_u8b) (void)hipFree(ctx->d_u8b);
+        if (ctx->d_u8c) (void)hipFree(ctx->d_u8c);
+        if (ctx->d_img3) (void)hipFree(ctx->d_img3);
+        for (unsigned char *b : ctx->d_png_scratch)
+            if (b) (void)hipFree(b);
+        for (unsigned char *b : ctx->d_png_file)
+            if (b) (void)hipFree(b);
+        if (ctx->h_png_bytes) (void)hipHostFree(ctx->h_png_bytes);
+        for (auto &b : ctx->file_pool)
+            if (b.first) (void)hipHostFree(b.first);
+        if (ctx->ev_png) (void)hipEventDestroy(ctx->ev_png);
+        for (bs_ctx::Partition &pt : ctx->parts)
+            for (hipStream_t st : {pt.trace[0], pt.trace[1], pt.post})
+                if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : ctx->ev_traced)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->ev_posted)
+            if (e) (void)hipEventDestroy(e);
+        if (ctx->ev_post) (void)hipEventDestroy(ctx->ev_post);
+        if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
+        if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+        if (ctx->ev_u0) (void)hipEventDestroy(ctx->ev_u0);
+        if (ctx->ev_u1) (void)hipEventDestroy(ctx->ev_u1);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int bs_set_mode(bs_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != BS_MODE_STRICT && mode != BS_MODE_FAST)) return fail(BS_EINVAL, "bad mode");
+    ctx->mode = mode;
+    return BS_OK;
+}
+
+int bs_get_mode(const bs_ctx *ctx) { return ctx ? ctx->mode : BS_EINVAL; }
+int bs_validate_config(const bs_config *cfg)
+{
+    if (!cfg) return fail(BS_EINVAL, "null argument");
+    bs::TraceParams p;
+    std::memset(&p, 0, sizeof p);
+    std::string err;
+    if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
+    return BS_OK;
+}
+
+int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg)
+{
+    if (!ctx || !cfg) return fail(BS_EINVAL, "null argument");
+    return bs::effective_mode(ctx, cfg);
+}
+
+int bs_set_max_steps(bs_ctx *ctx, int max_steps)
+{
+    if (!ctx || max_steps <= 0) return fail(BS_EINVAL, "bad max_steps");
+    // the kernel counts a ray's steps in an int and the frame's in 64 bits: 2^30 rays (the largest frame) x 2^30 steps = 2^60
+    if (max_steps > BS_MAX_STEPS_LIMIT) return fail(BS_EINVAL, "max_steps above BS_MAX_STEPS_LIMIT (2^30): the step counters could not hold a frame of capped rays");
+    ctx->max_steps = max_steps;
+    return BS_OK;
+}
+void *bs_host_alloc(bs_ctx *ctx, size_t bytes)
+{
+    if (!ctx || bytes == 0) { fail(BS_EINVAL, "null context or zero size"); return nullptr; }
+    void *p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        fail(BS_ENOMEM, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void bs_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

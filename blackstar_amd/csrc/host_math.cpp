@@ -98,22 +98,21 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
 {
     if (c.width <= 0 || c.height <= 0) { err = "resolution must be positive"; return false; }
     if ((long long)c.width * c.height > (1LL << 28)) { err = "resolution too large"; return false; }
-    // Inputs the reference does not survive either.  colorize has no iteration cap (src/Raytracer.hs:80-86): a NaN anywhere in the
-    // ray state makes every guard of findColor false (:93-98) and the loop never ends; a non-positive stepSize never moves a ray out
-    // of [1, safeDistance]; lookAt == position gives every ray the velocity 0 (linear's normalize returns the zero vector unchanged).
-    // Behind a blocking C call that would be max_steps x rays steps inside one uninterruptible kernel (seconds to minutes), so such
-    // configurations are refused up front.
+    // Inputs the reference does not survive either.  colorize has no iteration cap (src/Raytracer.hs:80-86): a NaN in the ray state makes
+    // every guard of findColor false (:93-98) and the loop never ends; a non-positive stepSize never moves a ray out of [1, safeDistance];
+    // lookAt == position gives every ray the velocity 0 (linear's normalize returns the zero vector unchanged).  Behind a blocking C call
+    // that would be max_steps x rays steps inside one uninterruptible kernel (seconds to minutes), so such configurations are refused up
+    // front.  ONLY such: what enters the ray state is the camera (position, lookAt, upVec, fov) and stepSize.  Everything else the
+    // reference renders, this renders -- negative disk radii (render squares them, :61-62, so -3 is 3), infinite or NaN disk / star
+    // parameters (safeDistance depends on the camera alone, :59-60, so every ray still ends; pixels come out inf / NaN as they do there).
     {
         const struct { const char *name; const double *v; int n; } fields[] = {
             {"camera.position", c.cam_pos, 3}, {"camera.lookAt", c.cam_lookat, 3}, {"camera.upVec", c.cam_up, 3}, {"camera.fov", &c.fov, 1},
-            {"scene.stepSize", &c.step_size, 1}, {"scene.starIntensity", &c.star_intensity, 1}, {"scene.starSaturation", &c.star_saturation, 1},
-            {"scene.diskColor", c.disk_hsi, 3}, {"scene.diskOpacity", &c.disk_opacity, 1}, {"scene.diskInner", &c.disk_inner, 1},
-            {"scene.diskOuter", &c.disk_outer, 1}};
+            {"scene.stepSize", &c.step_size, 1}};
         for (const auto &f : fields)
             for (int i = 0; i < f.n; i++)
                 if (!std::isfinite(f.v[i])) { err = std::string(f.name) + " is not finite (the reference's colorize would never terminate: src/Raytracer.hs:80-86)"; return false; }
         if (!(c.step_size > 0)) { err = "scene.stepSize must be positive (the reference's colorize would never terminate: src/Raytracer.hs:80-86)"; return false; }
-        if (c.disk_inner < 0 || c.disk_outer < 0) { err = "scene.diskInner / scene.diskOuter must not be negative"; return false; }
         {   // linear's normalize leaves a vector with |v|^2 <= 1e-12 as it is: a view direction that short makes every ray's velocity
             // that short too (generateRay never gets a unit vector to work with), and the rays crawl: >= 1e8 steps to leave the scene
             const double dv[3] = {c.cam_lookat[0] - c.cam_pos[0], c.cam_lookat[1] - c.cam_pos[1], c.cam_lookat[2] - c.cam_pos[2]};

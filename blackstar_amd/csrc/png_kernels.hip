@@ -107,18 +107,6 @@ size_t png_block_count(int w, int h)
     return (size_t)((total + kBlock - 1) / kBlock);
 }
 
-// Microseconds the four kernels take for a w x h frame on `cus` CUs (model): the block kernel is bound by the latency of its phases --
-// about 91 us per workgroup, three resident per CU (LDS), so 3 cus / 91 workgroups per microsecond once the CUs are full and never less
-// than one workgroup's 91 us -- the filter kernel about 25 us per eight rows per CU, and about 60 us of finish + gather that nothing hides.
-// Measured on the whole chip (1080p: 760 blocks, all resident at once): 91 + 29 + 23 + 46 us (profiles/r03_png_kernel_stats.csv); on 8 CUs
-// about 3.5 ms, on 16 about 1.8 (from the batch times of scripts/png_partition_ab.py).
-double estimate_png_us(int w, int h, int cus)
-{
-    if (w <= 0 || h <= 0 || cus <= 0) return -1.0;
-    const double nb = (double)png_block_count(w, h);
-    return std::max(91.0, nb * 91.0 / (3.0 * cus)) + std::max(25.0, (double)h * 25.0 / (8.0 * cus)) + 60.0;
-}
-
 size_t png_scratch_bytes(int w, int h)
 {
     const uint64_t total = (uint64_t)h * ((uint64_t)3 * w + 1);

@@ -835,26 +835,6 @@ static void blur_passes(const double *src, double *d_a, double *d_b, int w, int 
     }
 }
 
-// Estimated duration (microseconds) of bloom + sRGB8 of a w x h frame on a stream that owns `cus` CUs, the sweeps planned for that many
-// (bs_render_rgb8_batch's partitioned pipeline decides with it how many CUs the post stage gets).  Model fitted to
-// scripts/post_cost_probe.py (profiles/r03_post_partition_ab.txt): a sweep is ceil(groups / cus) rounds of workgroups, a workgroup takes
-// 4 us + (12.5 + 0.9 px) ns per row (chains of `n` rows; the more chain-pixels px a workgroup carries, the longer its STORE wavefronts
-// need per block: 17 ns per row at px = 5, 23 at px = 12), the combine streams 2.1 x the image at ~50 GB/s per CU.  Within ~10 % of the
-// measured 3.77 / 17.4 / 5.0 / 1.80 ms (1080p, 4K, r = 192, 720p on 8 CUs).
-// Returns a negative value when the frame does not take the LDS-DMA sweep path (odd sizes, very wide windows): no estimate.
-double estimate_post_us(int w, int h, int divider, int cus)
-{
-    if (divider <= 0 || w / divider < 1 || cus < 1) return -1.0;
-    const int r = w / divider;
-    SweepPlan ph, pv;
-    alignas(16) static const double aligned_dummy[2] = {0, 0};
-    if (!plan_dma_sweep(aligned_dummy, h, w, r, cus, ph, false, kDmaLds - 1024) || !plan_dma_sweep(aligned_dummy, w, h, r, cus, pv, false, kDmaLds - 1024))
-        return -1.0;
-    auto sweep = [&](const SweepPlan &pl, int rows) { return (double)((pl.groups + cus - 1) / cus) * (4.0 + (0.0125 + 0.0009 * pl.px) * rows); };
-    const double combine = 2.1 * (double)w * h * 24.0 / (cus * 50e9) * 1e6;
-    return 3.0 * (sweep(ph, w) + sweep(pv, h)) + combine;
-}
-
 int launch_bloom(const double *d_in, double *d_out, double *d_a, double *d_b, int w, int h, double strength, int divider, int n_cu, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;

@@ -70,15 +70,3 @@ void build_star_index(const bs_star *stars, size_t n, std::vector<StarNode> &nod
 }
 
 }  // namespace bs
-
-extern "C" long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_start, int32_t *entry_star, size_t cap)
-{
-    if ((n_stars && !stars) || !cell_start || (cap && !entry_star)) return BS_EINVAL;
-    std::vector<bs::StarNode> nodes;
-    std::vector<bs::StarColor> colors;
-    std::vector<uint32_t> cs;
-    bs::build_star_index(stars, n_stars, nodes, colors, cs);
-    std::copy(cs.begin(), cs.end(), cell_start);
-    for (size_t k = 0; k < nodes.size() && k < cap; k++) entry_star[k] = nodes[k].id;
-    return (long)nodes.size();
-}

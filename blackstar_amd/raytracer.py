@@ -149,11 +149,11 @@ def write_png(rgb8: np.ndarray, path: str, tree: StarTree = None) -> None:
 
 
 def trace_rays(cfg, startree: StarTree, ys, xs) -> np.ndarray:
-    """Test hook: per-ray terminal records for traced-resolution pixels (ys, xs)."""
+    """Test hook (libblackstar_gpu_debug.so): per-ray terminal records for traced-resolution pixels (ys, xs)."""
     c = _bs_config(cfg)
     yx = np.ascontiguousarray(np.stack([np.asarray(ys), np.asarray(xs)], axis=1).astype(np.int32))
     rec = np.zeros(len(yx), _lib.RECORD_DTYPE)
-    _lib.check(_lib.lib().bs_trace_rays(startree.handle, C.byref(c), yx.ctypes.data, len(yx), rec.ctypes.data), "bs_trace_rays")
+    _lib.check(_lib.debug_lib().bs_trace_rays(startree.handle, C.byref(c), yx.ctypes.data, len(yx), rec.ctypes.data), "bs_trace_rays")
     return rec
 
 

@@ -30,18 +30,24 @@
 extern "C" {
 #endif
 
-/* 3 (round 3): the PNG entry points (bs_png_bound, bs_encode_png[_device], bs_render_png[_batch], bs_render_png_files), BS_EIO -- additions only, every
+/* 4 (round 4): the test hooks (bs_debug_*, bs_trace_rays, struct bs_ray_record) left this header and this library: they are declared in
+ * blackstar_gpu_debug.h and live in libblackstar_gpu_debug.so; bs_debug_post_cus is gone (the CU partition is measured, not modelled);
+ * bs_set_max_steps refuses values above BS_MAX_STEPS_LIMIT; bs_validate_config accepts what the reference renders (negative disk
+ * radii, non-finite disk / star parameters).  Every struct and every other signature is unchanged.
+ * 3 (round 3): the PNG entry points (bs_png_bound, bs_encode_png[_device], bs_render_png[_batch], bs_render_png_files), BS_EIO -- additions only, every
  * struct and every version-2 signature is unchanged.
  * 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
  * non-finite fields, stepSize <= 0, negative radii, lookAt within 1e-6 of position).  1: rounds 1-2.  A binding should compare
  * bs_abi_version() with the BS_ABI_VERSION it was written against before anything else. */
-#define BS_ABI_VERSION 3
+#define BS_ABI_VERSION 4
 
 enum {
     BS_OK = 0,
     BS_EINVAL = -1,  /* bad argument: null pointer, non-positive resolution, buffer too small, bad hue; or a configuration on which the
-                      * reference's colorize never terminates (src/Raytracer.hs:80-86 has no iteration cap): a non-finite value anywhere
-                      * in bs_config, stepSize <= 0, a negative disk radius, lookAt within 1e-6 of position.  Returned before any GPU work. */
+                      * reference's colorize never terminates (src/Raytracer.hs:80-86 has no iteration cap): a non-finite camera
+                      * position / lookAt / upVec / fov / stepSize, stepSize <= 0, lookAt within 1e-6 of position.  Returned before any
+                      * GPU work.  Everything the reference does render is accepted: negative disk radii (render squares them,
+                      * src/Raytracer.hs:61-62), infinite or NaN disk and star parameters (pixels come out inf / NaN like the reference's). */
     BS_EDEVICE = -2, /* no such HIP device / HIP runtime error */
     BS_ENOMEM = -3,  /* host or device allocation failed */
     BS_ECAPPED = -4, /* never returned: rays stopped by the step cap are reported through bs_stats_t.capped only */
@@ -104,14 +110,6 @@ typedef struct bs_stats_t {
                              * from the kernel itself; 0: it went through a device image and a copy (pageable memory, a buffer that is
                              * not provably inside ONE page-locked range, BLACKSTAR_ZERO_COPY=0) */
 } bs_stats_t;
-
-/* Test hook: per-ray terminal state (not part of the reference interface). */
-typedef struct bs_ray_record {
-    double vel[3], pos[3]; /* state fed to the terminating findColor call */
-    double rgba[4];        /* composited colour before dropAlpha */
-    int32_t steps, fate;   /* fate: 0 horizon, 1 escaped, 2 step cap */
-    int32_t disk_hits, star_hits;
-} bs_ray_record;
 
 typedef struct bs_ctx bs_ctx;
 
@@ -201,11 +199,18 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
  * thread per context) and leaves the GPU as height*width*3 bytes of RGB8 in outs[i].  bloom_strengths[i] == 0 (or a NULL array)
  * skips the bloom of that frame like the reference does; bloom_dividers is only read where the strength is not 0.  Per context two
  * frames are in flight on two streams: the next frame's trace kernel takes over the SIMDs this frame's last tiles leave, and this
- * frame's bloom runs on the first CUs the next trace kernel frees.  Where it pays (supersampled frames with bloom from 720p up: the
- * default-aa frame 4.28 instead of 4.67 ms, at 3840x2160 17.4 instead of 17.8, lensing-disk at 4K 19.5 instead of 20.2) the chip is PARTITIONED instead: the trace kernels run on streams whose CU mask leaves 8
- * or 16 CUs out, bloom + sRGB8 of the previous frames run on a stream that owns exactly those, three frames in flight
- * (only when every outs[i] is page-locked; env BLACKSTAR_POST_CUS=0 turns it off, 8|16|24|32 forces it).  Page-locked outs[i]
- * (bs_host_alloc) are written by the last kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame either way; bs_stats is not updated. */
+ * frame's bloom runs on the first CUs the next trace kernel frees.  Where it MEASURES faster the chip is PARTITIONED instead: the trace
+ * kernels run on streams whose CU mask leaves 8 or 16 CUs out, bloom + sRGB8 of the previous frames run on a stream that owns exactly
+ * those, three frames in flight (the default-aa frame: 4.28 instead of 4.67 ms; 3840x2160: 17.4 instead of 17.8).  The decision is a
+ * measurement, taken once per frame shape (size, supersampling, bloom divider, arithmetic) and context: the first call whose share for a
+ * context holds at least 20 frames of one shape renders 8 of them on the shared chip and then 4 each shared / with 8 / with 16 post-stage
+ * CUs, timed, and the context remembers the fastest (a partition only if it wins by more than 1.5 %).  Shorter or mixed calls use what
+ * has been remembered, else the shared chip.  Only when every outs[i] is page-locked.  Environment BLACKSTAR_POST_CUS = 0 (never) | 8 |
+ * 16 | 24 | 32 (always that many) overrides.  The CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags):
+ * a host application that keeps the NULL stream of the device busy from another thread during this call serialises the pipeline
+ * against its own work -- correct, but the overlap is lost; BLACKSTAR_POST_CUS=0 avoids those streams altogether.  Page-locked outs[i]
+ * (bs_host_alloc) are written by the last kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame whichever way a
+ * frame was made; bs_stats is not updated. */
 int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                          const int *bloom_dividers, unsigned char *const *outs);
 
@@ -222,7 +227,9 @@ int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, 
  * out_png / d_png buffer below must have.  BS_EINVAL for non-positive sizes and frames above 1e9 pixels / files of 4 GiB. */
 int bs_png_bound(int width, int height, size_t *out_bytes);
 /* Enqueue-only: d_rgb8 (height*width*3 bytes, device) -> the file in d_png (cap >= bs_png_bound; device memory or a page-locked host
- * buffer's device alias), its size in *d_file_bytes (one 8-byte-aligned uint64, same choice), both valid once the stream has passed. */
+ * buffer's device alias), its size in *d_file_bytes (one 8-byte-aligned uint64, same choice), both valid once the stream has passed.
+ * (The encoder's scratch for this entry point and for bs_encode_png / bs_render_png is the context's own, separate from the batch
+ * pipelines': a batch call may follow at once.  Two calls on different streams are ordered by an event, like bs_bloom_device.) */
 int bs_encode_png_device(bs_ctx *ctx, const void *d_rgb8, int width, int height, void *d_png, size_t cap, void *d_file_bytes, void *hip_stream);
 /* Host buffers, blocking: the parity hook of the encoder alone (rgb8 -> file).  A page-locked out_png is written by the GPU itself. */
 int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned char *out_png, size_t cap, size_t *out_bytes);
@@ -232,8 +239,8 @@ int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int 
 /* bs_render_rgb8_batch with files instead of pixels: outs[i] (capacity caps[i] >= bs_png_bound of frame i) receives frame i's PNG file,
  * out_bytes[i] its size.  Two frames in flight per context, the encoder of frame k running under the trace kernel of frame k+1;
  * page-locked outs[i] are written by the encoder itself (only the file's bytes cross PCIe).  The chip is partitioned like in
- * bs_render_rgb8_batch, with the encoder's kernels counted into the post stage (the default-aa frame: 16 CUs, 4.44 ms per frame
- * against 4.77 on the shared chip and 4.31 for bs_render_rgb8_batch).  Blocking; bs_stats is not updated. */
+ * bs_render_rgb8_batch -- measured separately for files, whose post stage also runs the encoder's kernels (the default-aa frame: 16 CUs,
+ * 4.44 ms per frame against 4.77 on the shared chip and 4.31 for bs_render_rgb8_batch).  Blocking; bs_stats is not updated. */
 int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                         const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
 
@@ -245,43 +252,15 @@ int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
 int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                         const int *bloom_dividers, const char *const *paths, int pipe);
 
-/* Probe hook: bs_encode_png's block kernel with a shader-clock stamp (s_memtime) taken by every workgroup before its first phase and
- * after each of its 22 phases (blackstar_amd/csrc/png_block.h): clocks[b * 23 + p], b < ceil(height * (3 width + 1) / 8192).
- * scripts/png_phase_probe.py turns them into the table in profiles/. */
-int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned long long *clocks, size_t n_clocks);
-
-/* Test hook, host-only: how many CUs bs_render_rgb8_batch would set aside for the post stage of a batch made of this frame on a chip
- * of n_cu CUs in the given BS_MODE_* (0 = none: the post stage shares the chip with the trace kernels).  See bs_render_rgb8_batch.
- * mode | BS_DEBUG_POST_CUS_PNG: the same for bs_render_png_batch, whose post stage also encodes the file. */
-#define BS_DEBUG_POST_CUS_PNG 0x100
-int bs_debug_post_cus(const bs_config *cfg, double bloom_strength, int bloom_divider, int n_cu, int mode);
-/* Test hook: the CUs the post stage owned in this context's share of the last bs_render_rgb8_batch (0 = the shared chip, -1 = no batch yet). */
-int bs_debug_last_post_cus(const bs_ctx *ctx);
-
-/* Test hook: trace the given traced-resolution pixels (y,x pairs) and return per-ray records (host buffers). */
-int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out);
-
 /* Replaces: starLookup starmap intensity saturation vel (src/StarMap.hs:93-115), batched: dirs holds n
  * un-normalised direction vectors (x,y,z interleaved, host); out_rgb gets n RGB triples, out_hits (may be
  * NULL) the number of stars within the radius.  Runs the same device function the trace kernel calls. */
 int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const double *dirs, size_t n, double *out_rgb, int32_t *out_hits);
 
-/* Test hook: out_sqrt[i] = sqrt(a[i]), out_div[i] = a[i] / b[i] computed on the device (host buffers);
- * proves the f64 sqrt / divide sequences STRICT mode relies on are correctly rounded.  bare = 0: hipcc's
- * lowering of sqrt and '/'; bare = 1: the scaling-free FMA sequences used inside the RK4 right-hand side. */
-int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare);
-
-/* Test hook: depth (0..4, default 4) of the per-lane LDS queue of disk crossings; a ray with more crossings
- * takes the kernel's simple re-trace path, which tests force by shrinking the queue. */
-int bs_debug_set_disk_slots(bs_ctx *ctx, int slots);
-
-/* Roofline probe: times `iters` x 32 dependent-chain FP64 VALU instructions per lane (8 independent chains)
- * on `blocks` x 256 lanes.  kind 0 v_fma_f64, 1 v_mul_f64, 2 v_add_f64, 3 v_rsq_f64, 4 v_rcp_f64 (8 chains:
- * issue rate); 5/6/7 v_fma_f64 with 1/2/4 chains, 8 v_rsq_f64 with 1 chain (dependent latency at 1 wave/SIMD).
- * out_ginstr = lane-instructions executed / 1e9 (so rate = out_ginstr / out_ms * 1e3 Ginstr/s). */
-int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr);
-
-int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST (env BLACKSTAR_MODE=strict|fast overrides at bs_create) */
+/* Environment read ONCE, at bs_create (A/B switches for measurements; a host application sets none of them): BLACKSTAR_MODE=strict|fast
+ * (initial bs_set_mode), BLACKSTAR_POST_CUS (see bs_render_rgb8_batch), BLACKSTAR_ZERO_COPY=0, BLACKSTAR_FAST_GUARD=0, BLACKSTAR_HOST_BANDS,
+ * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS. */
+int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST */
 int bs_get_mode(const bs_ctx *ctx);
 /* The arithmetic a render of `cfg` on this context would be traced with: bs_get_mode(), except that a FAST context traces frames
  * with stepSize > 0.5 in STRICT (see BS_MODE_FAST above).  Returns BS_MODE_* or BS_EINVAL.  For batch frames (whose statistics
@@ -301,21 +280,9 @@ int bs_abi_version(void);
  * holds; writes at most `cap` of them.  Host-only; returns BS_EINVAL if nbytes < 28. */
 long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size_t cap);
 
-/* Test hook, host-only (no device is touched): the star index bs_create builds for buildStarTree (src/StarMap.hs:90-91),
- * a cube-map grid of star directions ("Star lookup").  Writes the 6*256*256 + 2 cell offsets to
- * cell_start (entries of cell c are [cell_start[c], cell_start[c+1]); the last cell lists the stars around the origin)
- * and, for each entry, the index of its star in `stars` to entry_star (at most `cap`).  Returns the number of entries
- * (stars + copies in neighbouring faces), or BS_EINVAL. */
-long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_start, int32_t *entry_star, size_t cap);
-
-/* Test hook, host-only: the 257 thresholds of writeImg's pixel map toWord8 . sRGB (src/Raytracer.hs:23-32) that bs_srgb8 and
- * bs_render_rgb8 compare against on the device: table[k], k = 1..255, is the smallest double whose byte is >= k (found by
- * bisection with the host libm's pow, once per process); table[0] = -inf, table[256] = +inf. */
-int bs_debug_srgb8_table(double table[257]);
-
 /* Host-only: the checks every bs_render* entry point applies to its bs_config before any GPU work (see BS_EINVAL): BS_OK, or
  * BS_EINVAL with the reason in bs_last_error().  No reference counterpart: `render` is total in the types and simply never
- * returns on such inputs (src/Raytracer.hs:80-86). */
+ * returns on such inputs (src/Raytracer.hs:80-86).  Only inputs on which it would not return are refused. */
 int bs_validate_config(const bs_config *cfg);
 
 /* Replaces: toPixelRGB on PixelHSI (massiv-io Graphics.ColorSpace; call sites src/Raytracer.hs:65,

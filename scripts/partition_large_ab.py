@@ -33,6 +33,6 @@ for w, h in ((2240, 1260), (2560, 1440), (3200, 1800), (3840, 2160)):
                 best = min(best, (time.perf_counter() - t0) / N)
             rec[setting] = round(best * 1e3, 3)
             if setting == "auto":
-                rec["auto_post_cus"] = _lib.lib().bs_debug_last_post_cus(tree.handle)
+                rec["auto_post_cus"] = _lib.debug_lib().bs_debug_last_post_cus(tree.handle)
             tree.close()
         print(json.dumps(rec), flush=True)

@@ -21,6 +21,6 @@ for scene, w, h, mode in (("lensing-disk", 3840, 2160, "fast"), ("lensing-disk",
         for _ in range(3):
             t0 = time.perf_counter(); bs.render_rgb8_batch([cfg] * N, [tree], outs=outs); best = min(best, (time.perf_counter() - t0) / N)
         rec[setting] = round(best * 1e3, 3)
-        if setting == "auto": rec["auto_post_cus"] = _lib.lib().bs_debug_last_post_cus(tree.handle)
+        if setting == "auto": rec["auto_post_cus"] = _lib.debug_lib().bs_debug_last_post_cus(tree.handle)
         tree.close()
     print(json.dumps(rec), flush=True)

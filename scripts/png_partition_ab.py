@@ -33,7 +33,7 @@ for scene, w, h, bloom in (("default-aa", 1920, 1080, 0.4), ("default-aa", 1920,
             best = min(best, (time.perf_counter() - t0) / N)
         rec[setting] = round(best * 1e3, 3)
         if setting == "auto":
-            rec["auto_post_cus"] = _lib.lib().bs_debug_last_post_cus(tree.handle)
+            rec["auto_post_cus"] = _lib.debug_lib().bs_debug_last_post_cus(tree.handle)
         tree.close()
     rows.append(rec)
     print(json.dumps(rec), flush=True)

@@ -17,7 +17,7 @@ h, w, _ = rgb8.shape
 nb = -(-(h * (3 * w + 1)) // 8192)
 clk = np.zeros((nb, len(PHASES) + 1), np.uint64)
 for _ in range(3):
-    _lib.check(_lib.lib().bs_debug_png_phases(tree.handle, rgb8.ctypes.data, w, h, clk.ctypes.data, clk.size), "bs_debug_png_phases")
+    _lib.check(_lib.debug_lib().bs_debug_png_phases(tree.handle, rgb8.ctypes.data, w, h, clk.ctypes.data, clk.size), "bs_debug_png_phases")
 d = np.diff(clk.astype(np.int64), axis=1)
 tot = d.sum(axis=1)
 rows = [{"phase": p, "median_cycles": int(np.median(d[:, i])), "p90_cycles": int(np.percentile(d[:, i], 90)),

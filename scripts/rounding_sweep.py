@@ -26,7 +26,7 @@ for name, gen in (("rhs_range", lambda n: (np.exp(rng.uniform(np.log(1e-3), np.l
         den = a ** 2.5 if name == "rhs_range" else np.exp(rng.uniform(-300, 300, chunk))
         s = np.empty(chunk); d = np.empty(chunk)
         for bare in (0, 1):
-            _lib.check(L.bs_debug_sqrt_div(t.handle, a.ctypes.data, den.ctypes.data, chunk, s.ctypes.data, d.ctypes.data, bare), "sqrt_div")
+            _lib.check(_lib.debug_lib().bs_debug_sqrt_div(t.handle, a.ctypes.data, den.ctypes.data, chunk, s.ctypes.data, d.ctypes.data, bare), "sqrt_div")
             bad[bare][0] += int((s != np.sqrt(a)).sum())
             bad[bare][1] += int((d != a / den).sum())
         total += chunk

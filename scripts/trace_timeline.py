@@ -14,7 +14,7 @@ import blackstar_amd as bs  # noqa: E402
 from blackstar_amd import _lib, synthetic  # noqa: E402
 from oracle import scenes  # noqa: E402
 
-L = _lib.lib()
+L = _lib.lib()   # (a probe build, through BLACKSTAR_LIB: it exports bs_debug_trace_probe itself)
 if not hasattr(L, "bs_debug_trace_probe"):
     raise SystemExit("not a probe build: set BLACKSTAR_LIB to a library built with -DBS_TRACE_PROBE")
 tree = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes()))

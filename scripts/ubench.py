@@ -19,7 +19,7 @@ def run(kind, blocks, iters):
     ms, gi = C.c_double(), C.c_double()
     best = 0.0
     for _ in range(3):
-        _lib.check(L.bs_debug_ubench(t.handle, kind, blocks, iters, C.byref(ms), C.byref(gi)), "ubench")
+        _lib.check(_lib.debug_lib().bs_debug_ubench(t.handle, kind, blocks, iters, C.byref(ms), C.byref(gi)), "ubench")
         best = max(best, gi.value / ms.value * 1e3)
     return best  # 1e9 lane-instructions per second
 

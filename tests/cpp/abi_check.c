@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "blackstar_gpu.h"
+#include "blackstar_gpu_debug.h" /* (includes blackstar_gpu.h; the hooks header must be C99 too -- only its struct is used here) */
 
 int main(void)
 {
@@ -19,7 +19,7 @@ int main(void)
     if (sizeof(bs_stats_t) != 88 || offsetof(bs_stats_t, kernel_ms) != 64 || offsetof(bs_stats_t, effective_mode) != 80 ||
         offsetof(bs_stats_t, zero_copy) != 84)
         return 19;
-    if (BS_ABI_VERSION != 3) return 20;
+    if (BS_ABI_VERSION != 4) return 20;
     if (bs_abi_version() != BS_ABI_VERSION) return 13;
     if (bs_hsi_to_rgb(0.5, 0.1, 1.05, rgb) != BS_OK || rgb[0] < 0.944 || rgb[0] > 0.946) return 14;
     if (bs_hsi_to_rgb(1.0, 0.1, 1.05, rgb) != BS_EINVAL) return 15;

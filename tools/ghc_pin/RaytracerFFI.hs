@@ -36,7 +36,7 @@ foreign import ccall unsafe "&bs_host_free"  p_bs_host_free  :: FunPtr (Ptr CDou
 foreign import ccall safe   "bs_png_bound"  c_bs_png_bound  :: CInt -> CInt -> Ptr CSize -> IO CInt
 foreign import ccall safe   "bs_render_png" c_bs_render_png :: Ptr BsCtx -> Ptr () -> CDouble -> CInt -> Ptr Word8 -> CSize -> Ptr CSize -> IO CInt
 foreign import ccall unsafe "bs_device_count" c_bs_device_count :: IO CInt     -- one context per device for batch mode
-foreign import ccall unsafe "bs_abi_version" c_bs_abi_version :: IO CInt        -- must be 3 (BS_ABI_VERSION this shim was written against)
+foreign import ccall unsafe "bs_abi_version" c_bs_abi_version :: IO CInt        -- must be 4 (BS_ABI_VERSION this shim was written against)
 
 -- struct bs_star  { double x,y,z,hue,sat; int32 mag; int32 _pad; }   = 48 bytes
 pokeStar :: Ptr () -> Int -> (V3 Double, (Int, Double, Double)) -> IO ()
@@ -54,7 +54,7 @@ withGpuTree device tree act = do
   allocaBytes (48 * max 1 n) $ \buf -> do
     forM_ (zip [0 ..] stars) $ \(i, s) -> pokeStar buf i s
     v <- c_bs_abi_version
-    when (v /= 3) $ ioError (userError ("libblackstar_gpu has ABI version " ++ show v ++ ", this shim expects 3"))
+    when (v /= 4) $ ioError (userError ("libblackstar_gpu has ABI version " ++ show v ++ ", this shim expects 4"))
     bracket (c_bs_create (fromIntegral device) buf (fromIntegral n)) c_bs_destroy $ \ctx -> do
       when (ctx == nullPtr) $ c_bs_error >>= peekCString >>= \e -> ioError (userError ("bs_create: " ++ e))
       nullBuf <- newForeignPtr_ nullPtr
