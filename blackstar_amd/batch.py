@@ -114,32 +114,6 @@ def render_png_files(cfgs: Sequence[Config], trees: Sequence[StarTree], paths: S
     _lib.check(_lib.lib().bs_render_png_files(ctxs, len(trees), arr, n, strengths, dividers, cpaths, int(pipe)), "bs_render_png_files")
 
 
-def render_scene_directory(in_dir: str, out_dir: str, trees: Sequence[StarTree], preview: bool = False, pipe: int = 16) -> List[str]:
-    """The reference's batch mode (app/Main.hs:64-77 over handleScene :80-91 and doRender :105-123) without its terminal: every `*.yaml`
-    of `in_dir`, in sorted order, decoded like `decodeFileEither`, `prepareScene`d (preview: 300-px long side, no supersampling, no
-    bloom, name prefixed `prev-`), rendered / bloomed / mapped to sRGB8 / PNG-encoded on the device and written by the library
-    (`bs_render_png_files`, scene i on trees[i % len(trees)]) to `<out_dir>/<scene name>.png` (existing files are overwritten: the reference's --force).
-    A scene file that does not decode is reported like the reference does -- its error is printed, the others are rendered.
-    Returns the paths written."""
-    import os
-    import sys
-
-    from .config_file import ConfigError, prepare_scene
-    names = sorted(f for f in os.listdir(in_dir) if os.path.splitext(f)[1] == ".yaml")
-    cfgs, outs = [], []
-    for f in names:
-        try:
-            cfg = Config.from_file(os.path.join(in_dir, f))
-        except (ConfigError, OSError, ValueError) as e:
-            print(f"{os.path.join(in_dir, f)}: {e}", file=sys.stderr)
-            continue
-        cfgs.append(prepare_scene(cfg, preview))
-        outs.append(os.path.join(out_dir, ("prev-" if preview else "") + os.path.splitext(f)[0] + ".png"))
-    os.makedirs(out_dir, exist_ok=True)
-    render_png_files(cfgs, trees, outs, pipe=pipe)
-    return outs
-
-
 def render_split(cfg, trees: Sequence[StarTree], out: np.ndarray = None) -> np.ndarray:
     """ONE frame over several StarTrees (one per GPU): tree k renders the k-th contiguous band of rows (`bs_render_split`).
     Bit-identical to render(cfg, trees[0]).  `out`: the (h, w, 3) float64 buffer to fill; a page-locked one (alloc_image) is

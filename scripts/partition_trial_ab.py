@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Does the MEASURED partition decision (csrc/batch.cpp: a trial of 8 + 3 x 4 frames per frame shape and context) pick what is fastest?
+For each of the 26 combinations rounds 2-3 measured by hand (scripts/post_partition_ab.py, partition_large_ab.py, partition_more_ab.py, png_partition_ab.py; results: profiles/r03_post_partition_ab.txt,
+r03_partition_large_ab.jsonl, r03_partition_more_ab.jsonl, r03_png_partition_ab.jsonl): the steady-state time per frame with the post stage
+forced to 0 / 8 / 16 CUs (BLACKSTAR_POST_CUS, a context each, N frames per call, best of 3 calls), then a fresh context left to itself:
+its first N-frame call runs the trial (trial_ms = the three segment times, choice = what it remembered), later calls use the choice
+(auto = their best of 3).  regret_pct = auto / min(forced) - 1.  One JSON line per combination, a summary line last.
+Usage: partition_trial_ab.py [N_FRAMES=24] [quick]      (quick: every third combination)"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import blackstar_amd as bs  # noqa: E402
+from blackstar_amd import _lib, synthetic  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+stars = bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_FULL))
+D = _lib.debug_lib()
+# (scene file, width, height, bloomStrength, bloomDivider, mode, form)
+COMBOS = [("default-aa", 1920, 1080, 0.15, 25, "fast", "rgb8"), ("default-aa", 1920, 1080, 0.15, 10, "fast", "rgb8"), ("default-aa", 1280, 720, 0.15, 25, "fast", "rgb8"),
+          ("lensing-disk", 1280, 800, 0.15, 25, "fast", "rgb8"), ("lensing-disk", 3840, 2160, 0.15, 25, "fast", "rgb8"), ("default", 1920, 1080, 0.15, 25, "fast", "rgb8"),
+          ("default-aa", 2240, 1260, 0.4, 25, "fast", "rgb8"), ("default-aa", 2560, 1440, 0.4, 25, "fast", "rgb8"), ("default-aa", 3200, 1800, 0.4, 25, "fast", "rgb8"),
+          ("default-aa", 3840, 2160, 0.4, 25, "fast", "rgb8"), ("default-aa", 2240, 1260, 0.4, 25, "fast", "png"), ("default-aa", 2560, 1440, 0.4, 25, "fast", "png"),
+          ("default-aa", 3200, 1800, 0.4, 25, "fast", "png"), ("default-aa", 3840, 2160, 0.4, 25, "fast", "png"), ("lensing-disk", 2560, 1440, 0.15, 25, "fast", "rgb8"),
+          ("default-aa", 1920, 1080, 0.15, 25, "strict", "rgb8"), ("default-aa", 1280, 720, 0.15, 25, "strict", "rgb8"), ("closeup", 1920, 1080, 0.7, 25, "fast", "rgb8"),
+          ("default-aa", 1920, 1080, 0.4, 25, "fast", "png"), ("default-aa", 1920, 1080, 0.0, 25, "fast", "png"), ("default-aa", 1280, 720, 0.4, 25, "fast", "png"),
+          ("default-aa", 1280, 720, 0.0, 25, "fast", "png"), ("lensing-disk", 1920, 1080, 0.4, 25, "fast", "png"), ("default-aa", 1920, 1080, 0.0, 25, "fast", "rgb8"),
+          ("default-aa", 640, 360, 0.15, 25, "fast", "rgb8"), ("default", 1920, 1080, 0.15, 25, "fast", "png")]
+if "quick" in sys.argv:
+    COMBOS = COMBOS[::3]
+worst, agree = 0.0, 0
+for scene, w, h, strength, divider, mode, form in COMBOS:
+    cfg = bs.Config.from_file(os.path.join(root, "scenes", scene + ".yaml")).with_resolution(w, h)
+    cfg.scene.bloomStrength, cfg.scene.bloomDivider = strength, divider
+    rec = {"scene": scene, "frame": f"{w}x{h}", "ss": bool(cfg.scene.supersampling), "bloom": strength, "divider": divider, "mode": mode, "form": form, "frames_per_call": N}
+    fn = bs.render_png_batch if form == "png" else bs.render_rgb8_batch
+    forced = {}
+    for setting in ("0", "8", "16", "auto"):
+        os.environ["BLACKSTAR_POST_CUS"] = setting
+        tree = bs.StarTree(stars)
+        del os.environ["BLACKSTAR_POST_CUS"]
+        tree.set_mode(_lib.BS_MODE_STRICT if mode == "strict" else _lib.BS_MODE_FAST)
+        bufs = [bs.alloc_png(tree, h, w) if form == "png" else bs.alloc_image(tree, h, w, dtype=np.uint8) for _ in range(4)]
+        outs = [bufs[i % 4] for i in range(N)]
+        fn([cfg] * N, [tree], outs=outs)          # auto: this call is the trial
+        if setting == "auto":
+            ms = (C.c_double * 3)()
+            rec["trial"] = bool(D.bs_debug_last_trial(tree.handle))
+            rec["choice"] = D.bs_debug_partition_choice(tree.handle, C.byref(_lib.make_config(cfg.to_bs_config())), strength, divider, int(form == "png"), ms)
+            rec["trial_ms"] = [round(m, 3) for m in ms]
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn([cfg] * N, [tree], outs=outs)
+            best = min(best, (time.perf_counter() - t0) / N)
+        if setting == "auto":
+            rec["auto"] = round(best * 1e3, 3)
+        else:
+            forced[setting] = round(best * 1e3, 3)
+        del bufs, outs
+        tree.close()
+    rec["forced"] = forced
+    fastest = min(forced, key=forced.get)
+    rec["fastest_forced"] = int(fastest)
+    rec["regret_pct"] = round((rec["auto"] / forced[fastest] - 1) * 100, 2)
+    # "agrees": the choice is the fastest forced setting, or within 1 % of it (two settings that close are the same answer)
+    rec["choice_time_vs_fastest_pct"] = round((forced.get(str(max(rec["choice"], 0)), rec["auto"]) / forced[fastest] - 1) * 100, 2)
+    rec["agrees"] = rec["choice_time_vs_fastest_pct"] <= 1.0
+    worst = max(worst, rec["regret_pct"])
+    agree += rec["agrees"]
+    print(json.dumps(rec), flush=True)
+print(json.dumps({"combinations": len(COMBOS), "choice_is_fastest_or_within_1pct": agree, "worst_regret_pct": worst}), flush=True)

@@ -359,8 +359,15 @@ def test_render_scene_directory_is_the_references_batch_mode(tree, tmp_path):
     mode = prepareScene (300-px long side, no supersampling, no bloom, `prev-` prefix).  Files decode to bs_render_rgb8 of the scene."""
     import shutil
 
+    import importlib.util
+
     import blackstar_amd as bs
     from tests.ghc_pin import decode_png_rgb8
+    # (an EXAMPLE since round 4 -- the CLI side of blackstar is out of scope -- kept under test because it drives bs_render_png_files)
+    spec = importlib.util.spec_from_file_location("render_scene_directory_example", os.path.join(os.path.dirname(SCENES), "examples", "render_scene_directory.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    render_scene_directory = mod.render_scene_directory
     src = tmp_path / "scenes"
     src.mkdir()
     for name in ("default-aa", "lensing-disk", "closeup"):
@@ -379,11 +386,11 @@ def test_render_scene_directory_is_the_references_batch_mode(tree, tmp_path):
         (src / (name + ".yaml")).write_text(yaml.safe_dump(d))
         small[name] = bs.Config.from_file(str(src / (name + ".yaml")))
     out = tmp_path / "out"
-    paths = bs.render_scene_directory(str(src), str(out), [tree])
+    paths = render_scene_directory(str(src), str(out), [tree])
     assert [os.path.basename(p) for p in paths] == ["closeup.png", "default-aa.png", "lensing-disk.png"] and sorted(os.listdir(out)) == sorted(os.path.basename(p) for p in paths)
     for name, cfg in small.items():
         assert np.array_equal(decode_png_rgb8(open(out / (name + ".png"), "rb").read()), bs.render_rgb8(cfg, tree)), name
-    prev = bs.render_scene_directory(str(src), str(out), [tree], preview=True)
+    prev = render_scene_directory(str(src), str(out), [tree], preview=True)
     assert [os.path.basename(p) for p in prev] == ["prev-closeup.png", "prev-default-aa.png", "prev-lensing-disk.png"]
     img = decode_png_rgb8(open(out / "prev-default-aa.png", "rb").read())
     assert max(img.shape[:2]) == 300 and np.array_equal(img, bs.render_rgb8(bs.prepare_scene(small["default-aa"], True), tree))
