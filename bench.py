@@ -357,10 +357,13 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
         rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
         outs = [rings[i % n_t][(i // n_t) % 4] for i in range(len(frame_objs))]
         call = F["call"]
-        # untimed warm-up = the same call once: the contexts' second stream, device images and blur scratch get created, every ring
-        # buffer is written once, and a one-off ~35 ms that the FIRST many-frame batch call of a process pays when no other timed work
-        # preceded it (measured: 5.96 ms per frame in the first 20-frame call, 4.10-4.11 in the next three; profiles/EXPERIMENTS.md) is spent
-        call(frame_objs, outs)
+        # untimed warm-up = the same call once, over at least WARM_PER_CONTEXT frames per context: the contexts' second stream, device images
+        # and blur scratch get created, every ring buffer is written once, a one-off ~35 ms that the FIRST many-frame batch call of a process
+        # pays when no other timed work preceded it (measured: 5.96 ms per frame in the first 20-frame call, 4.10-4.11 in the next three;
+        # profiles/EXPERIMENTS.md) is spent -- and every context MEASURES this frame shape once (csrc/batch.cpp: the partition trial, 8 + 3 x 8
+        # frames), so that the timed call runs with the context's remembered choice like any later call of a long-lived host would
+        n_warm = max(len(frame_objs), WARM_PER_CONTEXT * n_t)
+        call([frame_objs[i % len(frame_objs)] for i in range(n_warm)], [rings[i % n_t][(i // n_t) % 4] for i in range(n_warm)])
         if os.environ.get("BLACKSTAR_BENCH_D2H_REPS"):  # diagnostic: the same call several times, each timed (stderr)
             for rep in range(int(os.environ["BLACKSTAR_BENCH_D2H_REPS"])):
                 fence()
@@ -497,6 +500,7 @@ def digest_as_float(hexdigest):
     return float(int(hexdigest[:12], 16))
 
 
+WARM_PER_CONTEXT = 40   # frames per context of the delivered forms' untimed warm-up call (the partition trial needs 32)
 COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
 
 

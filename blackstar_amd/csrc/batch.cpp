@@ -18,6 +18,8 @@ using namespace bs;
 
 // (the bs_* entry points get C linkage from their declarations in include/blackstar_gpu.h)
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Frames first, first+step, ... on one context, double-buffered: while frame k's image is copied to the host (copy
 // stream), frame k+1's kernel already runs (compute stream).  Pageable host buffers: the copy itself is the runtime's
 // staged D2H (about 19 GB/s), but it no longer sits between two kernels.
@@ -197,7 +199,7 @@ struct PngSlots {
 // tiles leave (the fixed ~0.25 ms of a launch) and frame k's bloom runs on the CUs the next trace kernel frees
 // first.  The blur scratch is one pair per context: the bloom of frame k+1 is ordered behind frame k's by acquire/release_post.
 static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, const double *strengths, const int *dividers, unsigned char *const *outs,
-                                        int first, int n_frames, int step, const PngSink *png)
+                                        int first, int n_frames, int step, const PngSink *png, std::vector<double> *done_ms = nullptr)
 {
     if (first >= n_frames) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -222,6 +224,7 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
         const int b = k & 1;
         if (k >= 2) {
             HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
+            if (done_ms) done_ms->push_back(now_ms());       // (the partition trial: when each frame of the pipeline completed)
             if (png && (rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
         }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
@@ -256,16 +259,22 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 // chip's clocks -- rounds 2-3 measured 26 combinations (profiles/r03_post_partition_ab.txt, r03_partition_large_ab.jsonl,
 // r03_partition_more_ab.jsonl, r03_png_partition_ab.jsonl: C3 at 1080p 4.27 partitioned on 8 CUs / 4.67 ms shared, 720p wants 16, frames
 // without supersampling lose with any M, ...) and fitted a model with five constants to them.  Round 4 replaced the model with the
-// measurement itself: the first share of a context that holds at least kTrialFrames frames of ONE shape renders its first frames as a
-// TRIAL -- kTrialWarm frames on the shared chip (they also bring the clocks up: the first launches after an idle spell run up to 20 %
-// slow), then kTrialSegment frames each shared / with 8 / with 16 post-stage CUs, each segment a self-contained blocking pipeline timed
-// with the host clock -- and remembers the fastest for that shape (PartitionKey) for the life of the context.  Every trial frame is a
-// frame of the batch, delivered like any other (byte-identical whichever way it was made); what the trial costs is the difference
-// between the segments, a few per cent of twenty frames, once.  Shares that are too short, or mix shapes of which one has not been
-// measured, run on the shared chip (the safe side: a partition that is too small for its post stage costs 50-70 %, none costs <= 9 %).
+// measurement itself.  A share of frames of ONE shape that the context has not measured yet is rendered as a TRIAL: segments of
+// kTrialSegment frames, each a self-contained blocking pipeline -- shared chip, 8 post-stage CUs, 16 -- preceded, if the context's last
+// batch work ended more than a few milliseconds ago, by kTrialWarm frames on the shared chip (the first launches after an idle spell run
+// up to 20 % slow).  The segments need not fit one call: the context remembers how far it got (bs_ctx::trial), so 32 frames in one call
+// measure a shape, and so do three calls of 16 (bs_render_png_files' internal calls).  When all three are timed the fastest is remembered
+// for that shape (PartitionKey) for the life of the context.  What is timed is the segment's STEADY STATE: the host clock at the moments
+// the pipeline's own loop learns that frame k has left the device (it waits for frame k - depth before it enqueues frame k), first to
+// last, divided by the frames between.  The wall time of a short segment would not do: its fill and drain cost about one post stage on M
+// CUs -- a whole frame time -- and a first version that timed 4-frame segments end to end chose the shared chip for 16 of 26 shapes on
+// which a partition is 2-15 % faster (profiles/r04_partition_trial_ab_wall_time_v1.jsonl).  Every trial frame is a frame of the batch,
+// delivered like any other (byte-identical whichever way it was made); what the trial costs is the difference between the segments, a
+// few per cent of 32 frames, once.  Shares that are too short, or mix shapes of which one has not been measured, run on the shared chip
+// (the safe side: a partition that is too small for its post stage costs 50-70 %, none costs <= 9 %).
 // BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
-constexpr int kTrialWarm = 8, kTrialSegment = 4;
-static_assert(kTrialWarm + 3 * kTrialSegment == bs::kTrialFrames, "the trial's segments");
+constexpr int kTrialWarm = 8, kTrialSegment = 8;
+constexpr double kIdleMs = 5.0;   // a context whose last batch work ended longer ago than this starts its next trial segment with a warm-up
 static const int kTrialCus[3] = {0, 8, 16};
 
 int bs::pick_partition(const double *ms, const int *cus, int n)
@@ -323,7 +332,7 @@ static void plan_share(bs_ctx *ctx, const bs_config *cfgs, const double *strengt
     }
     if (!with_post) return;          // no bloom and no file anywhere: the post stage is one 30-us pixel map, nothing to set CUs aside for
     if (all_known) { *post_cus = std::max(widest, 0); return; }
-    if (one_shape && count >= bs::kTrialFrames) { *trial = true; *trial_key = k0; }
+    if (one_shape && count >= kTrialSegment) { *trial = true; *trial_key = k0; }
 }
 
 // The CU-masked streams of a partition (post stage on bits [0, post_cus), trace kernels on the rest), made once per context and M.
@@ -361,7 +370,7 @@ static bool ensure_partition(bs_ctx *ctx, int post_cus)
 // without a single bit gets ALL its CUs), so bits [0, post_cus) are post_cus / 8 CUs in every XCD (for 12, 20, 28: one more in the first
 // four XCDs -- the trace kernels' tile queue and the blur sweeps' plans balance themselves).  Three images in flight.
 static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_config *cfgs, const double *strengths, const int *dividers,
-                                          unsigned char *const *outs, int first, int n_frames, int step, const PngSink *png)
+                                          unsigned char *const *outs, int first, int n_frames, int step, const PngSink *png, std::vector<double> *done_ms = nullptr)
 {
     if (first >= n_frames) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -395,6 +404,7 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         hipStream_t ts = pt.trace[k & 1];
         if (k >= 3) {
             HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));  // frame k-3 (same image, same staging) has left the device
+            if (done_ms) done_ms->push_back(now_ms());
             if (png && (rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
         }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
@@ -452,21 +462,28 @@ static int run_share(bs_ctx *x, const bs_config *cfgs, int n_frames, const doubl
     }
     if (post_cus && !ensure_partition(x, post_cus)) post_cus = 0;
     x->last_trial = 0;
-    auto run = [&](int m, int a, int b) {  // frames a .. b-1 OF THE SHARE, with m post-stage CUs
+    auto run = [&](int m, int a, int b, std::vector<double> *done_ms = nullptr) {  // frames a .. b-1 OF THE SHARE, with m post-stage CUs
         const int first = c + a * step, bound = (int)std::min<long>(n_frames, (long)c + (long)b * step);
-        return m ? render_rgb8_frames_partitioned(x, m, cfgs, strengths, dividers, outs, first, bound, step, png)
-                 : render_rgb8_frames_pipelined(x, cfgs, strengths, dividers, outs, first, bound, step, png);
+        return m ? render_rgb8_frames_partitioned(x, m, cfgs, strengths, dividers, outs, first, bound, step, png, done_ms)
+                 : render_rgb8_frames_pipelined(x, cfgs, strengths, dividers, outs, first, bound, step, png, done_ms);
     };
     const int count = (n_frames - c + step - 1) / step;
+    struct Stamp {   // when this context's batch work last ended (whatever path the call took)
+        bs_ctx *x;
+        ~Stamp() { x->last_batch_end_ms = now_ms(); }
+    } stamp{x};
     if (!trial) {
         x->last_post_cus = post_cus;
         return run(post_cus, 0, count);
     }
-    // The trial (see "the CU partition: measured, not modelled" above).  A chip without CU-mask support measures nothing and stays shared.
-    bs_ctx::PartitionChoice ch{key, 0, {0, 0, 0}};
-    const bool masks = ensure_partition(x, kTrialCus[1]) && ensure_partition(x, kTrialCus[2]);
-    int done = 0;
-    if (masks) {
+    // The trial (see "the CU partition: measured, not modelled" above), possibly continued from an earlier call.
+    bs_ctx::Trial &T = x->trial;
+    if (!T.active || !(T.key == key)) T = bs_ctx::Trial{true, key, 0, {0, 0, 0}};
+    int done = 0, choice = 0;
+    bool decided = false;
+    if (!(ensure_partition(x, kTrialCus[1]) && ensure_partition(x, kTrialCus[2]))) {
+        decided = true;   // a chip without CU-mask support measures nothing and stays shared
+    } else {
         {   // every buffer either pipeline needs exists before anything is timed (the first segment would otherwise pay the allocations)
             size_t need = 0;
             if (int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, c, n_frames, step, &need)) return rc;
@@ -475,20 +492,32 @@ static int run_share(bs_ctx *x, const bs_config *cfgs, int n_frames, const doubl
                 return fail(BS_ENOMEM, "hipMalloc image failed");
             if (int rc = ensure_post(x, need)) return rc;
         }
-        if (int rc = run(0, 0, kTrialWarm)) return rc;
-        done = kTrialWarm;
-        for (int v = 0; v < 3; v++) {
-            const auto t0 = std::chrono::steady_clock::now();
-            if (int rc = run(kTrialCus[v], done, done + kTrialSegment)) return rc;
-            ch.ms[v] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / kTrialSegment;
-            done += kTrialSegment;
+        const bool cold = x->last_batch_end_ms == 0 || now_ms() - x->last_batch_end_ms > kIdleMs;
+        if (cold && count >= kTrialWarm + kTrialSegment) {
+            if (int rc = run(0, 0, kTrialWarm)) return rc;
+            done = kTrialWarm;
         }
-        ch.post_cus = pick_partition(ch.ms, kTrialCus, 3);
+        if (!cold || done) {   // (a cold context with too few frames to warm up AND measure: this call goes by on the shared chip)
+            while (T.stage < 3 && count - done >= kTrialSegment) {
+                std::vector<double> t;   // completion times of the segment's frames but the last two (shared) / three (partitioned)
+                if (int rc = run(kTrialCus[T.stage], done, done + kTrialSegment, &t)) return rc;
+                T.ms[T.stage] = t.size() >= 2 ? (t.back() - t.front()) / (double)(t.size() - 1) : 0.0;
+                done += kTrialSegment;
+                T.stage++;
+            }
+        }
+        if (T.stage == 3) {
+            decided = true;
+            choice = pick_partition(T.ms, kTrialCus, 3);
+        }
     }
-    x->partition_cache.push_back(ch);
-    x->last_trial = 1;
-    x->last_post_cus = ch.post_cus;
-    return done < count ? run(ch.post_cus, done, count) : BS_OK;
+    if (decided) {
+        x->partition_cache.push_back(bs_ctx::PartitionChoice{key, choice, {T.ms[0], T.ms[1], T.ms[2]}});
+        T.active = false;
+    }
+    x->last_trial = decided ? 1 : 2;
+    x->last_post_cus = decided ? choice : 0;
+    return done < count ? run(decided ? choice : 0, done, count) : BS_OK;
 }
 
 // bs_render_rgb8_batch / bs_render_png_batch: one host thread per context, frame i on context i % n_ctx.

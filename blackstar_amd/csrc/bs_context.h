@@ -87,8 +87,8 @@ struct bs_ctx {
     int launch_cus = 0;          // CUs the next trace launches may use (0 = n_cu): sizes the persistent grid
     int last_post_cus = -1;      // CUs the post stage owned in this context's share of the last batch call (0: shared chip; -1: none yet)
     int bloom_plan_cus = 0;      // probe only (env BLACKSTAR_BLOOM_PLAN_CUS): CU count bs_bloom_device plans its sweeps for (0 = n_cu)
-    // The partition decision is MEASURED, once per frame shape and context (batch.cpp: partition_trial): the first share of at least
-    // kTrialFrames frames of one shape runs its first frames shared / with 8 / with 16 post CUs, timed, and the fastest is remembered here.
+    // The partition decision is MEASURED, once per frame shape and context (batch.cpp: "measured, not modelled"): shares of one unmeasured
+    // shape run segments of 8 frames shared / with 8 / with 16 post CUs, their steady state timed, and the fastest is remembered here.
     struct PartitionKey {
         int32_t w, h, ss, divider, png, mode;  // divider 0 = no bloom
         bool operator==(const PartitionKey &o) const { return w == o.w && h == o.h && ss == o.ss && divider == o.divider && png == o.png && mode == o.mode; }
@@ -99,7 +99,14 @@ struct bs_ctx {
         double ms[3];           // per-frame wall time of the trial segments: shared, 8, 16 (0: not run)
     };
     std::vector<PartitionChoice> partition_cache;
-    int last_trial = 0;          // 1: the last batch call of this context ran a trial (test hook)
+    struct Trial {               // a trial in progress (its segments may span several batch calls)
+        bool active = false;
+        PartitionKey key{};
+        int stage = 0;           // segments timed so far: 0..3
+        double ms[3] = {0, 0, 0};
+    } trial;
+    double last_batch_end_ms = 0;  // host clock when this context's last rgb8 / png batch work ended (0: never): idle contexts warm up first
+    int last_trial = 0;          // the last batch call of this context: 0 no trial, 1 a trial ended in it (shape remembered), 2 a trial progressed (test hook)
     struct Partition {
         hipStream_t trace[2] = {nullptr, nullptr};  // CU mask: every CU but the post stage's
         hipStream_t post = nullptr;                 // CU mask: the post stage's CUs
@@ -199,7 +206,6 @@ uint64_t *png_bytes_slot(bs_ctx *ctx, int k);
 // The decision rule of the partition trial (host-only, pure): ms[i] = measured per-frame time with cus[i] post-stage CUs (cus[0] == 0:
 // the shared chip).  Returns the CU count of the fastest entry, the shared chip unless a partition beats it by more than kTrialMargin.
 int pick_partition(const double *ms, const int *cus, int n);
-constexpr double kTrialMargin = 0.015;  // (a segment of four frames resolves the per-frame time to about 1.5 %: pipeline fill and drain)
-constexpr int kTrialFrames = 20;   // frames of one shape a context's share must have before it is measured: 8 to warm up + 3 segments of 4
+constexpr double kTrialMargin = 0.015;  // (4-5 steady-state frame intervals per segment resolve the per-frame time to about 1 %)
 
 }  // namespace bs

@@ -159,7 +159,7 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
     p.star_intensity = c.star_intensity;
     p.star_saturation = c.star_saturation;
     p.star_a = std::log(2.0) / 50;  // StarMap.hs:108  a = log 2 / dynamic
-    // FAST mode's guard (trace_kernel.hip: trace_ray): a ray that needs more steps than the longest straight path through the
+    // FAST mode's guard (trace_device.h: trace_ray): a ray that needs more steps than the longest straight path through the
     // scene, N0 = (|camera| + sqrt safeDistance) / stepSize, plus one photon-sphere circumference (2 pi 1.5 ~ 9.4 -> 9.0 / stepSize
     // steps) has orbited the hole about once; every further orbit multiplies ANY rounding difference by e^(2 pi) ~ 535.  Measured
     // (scripts/fast_guard_probe.py, profiles/r02_fast_guard_probe.txt): FAST - STRICT grows 10x per 10 excess steps at h = 0.3, is

@@ -103,6 +103,13 @@ def alloc_png(startree: StarTree, height: int, width: int) -> np.ndarray:
     return alloc_image(startree, 1, png_bound(height, width), channels=1, dtype=np.uint8).reshape(-1)
 
 
+def _check_png_out(out: np.ndarray) -> None:
+    """A file buffer handed to C as (pointer, size): it must BE size contiguous bytes (a strided view such as buf[::2] advertises its
+    size but would be written contiguously, past the view)."""
+    if not isinstance(out, np.ndarray) or out.dtype != np.uint8 or out.ndim != 1 or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+        raise ValueError("out must be a flat, C-contiguous, writeable uint8 array (e.g. from alloc_png)")
+
+
 def encode_png(rgb8: np.ndarray, startree: StarTree, out: np.ndarray = None) -> memoryview:
     """The file writeImg writes (src/Raytracer.hs:30-32: massiv-io writeImage = a PNG encoder) for an (h, w, 3) uint8 image, made on
     the GPU (`bs_encode_png`): filter choice, deflate, checksums.  Returns the file's bytes (a view of `out` -- e.g. alloc_png(...) --
@@ -113,6 +120,8 @@ def encode_png(rgb8: np.ndarray, startree: StarTree, out: np.ndarray = None) -> 
     h, w, _ = rgb8.shape
     if out is None:
         out = np.empty(png_bound(h, w), np.uint8)
+    else:
+        _check_png_out(out)
     n = C.c_size_t()
     _lib.check(_lib.lib().bs_encode_png(startree.handle, rgb8.ctypes.data, w, h, out.ctypes.data, out.size, C.byref(n)), "bs_encode_png")
     return memoryview(out)[:n.value]
@@ -124,6 +133,8 @@ def render_png(cfg: Config, startree: StarTree, out: np.ndarray = None) -> memor
     c = _bs_config(cfg)
     if out is None:
         out = np.empty(png_bound(c.height, c.width), np.uint8)
+    else:
+        _check_png_out(out)
     n = C.c_size_t()
     _lib.check(_lib.lib().bs_render_png(startree.handle, C.byref(c), float(cfg.scene.bloomStrength), int(cfg.scene.bloomDivider),
                                         out.ctypes.data, out.size, C.byref(n)), "bs_render_png")

@@ -50,7 +50,8 @@ int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int h
 /* ---- the CU partition of bs_render_rgb8_batch / bs_render_png_batch (csrc/batch.cpp: measured once per frame shape and context) ---- */
 /* The CUs the post stage owned in this context's share of the last batch call (0 = the shared chip, -1 = no batch yet). */
 int bs_debug_last_post_cus(const bs_ctx *ctx);
-/* 1 if this context's share of the last batch call ran the trial (and so measured a shape), 0 if not. */
+/* This context's share of the last batch call: 0 no trial; 1 a trial ended in it (the shape is remembered now); 2 a trial progressed
+ * (segments timed, or waiting for a call long enough) without ending. */
 int bs_debug_last_trial(const bs_ctx *ctx);
 /* What the context has measured for frames of this shape (width, height, supersampling, bloom divider or none, pixels or PNG file, the
  * arithmetic the frame gets): the remembered post-stage CU count (0, 8, 16) and, in ms[3] (may be NULL), the per-frame times of the

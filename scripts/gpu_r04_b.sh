@@ -4,14 +4,14 @@
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04b
+O=$R/gpurun_out/${1:-r04b}
 mkdir -p $O
 (time python -c "import __graft_entry__ as g; g.smoke()") > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
 (time timeout 1500 python -m pytest tests -q -m gpu --durations=8 -rs) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --gpus 2 --steps 20 --cpu-seconds 0 --sustained-frames 100 2> $O/bench_n2.err | tail -n 1 > $O/bench_n2_single_process.json
-(time python scripts/fuzz_modes.py 20000 4242) 2> $O/fuzz.time > $O/fuzz_modes_20000.json
-(time timeout 1200 python scripts/partition_trial_ab.py 24) 2> $O/partition_ab.err > $O/partition_trial_ab.jsonl
+[ "${2:-fuzz}" = nofuzz ] || (time python scripts/fuzz_modes.py 20000 4242) 2> $O/fuzz.time > $O/fuzz_modes_20000.json
+(time timeout 1200 python scripts/partition_trial_ab.py 36) 2> $O/partition_ab.err > $O/partition_trial_ab.jsonl
 rocm-smi --showclocks 2>/dev/null | grep -i sclk | head -2 > $O/sclk.txt
 tail -n 3 $O/smoke.log; tail -n 25 $O/pytest_gpu.log
 for f in default n2_single_process; do

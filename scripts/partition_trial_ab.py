@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Does the MEASURED partition decision (csrc/batch.cpp: a trial of 8 + 3 x 4 frames per frame shape and context) pick what is fastest?
+"""Does the MEASURED partition decision (csrc/batch.cpp: a trial of 8 + 3 x 8 frames per frame shape and context) pick what is fastest?
 For each of the 26 combinations rounds 2-3 measured by hand (scripts/post_partition_ab.py, partition_large_ab.py, partition_more_ab.py, png_partition_ab.py; results: profiles/r03_post_partition_ab.txt,
 r03_partition_large_ab.jsonl, r03_partition_more_ab.jsonl, r03_png_partition_ab.jsonl): the steady-state time per frame with the post stage
 forced to 0 / 8 / 16 CUs (BLACKSTAR_POST_CUS, a context each, N frames per call, best of 3 calls), then a fresh context left to itself:
 its first N-frame call runs the trial (trial_ms = the three segment times, choice = what it remembered), later calls use the choice
 (auto = their best of 3).  regret_pct = auto / min(forced) - 1.  One JSON line per combination, a summary line last.
-Usage: partition_trial_ab.py [N_FRAMES=24] [quick]      (quick: every third combination)"""
+Usage: partition_trial_ab.py [N_FRAMES=36] [quick]      (quick: every third combination)"""
 import ctypes as C
 import json
 import os
@@ -18,7 +18,7 @@ import numpy as np  # noqa: E402
 import blackstar_amd as bs  # noqa: E402
 from blackstar_amd import _lib, synthetic  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 36
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 stars = bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_FULL))
 D = _lib.debug_lib()

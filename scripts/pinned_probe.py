@@ -1,5 +1,5 @@
 """What hipPointerGetAttributes / hipMemGetAddressRange report for the kinds of host memory a caller may hand to bs_render
-(diagnostic for csrc/bs_api.cpp:device_alias_of_pinned).  Run on the GPU box: python scripts/pinned_probe.py"""
+(diagnostic for csrc/context.cpp:device_alias_of_pinned).  Run on the GPU box: python scripts/pinned_probe.py"""
 import ctypes as C
 
 import numpy as np

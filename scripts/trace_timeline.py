@@ -68,7 +68,7 @@ for sid, n in zip(simd, tiles):
     per_simd_tiles[int(sid)] = per_simd_tiles.get(int(sid), 0) + int(n)
 pt = np.array(list(per_simd_tiles.values()))
 print(f"tiles per SIMD {pc(pt)}")
-slot = (np.arange(len(q)) // 4) // 256  # workgroup index / #CU: the residency slot (bs_api.cpp blocks_per_slot)
+slot = (np.arange(len(q)) // 4) // 256  # workgroup index / #CU: the residency slot (render.cpp: blocks_per_slot)
 for k in range(int(slot.max()) + 1):
     m = slot == k
     print(f"  slot {k}: {m.sum()} wavefronts, tiles per wave {pc(tiles[m])}, last tile end {pc(last[m])}")

@@ -106,7 +106,9 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     fences = []
     res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch", "png-batch", "png-files"], lambda: fences.append(1), lambda x: x)
     assert set(res) == {"batch", "rgb8_batch", "png_batch", "png_files"} and len(fences) == 8
-    assert [c[:3] for c in calls] == [("batch", 30, 3), ("batch", 30, 3), ("rgb8", 30, 3), ("rgb8", 30, 3), ("png", 30, 3), ("png", 30, 3),
+    W = bench.WARM_PER_CONTEXT * 3   # the warm-up call is long enough for every context to measure the frame shape (the partition trial)
+    assert W >= 32 * 3
+    assert [c[:3] for c in calls] == [("batch", W, 3), ("batch", 30, 3), ("rgb8", W, 3), ("rgb8", 30, 3), ("png", W, 3), ("png", 30, 3),
                                       ("files", 30, 3), ("files", 30, 3)]  # warm-up call, timed call
     assert res["png_files"]["bytes_written_per_frame"] == 77 and res["png_files"]["frames"] == 30 and res["png_files"]["entry_point"] == "bs_render_png_files"
     del calls[6:]

@@ -1572,8 +1572,9 @@ def test_rgb8_batch_on_a_partitioned_chip_is_byte_identical(post, catalogue_byte
 
 
 def test_rgb8_batch_partition_is_measured_at_full_size():
-    """The C3 frame itself.  Round 4: the partition is MEASURED (csrc/batch.cpp): the first batch call whose share holds 20 frames of one
-    shape runs the trial (8 frames shared, then 4 each shared / 8 / 16 post-stage CUs), remembers the fastest for that shape, and every
+    """The C3 frame itself.  Round 4: the partition is MEASURED (csrc/batch.cpp): frames of a shape the context has not measured are rendered
+    in segments of 8 (shared / 8 / 16 post-stage CUs, steady state timed; 8 more shared first on an idle context) -- 36 frames in one call
+    end the trial --, the context remembers the fastest for that shape, and every
     frame -- whichever way it was made -- is bs_render_rgb8's bytes.  Shorter calls before the trial stay on the shared chip; after it
     they use what was measured.  The remembered choice must be the trial's own fastest (1.5 % margin), and the steady state with it
     must not be slower than the shared chip."""
@@ -1594,12 +1595,12 @@ def test_rgb8_batch_partition_is_measured_at_full_size():
         if post == "auto":
             outs = [ring[i % 4] for i in range(8)]
             bs.render_rgb8_batch([cfg] * 8, [t], outs=outs)           # too short to measure, nothing remembered: the shared chip
-            assert D.bs_debug_last_post_cus(t.handle) == 0 and D.bs_debug_last_trial(t.handle) == 0
+            assert D.bs_debug_last_post_cus(t.handle) == 0 and D.bs_debug_last_trial(t.handle) == 2   # (8 frames on an idle context: not even a segment)
             assert D.bs_debug_partition_choice(t.handle, C.byref(c), cfg.scene.bloomStrength, cfg.scene.bloomDivider, 0, ms) == -1
-        outs = [ring[i % 4] for i in range(24)]
+        outs = [ring[i % 4] for i in range(36)]
         for o in ring:
             o[:] = 7
-        bs.render_rgb8_batch([cfg] * 24, [t], outs=outs)              # 24 frames of one shape: the trial (auto), 4 frames after it
+        bs.render_rgb8_batch([cfg] * 36, [t], outs=outs)              # 36 frames of one shape: the trial (auto), 4 frames after it
         assert all(np.array_equal(o, ref) for o in ring)
         if post == "auto":
             assert D.bs_debug_last_trial(t.handle) == 1
@@ -1615,11 +1616,29 @@ def test_rgb8_batch_partition_is_measured_at_full_size():
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
-            bs.render_rgb8_batch([cfg] * 24, [t], outs=outs)
-            best = min(best, (time.perf_counter() - t0) / 24 * 1e3)
+            bs.render_rgb8_batch([cfg] * 36, [t], outs=outs)
+            best = min(best, (time.perf_counter() - t0) / 36 * 1e3)
         assert D.bs_debug_last_trial(t.handle) == 0                   # measured once per shape and context
         assert all(np.array_equal(o, ref) for o in ring)
         times[post] = best
+        t.close()
+    # the segments need not fit one call: calls of 16 frames (bs_render_png_files' internal size) measure a shape too, and agree
+    t = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes()), device=0)
+    try:
+        ring = [bs.alloc_image(t, 1080, 1920, dtype=np.uint8) for _ in range(4)]
+        outs16 = [ring[i % 4] for i in range(16)]
+        states = []
+        for _ in range(5):
+            bs.render_rgb8_batch([cfg] * 16, [t], outs=outs16)
+            states.append(D.bs_debug_last_trial(t.handle))
+            if states[-1] == 1:
+                break
+        ms2 = (C.c_double * 3)()
+        choice2 = D.bs_debug_partition_choice(t.handle, C.byref(c), cfg.scene.bloomStrength, cfg.scene.bloomDivider, 0, ms2)
+        print(f"trial over calls of 16: states {states}, shared {ms2[0]:.3f}, 8 CUs {ms2[1]:.3f}, 16 CUs {ms2[2]:.3f} -> {choice2}")
+        assert states[-1] == 1 and all(s_ == 2 for s_ in states[:-1]) and 2 <= len(states) <= 4 and choice2 in (0, 8, 16) and all(m > 0 for m in ms2)
+        assert all(np.array_equal(o, ref) for o in ring)
+    finally:
         t.close()
     print(f"bs_render_rgb8_batch, C3: shared chip {times['0']:.3f} ms per frame, measured choice {times['auto']:.3f}")
     assert times["auto"] < times["0"] * 1.03  # (round 3 measured 4.3 against 4.7 ms; the bar guards against the measurement choosing badly)

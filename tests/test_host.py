@@ -238,9 +238,9 @@ def test_every_shipped_scene_and_animation_frame_validates():
 
 
 def test_partition_trial_decision_rule():
-    """Round 4: the CU partition of bs_render_rgb8_batch / bs_render_png_batch is decided by MEASUREMENT (csrc/batch.cpp: a trial of 8 + 3 x 4
+    """Round 4: the CU partition of bs_render_rgb8_batch / bs_render_png_batch is decided by MEASUREMENT (csrc/batch.cpp: a trial of 8 + 3 x 8
     frames per frame shape and context), not by a model.  Host-only: the rule that turns the trial's three per-frame times into the choice
-    -- the fastest, but a partition only if it beats the shared chip by more than 1.5 % (what four frames resolve).  The times below are
+    -- the fastest, but a partition only if it beats the shared chip by more than 1.5 % (what a segment of eight frames resolves).  The times below are
     rounds 2-3's measured A/B results (profiles/r03_post_partition_ab.txt, r03_partition_large_ab.jsonl, r03_png_partition_ab.jsonl)."""
     import ctypes as C
     D = _lib.debug_lib()
@@ -467,6 +467,18 @@ def test_batch_wrappers_check_their_arguments_before_the_library():
         bs.render_png_files([cfg.to_bs_config()], [fake_tree], ["a.png"])
     with pytest.raises(ValueError):
         bs.render_png_files([cfg], [], ["a.png"])
+    # single-frame PNG wrappers: `out` goes to C as (pointer, size), so it must be `size` contiguous writeable bytes
+    img = np.zeros((8, 16, 3), np.uint8)
+    big = np.zeros(4 * bs.png_bound(8, 16), np.uint8)
+    for bad in (big[::2], big.reshape(4, -1), big.astype(np.int8), np.zeros((2, 3)), memoryview(bytearray(10000))):
+        with pytest.raises(ValueError, match="flat, C-contiguous"):
+            bs.encode_png(img, fake_tree, out=bad)
+        with pytest.raises(ValueError, match="flat, C-contiguous"):
+            bs.render_png(cfg, fake_tree, out=bad)
+    ro = np.zeros(bs.png_bound(8, 16), np.uint8)
+    ro.setflags(write=False)
+    with pytest.raises(ValueError, match="writeable"):
+        bs.encode_png(img, fake_tree, out=ro)
     assert bs.png_bound(8, 16) == 8 * (3 * 16 + 1) + 47 + 33 + 17   # pixels + filter bytes + fixed chunks + one block's stored-header and chunk framing
 
 

@@ -307,7 +307,7 @@ def test_render_png_batch_equals_frame_by_frame(tree):
 @pytest.mark.gpu
 def test_render_png_batch_at_full_size(tree):
     """BASELINE's C3 frame (default-aa.yaml, 1920x1080, 4x supersampled) through bs_render_png_batch: every file is bs_render_png's, decodes
-    to bs_render_rgb8's pixels, whichever way the frame was made (the 24-frame calls run the partition trial: shared chip / 8 / 16 CUs for
+    to bs_render_rgb8's pixels, whichever way the frame was made (the 36-frame calls run the partition trial: shared chip / 8 / 16 CUs for
     bloom + sRGB8 + the encoder, measured separately for files and for pixels); the price of the file over the pixels
     (bs_render_rgb8_batch) stays below 8 %."""
     import io
@@ -323,7 +323,7 @@ def test_render_png_batch_at_full_size(tree):
     from blackstar_amd import synthetic
     full = bs.StarTree(bs.read_map(synthetic.ppm_catalogue_bytes(synthetic.N_FULL)))
     try:
-        n = 24
+        n = 36
         want_px = bs.render_rgb8(cfg, full)
         want = bytes(bs.render_png(cfg, full))
         assert np.array_equal(np.array(Image.open(io.BytesIO(want)).convert("RGB")), want_px)
