@@ -500,7 +500,7 @@ def digest_as_float(hexdigest):
     return float(int(hexdigest[:12], 16))
 
 
-WARM_PER_CONTEXT = 40   # frames per context of the delivered forms' untimed warm-up call (the partition trial needs 32)
+WARM_PER_CONTEXT = 48   # frames per context of the delivered forms' untimed warm-up call (the partition trial needs 32, 40 on small frames)
 COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
 
 

@@ -260,9 +260,9 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 // r03_partition_more_ab.jsonl, r03_png_partition_ab.jsonl: C3 at 1080p 4.27 partitioned on 8 CUs / 4.67 ms shared, 720p wants 16, frames
 // without supersampling lose with any M, ...) and fitted a model with five constants to them.  Round 4 replaced the model with the
 // measurement itself.  A share of frames of ONE shape that the context has not measured yet is rendered as a TRIAL: segments of
-// kTrialSegment frames, each a self-contained blocking pipeline -- shared chip, 8 post-stage CUs, 16 -- preceded, if the context's last
-// batch work ended more than a few milliseconds ago, by kTrialWarm frames on the shared chip (the first launches after an idle spell run
-// up to 20 % slow).  The segments need not fit one call: the context remembers how far it got (bs_ctx::trial), so 32 frames in one call
+// kTrialSegment frames, each a self-contained blocking pipeline -- shared chip, 16 post-stage CUs, 8 -- preceded, if the context's last
+// batch work ended more than a few milliseconds ago, by at least kTrialWarm frames and 30 ms on the shared chip (the first launches after
+// an idle spell run up to 20 % slow).  The segments need not fit one call: the context remembers how far it got (bs_ctx::trial), so 32 frames in one call
 // measure a shape, and so do three calls of 16 (bs_render_png_files' internal calls).  When all three are timed the fastest is remembered
 // for that shape (PartitionKey) for the life of the context.  What is timed is the segment's STEADY STATE: the host clock at the moments
 // the pipeline's own loop learns that frame k has left the device (it waits for frame k - depth before it enqueues frame k), first to
@@ -273,9 +273,16 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 // few per cent of 32 frames, once.  Shares that are too short, or mix shapes of which one has not been measured, run on the shared chip
 // (the safe side: a partition that is too small for its post stage costs 50-70 %, none costs <= 9 %).
 // BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
-constexpr int kTrialWarm = 8, kTrialSegment = 8;
-constexpr double kIdleMs = 5.0;   // a context whose last batch work ended longer ago than this starts its next trial segment with a warm-up
-static const int kTrialCus[3] = {0, 8, 16};
+// Order: shared, 16, 8 -- NOT ascending.  A partition that is too small for its post stage leaves the trace CUs idle half of the time, the
+// chip lowers its clocks, and the segment measured NEXT starts slow: with the order shared / 8 / 16 the 16-CU segment of every shape whose
+// 8-CU segment was starved read 5-13 % high and lost to the shared chip on 4 of 26 shapes (profiles/r04_partition_trial_ab_order_v2.jsonl).
+// 16 CUs are rarely starved; when they are (more than kStarved x the shared time) 8 can only be worse and is not run at all.
+constexpr int kTrialWarm = 8, kTrialSegment = 8, kTrialWarmMax = 64;
+constexpr double kIdleMs = 5.0;   // a context whose last batch work ended longer ago than this starts its next trial segment with a warm-up ...
+constexpr double kWarmMs = 30.0;  // ... of at least this long (and kTrialWarm frames): the clocks need ~35 ms of work to come back from idle
+constexpr double kStarved = 1.25;
+static const int kTrialCus[3] = {0, 8, 16};   // (index into PartitionChoice::ms)
+static const int kTrialOrder[3] = {0, 2, 1};  // stage -> index into kTrialCus
 
 int bs::pick_partition(const double *ms, const int *cus, int n)
 {
@@ -493,17 +500,22 @@ static int run_share(bs_ctx *x, const bs_config *cfgs, int n_frames, const doubl
             if (int rc = ensure_post(x, need)) return rc;
         }
         const bool cold = x->last_batch_end_ms == 0 || now_ms() - x->last_batch_end_ms > kIdleMs;
-        if (cold && count >= kTrialWarm + kTrialSegment) {
-            if (int rc = run(0, 0, kTrialWarm)) return rc;
-            done = kTrialWarm;
+        if (cold) {   // shared-chip frames until the clocks are back: at least kTrialWarm frames and kWarmMs, while a segment still fits behind them
+            const double t0 = now_ms();
+            while (count - done >= kTrialWarm + kTrialSegment && done < kTrialWarmMax && (done == 0 || now_ms() - t0 < kWarmMs)) {
+                if (int rc = run(0, done, done + kTrialWarm)) return rc;
+                done += kTrialWarm;
+            }
         }
         if (!cold || done) {   // (a cold context with too few frames to warm up AND measure: this call goes by on the shared chip)
             while (T.stage < 3 && count - done >= kTrialSegment) {
+                const int v = kTrialOrder[T.stage];
                 std::vector<double> t;   // completion times of the segment's frames but the last two (shared) / three (partitioned)
-                if (int rc = run(kTrialCus[T.stage], done, done + kTrialSegment, &t)) return rc;
-                T.ms[T.stage] = t.size() >= 2 ? (t.back() - t.front()) / (double)(t.size() - 1) : 0.0;
+                if (int rc = run(kTrialCus[v], done, done + kTrialSegment, &t)) return rc;
+                T.ms[v] = t.size() >= 2 ? (t.back() - t.front()) / (double)(t.size() - 1) : 0.0;
                 done += kTrialSegment;
                 T.stage++;
+                if (T.stage == 2 && T.ms[0] > 0 && T.ms[2] > kStarved * T.ms[0]) T.stage = 3;   // 16 CUs starved: 8 is not worth a segment
             }
         }
         if (T.stage == 3) {

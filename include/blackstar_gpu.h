@@ -203,7 +203,7 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
  * kernels run on streams whose CU mask leaves 8 or 16 CUs out, bloom + sRGB8 of the previous frames run on a stream that owns exactly
  * those, three frames in flight (the default-aa frame: 4.28 instead of 4.67 ms; 3840x2160: 17.4 instead of 17.8).  The decision is a
  * measurement, taken once per frame shape (size, supersampling, bloom divider, arithmetic) and context: a share of frames of one shape
- * the context has not measured yet is rendered in segments of 8 frames -- shared chip, 8, 16 post-stage CUs; 8 more on the shared chip
+ * the context has not measured yet is rendered in segments of 8 frames -- shared chip, 16, 8 post-stage CUs; 8 more on the shared chip
  * first if the context has been idle -- each segment's steady state is timed, and once all three are (32 frames in one call, or e.g. three
  * calls of 16) the context remembers the fastest (a partition only if it wins by more than 1.5 %).  Shares of fewer than 8 frames or of
  * mixed shapes use what has been remembered, else the shared chip.  Only when every outs[i] is page-locked.  Environment BLACKSTAR_POST_CUS = 0 (never) | 8 |

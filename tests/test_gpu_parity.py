@@ -1573,7 +1573,7 @@ def test_rgb8_batch_on_a_partitioned_chip_is_byte_identical(post, catalogue_byte
 
 def test_rgb8_batch_partition_is_measured_at_full_size():
     """The C3 frame itself.  Round 4: the partition is MEASURED (csrc/batch.cpp): frames of a shape the context has not measured are rendered
-    in segments of 8 (shared / 8 / 16 post-stage CUs, steady state timed; 8 more shared first on an idle context) -- 36 frames in one call
+    in segments of 8 (shared / 16 / 8 post-stage CUs, steady state timed; 8 more shared first on an idle context) -- 36 frames in one call
     end the trial --, the context remembers the fastest for that shape, and every
     frame -- whichever way it was made -- is bs_render_rgb8's bytes.  Shorter calls before the trial stay on the shared chip; after it
     they use what was measured.  The remembered choice must be the trial's own fastest (1.5 % margin), and the steady state with it
@@ -1605,7 +1605,7 @@ def test_rgb8_batch_partition_is_measured_at_full_size():
         if post == "auto":
             assert D.bs_debug_last_trial(t.handle) == 1
             choice = D.bs_debug_partition_choice(t.handle, C.byref(c), cfg.scene.bloomStrength, cfg.scene.bloomDivider, 0, ms)
-            assert choice in (0, 8, 16) and D.bs_debug_last_post_cus(t.handle) == choice and all(m > 0 for m in ms)
+            assert choice in (0, 8, 16) and D.bs_debug_last_post_cus(t.handle) == choice and ms[0] > 0 and ms[2] > 0   # (ms[1] = 0: 8 CUs not run because 16 were starved)
             assert choice == D.bs_debug_pick_partition(ms, (C.c_int * 3)(0, 8, 16), 3)
             print(f"trial, C3: shared {ms[0]:.3f}, 8 CUs {ms[1]:.3f}, 16 CUs {ms[2]:.3f} ms per frame -> {choice}")
             assert D.bs_debug_partition_choice(t.handle, C.byref(c), cfg.scene.bloomStrength, cfg.scene.bloomDivider, 1, None) == -1   # files: another shape
@@ -1636,7 +1636,7 @@ def test_rgb8_batch_partition_is_measured_at_full_size():
         ms2 = (C.c_double * 3)()
         choice2 = D.bs_debug_partition_choice(t.handle, C.byref(c), cfg.scene.bloomStrength, cfg.scene.bloomDivider, 0, ms2)
         print(f"trial over calls of 16: states {states}, shared {ms2[0]:.3f}, 8 CUs {ms2[1]:.3f}, 16 CUs {ms2[2]:.3f} -> {choice2}")
-        assert states[-1] == 1 and all(s_ == 2 for s_ in states[:-1]) and 2 <= len(states) <= 4 and choice2 in (0, 8, 16) and all(m > 0 for m in ms2)
+        assert states[-1] == 1 and all(s_ == 2 for s_ in states[:-1]) and 2 <= len(states) <= 4 and choice2 in (0, 8, 16) and ms2[0] > 0 and ms2[2] > 0
         assert all(np.array_equal(o, ref) for o in ring)
     finally:
         t.close()
