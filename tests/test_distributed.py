@@ -146,3 +146,102 @@ def test_two_process_row_sharding_of_one_frame(height):
     assert shape == (height, 5, 3) and rows == [float(y) for y in range(height)]  # bands re-assembled in row order, padding trimmed
     split = shard_rows(height, 0, 2)[1]
     assert tagged == [y + (0.001 if y >= split else 0.0) for y in range(height)]  # each row from the rank that owns it
+
+
+def _bench_validation_worker(rank, world, port, poison_rank, q):
+    """bench.py's untimed validation as two real processes over gloo: the objects all-gather of the validation block, the float collective
+    of the delivered forms' frames_identical, the per-rank split leg.  poison_rank renders a frame that differs in one value."""
+    import numpy as np
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import blackstar_amd as real
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = 2160, 3840
+    bad = rank == poison_rank
+
+    def frame(r0, r1):
+        a = np.broadcast_to(np.arange(r0, r1, dtype=np.float64)[:, None, None], (r1 - r0, W, 3)).copy()
+        if bad:
+            a[-1, -1, -1] += 1.0
+        return a
+
+    class Tree:
+        def stats(self):
+            return {"rays": 4 * H * W, "steps": 1000 + (1 if bad else 0), "wave_iters": 10, "kernel_ms": 19.0}
+
+    class Bs:
+        Config = real.Config
+
+        @staticmethod
+        def alloc_image(tree, h, w, dtype=np.float64):
+            return np.zeros((h, w, 3), dtype)
+
+        @staticmethod
+        def render(cfg, tree, out=None):
+            out[:] = frame(0, H)
+            return out
+
+        @staticmethod
+        def render_rows(cfg, tree, row0, row1, out=None):
+            out[:] = frame(row0, row1)
+            return out
+
+        @staticmethod
+        def render_batch(cfgs, trees, outs=None):
+            for o in outs:
+                o[:] = 7 + (1 if bad else 0)
+            return outs
+
+    def all_ranks(x):
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return [float(g.item()) for g in got]
+
+    def gather_objs(o):
+        objs = [None] * world
+        dist.all_gather_object(objs, o)
+        return objs
+
+    split = bench.split_leg(Bs, np, [Tree()], rank, world, dist.barrier, lambda x: max(all_ranks(x)), gather_objs, reps=1)
+    forms = bench.d2h_forms(Bs, np, [Tree()], ["same"] * 6, 16, 8, world, ["batch"], dist.barrier, lambda x: max(all_ranks(x)), same_frames=True, all_ranks=all_ranks)
+    digest = bench.frame_digest(np, frame(0, 4))
+    val = bench.validation_block(gather_objs((digest, {k: (1000 + (1 if bad else 0) if k == "steps" else 5) for k in bench.COUNTERS})), "frame")
+    dist.barrier()
+    q.put((rank, split["identical_to_one_device"], split["bands"], split["parts"], forms["batch"]["frames_identical"], val["valid"],
+           val["frames_identical_across_devices"], val["steps_per_device"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("poison_rank", [-1, 1])
+def test_two_process_bench_validation_tells_a_wrong_frame_on_one_rank(poison_rank):
+    """VERDICT r3 item 1b as real processes: with both ranks right every check says so on every rank; with rank 1 wrong in ONE value of its
+    frames every rank -- rank 0 too, which prints the line -- learns it: split not identical, delivered frames not identical, validation
+    invalid with the per-rank step counters.  No rank hangs in a collective the other one skipped."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_validation_worker, args=(r, 2, port, poison_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        got = q.get(timeout=180)
+        res[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ok = poison_rank < 0
+    for r in (0, 1):
+        split_ok, bands, parts, forms_ok, valid, frames_same, steps = res[r]
+        assert bands == [[0, 1080], [1080, 2160]] and parts == 2
+        assert split_ok is ok and forms_ok is ok and valid is ok and frames_same is ok, (r, res[r])
+        assert steps == ([1000, 1000] if ok else [1000, 1001])

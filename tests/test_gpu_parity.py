@@ -399,6 +399,67 @@ def test_render_rgb8_pipeline(tree, oracle, tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png")), got)
 
 
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("shape", [(1, 1, False), (1, 1, True), (1, 7, True), (9, 1, False), (9, 1, True), (3, 5, False), (17, 9, True), (8, 8, True), (64, 1, True)])
+def test_degenerate_frame_shapes(shape, mode, tree, oracle, oracle_index):
+    """Frames smaller than one 8x8 tile, one pixel wide or high, with and without the 2x2 supersample (a quad of lanes per output pixel):
+    every lane outside the image must stay out of the pixels AND out of the statistics."""
+    w, h, ss = shape
+    cfg = scenes.with_res(scenes.DEFAULT_AA, w, h, ss=ss)
+    ref, ost = oracle.render(cfg, oracle_index, threads=0)
+    tree.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+    try:
+        img = bs.render(cfg, tree)
+        st = tree.stats()
+        rows = np.concatenate([bs.render_rows(cfg, tree, y, y + 1) for y in range(h)])   # one band per output row
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    assert img.shape == (h, w, 3) and st["rays"] == ost["rays"] == w * h * (4 if ss else 1)
+    assert st["steps"] == ost["steps"] and st["horizon"] + st["escaped"] + st["capped"] == st["rays"] and st["star_hits"] == ost["star_hits"]
+    rt, at = (RTOL_STRICT, ATOL_STRICT) if mode == "strict" else (RTOL_FAST, ATOL_FAST)
+    assert (np.abs(img - ref) <= at + rt * np.abs(ref)).all()
+    assert np.array_equal(rows, img)
+
+
+@pytest.mark.timeout(600, method="thread")
+def test_maximum_size_frame_2_pow_28_pixels(tree):
+    """The largest frame the ABI accepts (host_math.cpp: width x height <= 2^28), supersampled: 2^30 rays, 16.7 M tiles, a 6.4 GB image in
+    HBM.  No oracle at this size; what must hold: every ray accounted for, row bands rendered on their own (first rows, a middle band
+    that straddles nothing special, the last rows) bit-identical to the frame's rows -- the 64-bit image offsets --, and pixels at the
+    corners and the centre equal to the quad average of their four rays' records."""
+    import torch
+    W = H = 16384
+    cfg = scenes.with_res(scenes.DEFAULT_AA, W, H)
+    assert _lib.lib().bs_validate_config(C.byref(_lib.make_config(cfg))) == 0
+    tree.set_mode(_lib.BS_MODE_FAST)
+    try:
+        out = torch.empty((H, W, 3), dtype=torch.float64, device="cuda:0")
+        out.fill_(-1.0)
+        s = torch.cuda.current_stream()
+        bs.render_device(cfg, tree, out.data_ptr(), out.numel(), s.cuda_stream)
+        torch.cuda.synchronize()
+        st = tree.stats()
+        assert st["rays"] == 1 << 30 and st["capped"] == 0 and st["horizon"] + st["escaped"] == 1 << 30
+        assert st["steps"] > 200 * (1 << 30) and st["steps"] < 300 * (1 << 30) and st["steps"] > 1 << 37
+        assert bool((out >= 0).all())                                     # every pixel written (the fill value is gone), none negative
+        print(f"2^28-pixel frame: {st['kernel_ms']:.0f} ms, {st['steps'] / st['rays']:.1f} steps per ray, {W * H / st['kernel_ms'] / 1e3:.0f} Mpixel/s")
+        band = torch.empty((8, W, 3), dtype=torch.float64, device="cuda:0")
+        for r0 in (0, 8191, H - 8):
+            bs.render_rows_device(cfg, tree, r0, r0 + 8, band.data_ptr(), band.numel(), s.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(band, out[r0:r0 + 8]), r0
+        for y, x in ((0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (H // 2, W // 2), (12345, 6789)):
+            rec = bs.trace_rays(cfg, tree, [2 * y, 2 * y + 1, 2 * y, 2 * y + 1], [2 * x, 2 * x, 2 * x + 1, 2 * x + 1])   # the order of ImageFilters.hs:94-96
+            want = 0.25 * (((rec["rgba"][0, :3] + rec["rgba"][1, :3]) + rec["rgba"][2, :3]) + rec["rgba"][3, :3])
+            assert np.array_equal(out[y, x].cpu().numpy(), want), (y, x)
+        del out, band
+        torch.cuda.empty_cache()
+    finally:
+        tree.set_mode(_lib.BS_MODE_STRICT)
+    over = _lib.make_config(scenes.with_res(scenes.DEFAULT_AA, W + 1, H))
+    assert _lib.lib().bs_validate_config(C.byref(over)) == -1 and b"too large" in _lib.lib().bs_last_error()
+
+
 EDGE_CASES = {
     "camera_in_disk_plane_radial_centre_ray": dict(cam_pos=(0.0, 0.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 1.0, 0.0)),
     "camera_inside_horizon": dict(cam_pos=(0.0, 0.5, 0.3)),
