@@ -234,6 +234,11 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
         good = ok(hipEventCreate(&sl.ev0), "hipEventCreate") && ok(hipEventCreate(&sl.ev1), "hipEventCreate") &&
                ok(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming), "hipEventCreate");
     }
+    // The uploads above are hipMemcpy from PAGEABLE host memory on the NULL stream; every kernel of this context runs on NON-BLOCKING
+    // streams, which do not order themselves behind the NULL stream.  A blocking copy may return once the pageable source has been
+    // staged (the documented behaviour of the API family), so the context is only handed out when the device has really finished:
+    // a first kernel that read a half-uploaded cell_start would index the star grid out of bounds (a GPU fault ends the process).
+    if (good) good = ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
     if (!good) {
         const std::string keep = bs::error_message();
         bs_destroy(ctx);

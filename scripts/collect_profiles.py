@@ -75,3 +75,21 @@ for src, dst in (("bloom_ab_final.txt", "bloom_ab.txt"), ("sweep_probe_final.txt
                  ("bench_c5_animation.json", "bench_c5_animation.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{R}_{dst}"))
+
+# ---- round 4: the bench lines of scripts/gpu_r04_final.sh, the partition trial A/B (one file per box), the fuzz re-run ----
+import glob  # noqa: E402
+for fn in sorted(glob.glob(os.path.join(G, "bench_*.json"))):
+    dst = os.path.join(P, f"{R}_{os.path.basename(fn)}")
+    if os.path.getsize(fn) > 2 and not os.path.exists(dst):
+        shutil.copy(fn, dst)
+for src, dst in (("fuzz_modes_20000.json", "fuzz_modes_20000.json"),):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, f"{R}_{dst}"))
+ab = os.path.join(G, "partition_trial_ab.jsonl")
+if os.path.exists(ab):
+    last = open(ab).read().strip().splitlines()[-1]
+    try:
+        host = json.loads(last).get("hostname", "box")
+    except ValueError:
+        host = "box"
+    shutil.copy(ab, os.path.join(P, f"{R}_partition_trial_ab_{host[-8:]}.jsonl"))
