@@ -29,7 +29,70 @@ anim.nFrames = 600
 frames = bs.generate_frames(anim)
 t_end = time.time() + seconds
 rounds = checked = 0
+D = _lib.debug_lib()
+trials = {"ended": 0, "progressed": 0, "choices": {}}
+
+
+def same_shape_round():
+    """Round 4: batches of ONE shape, 8 .. 40 frames of different cameras, all outputs page-locked -- what the partition trial needs
+    (csrc/batch.cpp).  A shape is kept for a few calls so that trials are continued over calls, end, and later calls run with the remembered
+    choice; whichever pipeline made a frame (shared / 8 / 16 post-stage CUs, warm-up or timed segment), its bytes are the blocking call's.
+    Right before some batches an enqueue-only bs_encode_png_device is left in flight on a caller's stream (its scratch must be
+    its own)."""
+    global checked
+    w, h = int(rng.integers(40, 160)) * 2, int(rng.integers(30, 90)) * 2
+    ss = bool(rng.random() < 0.7)
+    strength = 0.0 if rng.random() < 0.2 else float(rng.uniform(0.05, 0.5))
+    divider = int(rng.integers(5, 30))
+    png = bool(rng.random() < 0.5)
+    use = trees if rng.random() < 0.4 else trees[:1]
+    for _call in range(int(rng.integers(1, 5))):
+        n = int(rng.integers(8, 41)) * len(use)
+        cfgs = []
+        for _ in range(n):
+            c = copy.deepcopy(frames[int(rng.integers(0, 600))])
+            c.scene.resolution, c.scene.supersampling, c.scene.bloomStrength, c.scene.bloomDivider = (w, h), ss, strength, divider
+            cfgs.append(c)
+        idx = sorted(int(i) for i in rng.choice(n, size=min(n, 6), replace=False))   # reference renders for a few frames of the call, at random positions
+        want8 = {i: bs.render_rgb8(cfgs[i], trees[0]).copy() for i in idx}
+        pending = None
+        if rng.random() < 0.5:   # an enqueue-only encode on a caller's stream, not waited for before the batch starts
+            src = want8[idx[0]]
+            st = torch.cuda.Stream()
+            d8 = torch.from_numpy(src).cuda()
+            dp = torch.zeros(bs.png_bound(*src.shape[:2]), dtype=torch.uint8, device="cuda:0")
+            dn = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+            st.wait_stream(torch.cuda.current_stream())
+            _lib.check(_lib.lib().bs_encode_png_device(trees[0].handle, d8.data_ptr(), src.shape[1], src.shape[0], dp.data_ptr(), dp.numel(), dn.data_ptr(),
+                                                       C.c_void_p(st.cuda_stream)), "png on a stream")
+            pending = (src, d8, dp, dn)
+        if png:
+            outs = [bs.alloc_png(use[i % len(use)], h, w) for i in range(n)]
+            got = bs.render_png_batch(cfgs, use, outs=outs)
+            for i in idx:
+                assert bytes(got[i]) == bytes(bs.encode_png(want8[i], trees[0])), f"same-shape round: png frame {i} of {n} differs ({w}x{h})"
+        else:
+            outs = [bs.alloc_image(use[i % len(use)], h, w, dtype=np.uint8) for i in range(n)]
+            got = bs.render_rgb8_batch(cfgs, use, outs=outs)
+            for i in idx:
+                assert np.array_equal(got[i], want8[i]), f"same-shape round: rgb8 frame {i} of {n} differs ({w}x{h})"
+        if pending is not None:
+            torch.cuda.synchronize()
+            src, d8, dp, dn = pending
+            assert bytes(dp[:int(dn[0].item())].cpu().numpy()) == bytes(bs.encode_png(src, trees[0])), "enqueue-only png raced with the batch"
+        for t in use:
+            state = D.bs_debug_last_trial(t.handle)
+            trials["ended"] += state == 1
+            trials["progressed"] += state == 2
+            if state == 1:
+                k = str(D.bs_debug_last_post_cus(t.handle))
+                trials["choices"][k] = trials["choices"].get(k, 0) + 1
+        checked += len(idx)
+
+
 while time.time() < t_end:
+    if rounds % 4 == 3:
+        same_shape_round()
     n = int(rng.integers(1, 9))
     cfgs = []
     for _ in range(n):
@@ -86,4 +149,5 @@ while time.time() < t_end:
         assert np.array_equal(d.cpu().numpy(), ref), f"round {rounds}: multi-stream frame {i} differs"
     rounds += 1
     checked += 5 * n
-print(f"soak: {rounds} rounds, {checked} frames compared, all identical, {seconds:.0f} s")
+print(f"soak: {rounds} rounds, {checked} frames compared, all identical, {seconds:.0f} s; partition trials ended {trials['ended']}, "
+      f"continued over calls {trials['progressed']}, choices {trials['choices']}")
