@@ -1,0 +1,672 @@
+"""bench_legs.py -- what bench.py measures BESIDE its headline value, and how the result line is put together: the workloads table, the
+delivered forms (with_d2h), the split leg, per_config, validation, sustained, boundary, roofline / PMC traffic, the device sampler
+(the cpu_baseline leg -- the only place the oracle is touched -- stays in bench.py).  bench.py (the driver's contract: CLI, the timed region, one JSON line) imports everything from here; tests reach the same names
+through `bench.`.  Nothing here is product code."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "d2h_forms", "png_files_leg", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "COUNTERS", "validation_block", "per_config_block", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "split_headline", "result_line"]
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_STEP = 145  # 130 (rk4, src/Raytracer.hs:113-134) + 15 (findColor where-bindings, :100-102)
+PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X FP64 vector, FMA = 2 flop (= 1/2 of the guide's 157.3 TF FP32 vector peak)
+PEAK_HBM_GBS = 8000.0
+# VALU instructions the stepping loop issues per RK4 step of a wavefront (ISA count, scripts/isa_hot_blocks.py; static):
+# full-rate f64 ops and quarter-rate transcendental seeds (v_rsq_f64 / v_rcp_f64 occupy the pipe for 4 issue slots).
+LOOP_VALU = {"fast": {"full_rate": 62, "quarter_rate": 4}, "strict": {"full_rate": 178, "quarter_rate": 8}}
+WORKLOAD_C3 = ("scenes/default-aa.yaml 1920x1080, 4x supersample (8,294,400 rays/frame), {cat}, "
+               "direction-grid star lookup (BASELINE configs[2])")
+WORKLOAD_C5 = ("animations/default-ani.yaml, nFrames=600, 1920x1080, 4x supersample, {cat}, "
+               "frame i on rank i % N (BASELINE configs[4]); roofline figures refer to the LAST frame rendered")
+# The single-frame BASELINE configs that fit one GPU: scene file, resolution override, whether the star map is part of the config.
+WORKLOADS = {
+    "default-aa": {"scene": "default-aa.yaml", "resolution": None, "stars": True, "baseline": "configs[2]", "label": WORKLOAD_C3,
+                   "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml"},
+    "default": {"scene": "default.yaml", "resolution": None, "stars": False, "baseline": "configs[1]",
+                "label": "scenes/default.yaml 1920x1080, no supersampling (2,073,600 rays/frame), NO star map: disk + horizon only (BASELINE configs[1])",
+                "metric": "Mpixel/s (geodesic rays/s) on default.yaml, no star map"},
+    "lensing-4k": {"scene": "lensing-disk.yaml", "resolution": (3840, 2160), "stars": True, "baseline": "configs[3]",
+                   "label": "scenes/lensing-disk.yaml at 3840x2160, 4x supersample (33,177,600 rays/frame), {cat}, direction-grid star lookup "
+                            "(BASELINE configs[3]: close-orbit long geodesics)",
+                   "metric": "Mpixel/s (geodesic rays/s) on lensing-disk.yaml at 3840x2160"},
+    "animation": {"label": WORKLOAD_C5, "baseline": "configs[4]", "stars": True, "metric": "Mpixel/s (geodesic rays/s) on default-aa.yaml"},
+}
+
+
+def workload_config(bs, name):
+    """The Config of a single-frame workload: the scene file as the reference ships it, with BASELINE's resolution override."""
+    w = WORKLOADS[name]
+    cfg = bs.Config.from_file(os.path.join(ROOT, "scenes", w["scene"]))
+    return cfg.with_resolution(*w["resolution"]) if w["resolution"] else cfg
+CATALOGUES = {"synthetic": "470k-star synthetic PPM-layout catalogue (uniform sky, SURVEY 8d recipe)",
+              "clustered": "686k-star NON-uniform synthetic PPM-layout catalogue (the 470k uniform stars + 3000 clusters of 6..40 stars "
+                           "inside 0.001 rad + a band at 10x the mean density; blackstar_amd/synthetic.py)"}
+
+
+def catalogue_note(args, n_stars):
+    return CATALOGUES.get(args.catalogue, f"REAL catalogue file {os.path.basename(args.catalogue)} ({n_stars} stars; not the BASELINE input: reported separately)")
+
+
+class DeviceSampler:
+    """Mean shader clock and package power of the given devices while a leg runs: amdgpu's hwmon files (freq1_input = sclk in Hz,
+    power1_input / power1_average = package power in uW), matched to HIP devices by PCI bus number, read by one thread at ~25 Hz.
+    The box's sysfs lists every GPU of the host, other tenants' included: a device whose bus cannot be matched is not reported."""
+
+    def __init__(self, pci_bus_ids, sysfs="/sys/class/drm"):
+        import glob
+        found = {}
+        for hw in glob.glob(os.path.join(sysfs, "card[0-9]*/device/hwmon/hwmon*")):
+            try:
+                bus = int(os.path.basename(os.path.realpath(os.path.join(hw, "..", ".."))).split(":")[1], 16)
+            except (IndexError, ValueError):
+                continue
+            files = {}
+            if os.path.exists(os.path.join(hw, "freq1_input")):
+                files["sclk_Hz"] = os.path.join(hw, "freq1_input")
+            for f in ("power1_input", "power1_average"):
+                if os.path.exists(os.path.join(hw, f)):
+                    files["power_uW"] = os.path.join(hw, f)
+                    break
+            if files:
+                found[bus] = files
+        self.cards = [(b, found[b]) for b in dict.fromkeys(pci_bus_ids) if b in found]
+        self.samples = [{k: [] for k in files} for _, files in self.cards]
+        self._stop = self._t = None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                for (_, files), acc in zip(self.cards, self.samples):
+                    for k, fn in files.items():
+                        try:
+                            with open(fn) as f:
+                                acc[k].append(float(f.read().split()[0]))
+                        except (OSError, ValueError, IndexError):
+                            pass
+                self._stop.wait(0.04)
+        if self.cards:
+            self._t = threading.Thread(target=loop, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._t:
+            self._t.join()
+
+    def summary(self):
+        out = []
+        for (bus, _), acc in zip(self.cards, self.samples):
+            d = {"pci_bus": f"{bus:02x}", "samples": max((len(v) for v in acc.values()), default=0)}
+            if acc.get("sclk_Hz"):
+                d["sclk_MHz_mean"] = sum(acc["sclk_Hz"]) / len(acc["sclk_Hz"]) / 1e6
+                d["sclk_MHz_min"] = min(acc["sclk_Hz"]) / 1e6
+            if acc.get("power_uW"):
+                d["power_W_mean"] = sum(acc["power_uW"]) / len(acc["power_uW"]) / 1e6
+                d["power_W_max"] = max(acc["power_uW"]) / 1e6
+            out.append(d)
+        return out or None
+
+
+def pci_bus_of(torch, d):
+    try:
+        return int(torch.cuda.get_device_properties(d).pci_bus_id)
+    except (AttributeError, RuntimeError, ValueError):
+        return None
+
+
+def pmc_traffic(mode):
+    """HBM bytes per launch of the trace kernel from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950 -- an upper
+    bound here, since that calibration is for wide coalesced reads and this kernel's reads are 32-byte star-grid entries).
+    A static figure: counters cannot be collected from inside an un-profiled run."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(fn)).get(mode, {})
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.basename(fn)
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
+def pmc_traffic_live(mode, catalogue, timeout_s=60):
+    """HBM bytes per launch of the trace kernel MEASURED NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- separate
+    runs, as MI355X_MICROARCH.md's HBM section prescribes) over scripts/prof_frame.py, which renders the same frame three times
+    through the C ABI in a child process.  Counters cannot be read from inside an un-profiled process, hence the children; timing is
+    never taken from them.  Returns (bytes, detail) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    work = tempfile.mkdtemp(prefix="bs_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--",
+                   sys.executable, os.path.join(ROOT, "scripts", "prof_frame.py"), "--mode", mode, "--stars", catalogue, "--frames", "3"]
+            try:
+                r = subprocess.run(cmd, cwd=work, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
+            vals = []
+            for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(fn) as f:
+                    vals += [float(row["Counter_Value"]) for row in csv.DictReader(f)
+                             if row.get("Counter_Name") == counter and "trace_frame" in row.get("Kernel_Name", "")]
+            if r.returncode != 0 or not vals:
+                return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(vals)} samples"
+            got[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    # KiB units; FETCH_SIZE doubled: the guide's gfx950 correction (an upper bound for this kernel's 32-byte star-grid reads)
+    return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, {"FETCH_SIZE_KiB": got["FETCH_SIZE"], "WRITE_SIZE_KiB": got["WRITE_SIZE"],
+                                                                   "launches_per_pass": 3}
+
+
+def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ranks, same_frames=False, all_ranks=None, split=None):
+    """The product's own batch entry points with every frame DELIVERED to the host (SURVEY 8d/7.6 "with and without D2H"):
+    frame_objs[i] (a Config; its scene carries bloomStrength / bloomDivider) goes to trees[i % len(trees)].  Output buffers are
+    page-locked (bs_host_alloc), a ring of 4 per context: two frames are in flight per context, so frame k's buffer is free again
+    by the time frame k + 4 is enqueued -- the consumer (the reference writes each frame to a PNG file, app/Main.hs:121-123) is
+    NOT part of the timed region.  Timed like the headline: fence, one blocking call, fence; max over ranks.
+    same_frames: every frame_objs[i] is the same scene, so after the timed call (untimed) every delivered frame -- whichever context, device
+    or rank made it -- must be byte-identical to the first: `frames_identical` (None when the frames differ by design: the animation).
+    all_ranks(x) -> every rank's x; split() -> the `split` block (split_leg), supplied by the caller who knows the ranks."""
+    n_t = len(trees)
+    res = {}
+
+    def identical_everywhere(blobs):
+        """blobs: this process's delivered frames (arrays or bytes).  All equal here, and -- through 48 bits of a digest -- on every rank.
+        With ranks this is a collective: every rank calls it, also one that has nothing to show (which makes the answer False)."""
+        if not same_frames:
+            return None
+        arrs = [np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray, memoryview)) else np.asarray(b) for b in blobs]
+        here = bool(arrs) and all(np.array_equal(a, arrs[0]) for a in arrs[1:])
+        if all_ranks is None:
+            return here if arrs else None
+        marks = all_ranks(digest_as_float(frame_digest(np, arrs[0])) if here else -1.0)
+        return bool(min(marks) >= 0 and len(set(marks)) == 1)
+
+    FORMS = {
+        "batch": dict(key="batch", entry="bs_render_batch", call=lambda fo, o: bs.render_batch(fo, trees, outs=o),
+                      alloc=lambda t: bs.alloc_image(t, H, W, dtype=np.float64), nbytes=lambda r: W * H * 3 * 8,
+                      note="RGB f64 frames written into page-locked host memory by the trace kernels themselves (zero copy), two frames in flight per context"),
+        "rgb8-batch": dict(key="rgb8_batch", entry="bs_render_rgb8_batch", call=lambda fo, o: bs.render_rgb8_batch(fo, trees, outs=o),
+                           alloc=lambda t: bs.alloc_image(t, H, W, dtype=np.uint8), nbytes=lambda r: W * H * 3,
+                           note="doRender on the device (render -> bloom -> sRGB8, app/Main.hs:105-123): only RGB8 reaches the host, two frames in flight per context"),
+        "png-batch": dict(key="png_batch", entry="bs_render_png_batch", call=lambda fo, o: bs.render_png_batch(fo, trees, outs=o),
+                          alloc=lambda t: bs.alloc_png(t, H, W), nbytes=lambda r: int(sum(len(f) for f in r) / max(len(r), 1)),
+                          note="doRender on the device to the end (render -> bloom -> sRGB8 -> PNG encoder, app/Main.hs:105-123 with writeImg's file format): "
+                               "the finished file is all that reaches the host (bytes_to_host_per_frame = its mean size); what is left for the host is write(2)"),
+    }
+    for form in forms:
+        if form == "split":
+            if split is not None:
+                res["split"] = split()
+            continue
+        if form == "png-files":
+            res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere)
+            continue
+        F = FORMS[form]
+        rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
+        outs = [rings[i % n_t][(i // n_t) % 4] for i in range(len(frame_objs))]
+        call = F["call"]
+        # untimed warm-up = the same call once, over at least WARM_PER_CONTEXT frames per context: the contexts' second stream, device images
+        # and blur scratch get created, every ring buffer is written once, a one-off ~35 ms that the FIRST many-frame batch call of a process
+        # pays when no other timed work preceded it (measured: 5.96 ms per frame in the first 20-frame call, 4.10-4.11 in the next three;
+        # profiles/EXPERIMENTS.md) is spent -- and every context MEASURES this frame shape once (csrc/batch.cpp: the partition trial, 8 + 3 x 8
+        # frames), so that the timed call runs with the context's remembered choice like any later call of a long-lived host would
+        n_warm = max(len(frame_objs), WARM_PER_CONTEXT * n_t)
+        call([frame_objs[i % len(frame_objs)] for i in range(n_warm)], [rings[i % n_t][(i // n_t) % 4] for i in range(n_warm)])
+        if os.environ.get("BLACKSTAR_BENCH_D2H_REPS"):  # diagnostic: the same call several times, each timed (stderr)
+            for rep in range(int(os.environ["BLACKSTAR_BENCH_D2H_REPS"])):
+                fence()
+                t0 = time.perf_counter()
+                call(frame_objs, outs)
+                fence()
+                print(f"[d2h {form} rep {rep}] {(time.perf_counter() - t0) / (len(frame_objs) / n_t) * 1e3:.3f} ms per frame per GPU", file=sys.stderr)
+        fence()
+        t0 = time.perf_counter()
+        got = call(frame_objs, outs)
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        frames = len(frame_objs) * world // 1  # every rank runs the same number of frames
+        per_gpu = len(frame_objs) / n_t
+        res[F["key"]] = {
+            "Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
+            "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"],
+            # (ring buffers: the distinct ones hold the last frame written into each; PNG: every file of the call)
+            "frames_identical": identical_everywhere([bytes(g) for g in got] if form == "png-batch" else list({id(o): o for o in outs}.values()))}
+        if form == "png-batch" and hasattr(bs, "render_rgb8"):
+            # what the same file costs the way the reference makes it (JuicyPixels over zlib, one core): this frame's pixels through zlib
+            # on ONE host core, the Sub-filtered scanlines at levels 1 and 6 -- a reported baseline like cpu_baseline, outside every timed region
+            import zlib
+            px = bs.render_rgb8(frame_objs[0], trees[0])
+            sub = px.copy()
+            sub[:, 1:] -= px[:, :-1]
+            raw = b"".join(b"\x01" + sub[y].tobytes() for y in range(px.shape[0]))
+            host = {}
+            for level in (1, 6):
+                t0 = time.perf_counter()
+                z = zlib.compress(raw, level)
+                host[f"zlib_level{level}"] = {"ms_per_frame_one_core": (time.perf_counter() - t0) * 1e3, "bytes": len(z)}
+            res[F["key"]]["host_encoder_baseline"] = host
+        del rings, outs, got
+    return res
+
+
+def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere=None):
+    """The reference's batch loop to the very end: every frame rendered, bloomed, encoded AND written to a file by ONE bs_render_png_files
+    call (frames in flight on the GPUs, a native writer thread on page-locked buffers), into a fresh directory on the RAM disk (or the
+    temp directory) that is removed afterwards.  One untimed call first, like the other delivered forms."""
+    import shutil
+    import tempfile
+    # A directory with room for the files (a container's /dev/shm can be 64 MB): RAM disk if it has 4x what the frames need, else the temp
+    # directory, else the leg is skipped -- on EVERY rank (the decision is a collective), so nobody waits in a fence for a rank that left.
+    need = 4 * len(frame_objs) * (W * H * 3 + 4096)
+    base = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free >= need:
+                base = cand
+                break
+        except OSError:
+            pass
+    if max_over_ranks(0.0 if base else 1.0) > 0:
+        return {"skipped": f"no directory with {need >> 20} MiB free on some rank (/dev/shm, {tempfile.gettempdir()})"}
+    d = tempfile.mkdtemp(prefix="blackstar_bench_", dir=base)
+    err, dt_local, size, files = None, float("inf"), 0, None
+    try:
+        paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
+        try:
+            bs.render_png_files(frame_objs, trees, paths)
+        except Exception as e:  # a failing rank still goes through the same fences and collectives as the others
+            err = f"{type(e).__name__}: {e}"
+        fence()
+        t0 = time.perf_counter()
+        if err is None:
+            try:
+                bs.render_png_files(frame_objs, trees, paths)
+                dt_local = time.perf_counter() - t0
+                size = sum(os.path.getsize(p) for p in paths)
+                if identical_everywhere is not None:  # read back before the directory goes (untimed; a few distinct files would do, all is simplest)
+                    files = []
+                    for p in paths:
+                        with open(p, "rb") as f:
+                            files.append(f.read())
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
+        fence()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    dt = max_over_ranks(dt_local)
+    same = identical_everywhere(files or []) if identical_everywhere is not None else None   # (a collective when there are ranks: every rank calls it)
+    if err is not None or dt == float("inf"):
+        return {"error": err or "another rank failed"}
+    frames = len(frame_objs) * world
+    per_gpu = len(frame_objs) / len(trees)
+    return {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
+            "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
+            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same,
+            "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device, write(2) by a native writer thread while the next frames render "
+                    "(app/Main.hs:68-77 incl. writeImg's write)"}
+
+
+def sustained_leg(bs, torch, np, trees, cfgs, outs, streams, devs, n_frames):
+    """n_frames more frames per device, back to back on one stream each (all devices at once), with an event every 50 frames:
+    what the chip sustains under its package power cap once it is warm, which 20 launches cannot show.  Returns per-device
+    (ms per frame overall, first 50, last 50).  n_frames must be a multiple of 50."""
+    assert n_frames >= 50 and n_frames % 50 == 0
+    marks = []
+    for k, d in enumerate(devs):
+        with torch.cuda.device(d):
+            marks.append([torch.cuda.Event(enable_timing=True) for _ in range(n_frames // 50 + 1)])
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        for k, d in enumerate(devs):
+            if i % 50 == 0:
+                with torch.cuda.device(d):
+                    marks[k][i // 50].record(streams[k])
+            bs.render_device(cfgs[k], trees[k], outs[k].data_ptr(), outs[k].numel(), streams[k].cuda_stream)
+    for k, d in enumerate(devs):
+        with torch.cuda.device(d):
+            marks[k][-1].record(streams[k])
+    for d in sorted(set(devs)):
+        torch.cuda.synchronize(d)
+    wall = time.perf_counter() - t0
+    per_dev = []
+    for k in range(len(devs)):
+        seg = [marks[k][j].elapsed_time(marks[k][j + 1]) / 50 for j in range(len(marks[k]) - 1)]  # n_frames is a multiple of 50
+        per_dev.append({"ms_per_frame": marks[k][0].elapsed_time(marks[k][-1]) / n_frames, "ms_first_50": seg[0], "ms_last_50": seg[-1],
+                        "ms_slowest_50": max(seg)})
+    return wall, per_dev
+
+
+def frame_digest(np, frame):
+    """sha256 of a frame's bytes (a torch tensor resident on any device, or a numpy array).  Untimed: the image crosses PCIe once."""
+    import hashlib
+    a = frame.detach().cpu().numpy() if hasattr(frame, "detach") else np.asarray(frame)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def digest_as_float(hexdigest):
+    """48 bits of a digest as a float (exact in binary64): lets equality of frames be decided through the float collectives."""
+    return float(int(hexdigest[:12], 16))
+
+
+WARM_PER_CONTEXT = 48   # frames per context of the delivered forms' untimed warm-up call (the partition trial needs 32, 40 on small frames)
+COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
+
+
+def validation_block(per_device, what, repeat_digest=None):
+    """What makes an N > 1 line prove itself: per_device = one (sha256 of the frame, bs_stats dict) per device /
+    rank, all of the SAME frame rendered once more after the timed region.  The arithmetic is deterministic, so the frames must be
+    bit-identical and every counter equal; a mismatch makes the line "valid": false (the measurement is still printed)."""
+    digests = [d for d, _ in per_device]
+    identical = len(set(digests)) == 1
+    counters = {k: [int(st[k]) for _, st in per_device] for k in COUNTERS}
+    counters_equal = all(len(set(v)) == 1 for v in counters.values())
+    out = {"frame": what, "devices_compared": len(per_device), "frames_identical_across_devices": identical,
+           "frame_sha256_per_device": [d[:16] for d in digests], "steps_per_device": counters["steps"],
+           "counters_identical_across_devices": counters_equal,
+           "counters_device0": {k: v[0] for k, v in counters.items()}}
+    if not counters_equal:
+        out["counters_per_device"] = counters
+    valid = identical and counters_equal and all(v > 0 for v in counters["steps"])
+    if repeat_digest is not None:  # the same frame twice on device 0: the kernel is deterministic run to run
+        out["repeat_identical_on_device0"] = repeat_digest == digests[0]
+        valid = valid and out["repeat_identical_on_device0"]
+    out["valid"] = bool(valid)
+    return out
+
+
+def per_config_block(bs, torch, np, _lib, tree, args, device):
+    """BASELINE configs[1] and configs[3] in the default line: per config, two untimed launches, then three launches
+    each bracketed by HIP events on the launch stream, image resident in HBM like the headline.  frac = 145 flop x executed RK4 steps /
+    mean launch time / the FP64 vector peak, exactly like roofline.frac.  About 0.15 s in all; runs right after the timed region, while
+    the clocks are up."""
+    res = {}
+    for name in ("default", "lensing-4k"):
+        wl = WORKLOADS[name]
+        cfg = workload_config(bs, name).to_bs_config()
+        W, H = cfg["width"], cfg["height"]
+        t = tree
+        if not wl["stars"]:  # configs[1] has no star map: its own context, built from an empty star set
+            t = bs.StarTree(None, device=device)
+            t.set_mode(_lib.BS_MODE_FAST if args.mode == "fast" else _lib.BS_MODE_STRICT)
+        try:
+            img = torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
+            stream = torch.cuda.current_stream()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            for _ in range(2):
+                bs.render_device(cfg, t, img.data_ptr(), img.numel(), stream.cuda_stream)
+            for a, b in ev:
+                a.record(stream)
+                bs.render_device(cfg, t, img.data_ptr(), img.numel(), stream.cuda_stream)
+                b.record(stream)
+            torch.cuda.synchronize()
+            st = t.stats()
+            each = [float(a.elapsed_time(b)) for a, b in ev]
+            ms = float(np.mean(each))
+            executed = int(st["steps"]) - int(st["rays"])
+            tf = FLOP_PER_STEP * executed / (ms * 1e-3) / 1e12
+            res[name] = {"workload": wl["label"].format(cat="same catalogue as the headline"), "baseline_config": wl["baseline"],
+                         "ms": ms, "ms_each": [round(x, 4) for x in each], "Mpixel_s": W * H / ms / 1e3, "rays": int(st["rays"]),
+                         "steps": int(st["steps"]), "rk4_steps_executed": executed, "achieved_TFLOPs": tf, "frac": tf / PEAK_FP64_VALU_TFLOPS,
+                         "lane_efficiency": st["steps"] / (64.0 * st["wave_iters"]), "effective_mode": ["strict", "fast"][int(st["effective_mode"])],
+                         "frame_sha256": frame_digest(np, img)[:16]}
+            del img
+        finally:
+            if t is not tree:
+                t.close()
+    return res
+
+
+def split_leg(bs, np, trees, rank, world, fence, max_over_ranks, gather_objs, reps=3):
+    """ONE frame of BASELINE configs[3] (lensing-disk at 3840x2160, 4x supersample) cut into row bands over all GPUs -- SURVEY 8e's
+    fallback for a single huge frame.  One process with N contexts: bs_render_split (one host thread per context, every GPU writes its
+    band straight into the caller's page-locked frame).  One process per GPU: each rank renders band `rank` with bs_render_rows.  Either
+    way the bands are compared byte for byte with the whole frame rendered by ONE device (untimed), and the one-device time of the
+    same call is reported beside it: total work is fixed, so this is the strong-scaling figure."""
+    from blackstar_amd.distributed import shard_rows
+    cfg_obj = workload_config(bs, "lensing-4k")
+    cfg = cfg_obj.to_bs_config()
+    W, H = cfg["width"], cfg["height"]
+    n_t = len(trees)
+    n_parts = n_t * world
+    ref = bs.alloc_image(trees[0], H, W)
+
+    def timed(fn):
+        fn()  # untimed: buffers touched, streams made
+        ts = []
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            fence()
+            ts.append(max_over_ranks(time.perf_counter() - t0))
+        return ts
+
+    one = timed(lambda: bs.render(cfg, trees[0], out=ref))   # the whole frame on one device (every rank does this: its own reference)
+    st1 = trees[0].stats()
+    ref_steps = int(st1["steps"])
+    if world == 1:
+        full = bs.alloc_image(trees[0], H, W)
+        full[:] = 0
+        ts = timed(lambda: bs.render_split(cfg, trees, out=full))
+        identical = bool(np.array_equal(full, ref))
+        bands = [shard_rows(H, k, n_t) for k in range(n_t)]
+        entry = "bs_render_split"
+    else:
+        row0, row1 = shard_rows(H, rank, world)
+        band = bs.alloc_image(trees[0], row1 - row0, W)
+        band[:] = 0
+        ts = timed(lambda: bs.render_rows(cfg, trees[0], row0, row1, out=band))
+        mine = bool(np.array_equal(band, ref[row0:row1]))   # this rank's band against this rank's own whole frame ...
+        got = gather_objs((mine, frame_digest(np, ref), (row0, row1)))
+        identical = all(g[0] for g in got) and len({g[1] for g in got}) == 1   # ... and every rank's whole frame is the same frame
+        bands = [g[2] for g in got]
+        entry = "bs_render_rows (one band per rank)"
+    dt, dt_one = float(np.mean(ts)), float(np.mean(one))
+    return {"Mpixel_s": W * H / dt / 1e6, "ms_per_frame": dt * 1e3, "ms_each": [round(t * 1e3, 4) for t in ts], "seconds": dt, "frames": 1,
+            "parts": n_parts, "bands": [list(b) for b in bands], "entry_point": entry,
+            "one_device_ms_per_frame": dt_one * 1e3, "one_device_Mpixel_s": W * H / dt_one / 1e6, "speedup_vs_one_device": dt_one / dt,
+            "identical_to_one_device": identical, "one_device_steps": ref_steps, "bytes_to_host_per_frame": W * H * 24,
+            "one_device_stats": {k: (float(st1[k]) if k == "kernel_ms" else int(st1[k])) for k in ("rays", "steps", "wave_iters", "kernel_ms")},
+            "workload": WORKLOADS["lensing-4k"]["label"].format(cat="same catalogue as the headline"),
+            "note": "ONE frame, row bands over all GPUs, RGB f64 written into page-locked host memory by the kernels themselves; blocking call, "
+                    f"mean of {reps}; strong scaling: speedup_vs_one_device is the figure for a single huge frame (SURVEY 8e)"}
+
+
+def optional_leg(name, safe, fn):
+    """Run a leg that is reported NEXT TO the headline value.  With safe=True (one rank, and the headline does not come from this
+    leg) a failure becomes {"error": ...} in the line instead of costing the value already measured; otherwise it propagates
+    (with several ranks, one rank leaving a leg early would leave the others waiting in its barrier)."""
+    if not safe:
+        return fn()
+    try:
+        return fn()
+    except Exception as e:
+        print(f"bench.py: optional leg {name!r} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def roofline_block(args, st, kernel_ms, W, H, peak_measured=None):
+    executed = int(st["steps"]) - int(st["rays"])  # the kernel skips the reference's final, discarded rk4 per ray
+    flops = FLOP_PER_STEP * executed
+    achieved = flops / (kernel_ms * 1e-3) / 1e12  # mean launch duration over the timed region (HIP events on the launch stream)
+    alg_bytes = 24.0 * W * H
+    live = getattr(args, "traffic_live", None)
+    if args.traffic_bytes is not None:
+        traffic, traffic_src, kind = args.traffic_bytes, "--traffic-bytes", "given"
+    elif live and live[0] is not None:
+        traffic, traffic_src, kind = live[0], live[1], "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over scripts/prof_frame.py, same frame, child processes"
+    else:
+        traffic, traffic_src = pmc_traffic(args.mode)
+        kind = "static (committed rocprofv3 --pmc passes, not measured in this run" + (f"; live measurement unavailable: {live[1]})" if live else ")")
+    r = {"bound": "valu", "detail": "FP64 VALU issue (scalar ODE per lane; HBM and MFMA are not the bound)",
+         "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS,
+         "flop_kind": "reference-equivalent: 145 flop per RK4 step as the reference's arithmetic counts them (SURVEY 8d), "
+                      "NOT executed instructions -- see valu_issue_frac for those",
+         "flop_per_launch": flops, "flop_per_step": FLOP_PER_STEP, "rk4_steps_executed": executed,
+         "traffic": traffic, "traffic_kind": kind,
+         "traffic_source": traffic_src,
+         "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+                 "peak_GBs": PEAK_HBM_GBS, "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    if peak_measured:
+        lv = LOOP_VALU[args.mode]
+        # issue slots the stepping loop needs: every wavefront iteration issues full_rate + 4 * quarter_rate slots of 64 lanes
+        slots = float(st["wave_iters"]) * 64.0 * (lv["full_rate"] + 4 * lv["quarter_rate"])
+        r["peak_measured"] = peak_measured["TFLOPs"]
+        r["peak_measured_detail"] = peak_measured["detail"]
+        r["frac_of_measured_peak"] = achieved / peak_measured["TFLOPs"]
+        r["valu_issue_frac"] = slots / (kernel_ms * 1e-3) / (peak_measured["Ginstr_per_s"] * 1e9)
+        r["valu_issue_detail"] = (f"stepping-loop VALU issue slots ({lv['full_rate']} full-rate f64 + {lv['quarter_rate']} quarter-rate per "
+                                  "wavefront step, ISA count) x wavefront iterations / launch time, over the v_fma_f64 issue rate measured in this run")
+    return r
+
+
+def measure_peak(tree, _lib):
+    """v_fma_f64 issue rate on this box, this run (bs_debug_ubench: 8 independent chains per lane, 2048 workgroups)."""
+    import ctypes as C
+    L = _lib.lib()
+    ms, gi = C.c_double(), C.c_double()
+    best = 0.0
+    for _ in range(3):
+        _lib.check(_lib.debug_lib().bs_debug_ubench(tree.handle, 0, 256 * 8, 20000, C.byref(ms), C.byref(gi)), "bs_debug_ubench")
+        best = max(best, gi.value / ms.value * 1e3)
+    return {"Ginstr_per_s": best, "TFLOPs": best * 2 / 1e3, "detail": "v_fma_f64, 8 chains/lane, best of 3 (bs_debug_ubench)"}
+
+
+def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
+    """What SURVEY 8d asks for beside the kernel-only figure: the wall time of the drop-in calls themselves (kernel + D2H),
+    and the STRICT mode of the same frame.  Runs after the timed loop, outside `value`."""
+    import numpy as np
+    W, H = cfg["width"], cfg["height"]
+    res = {}
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+
+    def entry(ms, note):
+        return {"ms": ms, "Mpixel_s": W * H / ms / 1e3, "note": note}
+
+    t0 = time.perf_counter()
+    pinned = bs.alloc_image(tree, H, W)
+    res["bs_host_alloc_ms"] = (time.perf_counter() - t0) * 1e3  # why the shim allocates its page-locked image buffer ONCE
+    bs.render(cfg, tree, out=pinned)
+    res["bs_render_pinned"] = entry(med(lambda: bs.render(cfg, tree, out=pinned), 5),
+                                    "bs_render into a bs_host_alloc (page-locked) buffer: the kernel writes the frame straight into host memory over PCIe (zero copy), blocking")
+    touched = np.empty((H, W, 3))
+    bs.render(cfg, tree, out=touched)
+    res["bs_render_pageable_reused"] = entry(med(lambda: bs.render(cfg, tree, out=touched), 5),
+                                             "bs_render into ONE pageable buffer reused across calls: kernel (two half-frame launches) + 49.8 MB staged D2H")
+    res["bs_render_pageable"] = entry(med(lambda: bs.render(cfg, tree, out=np.empty((H, W, 3))), 3),
+                                      "bs_render into a freshly allocated pageable buffer every call (first-touch page faults included)")
+    pinned8 = bs.alloc_image(tree, H, W, dtype=np.uint8)
+    bs.render_rgb8(cfg_obj, tree, out=pinned8)
+    res["bs_render_rgb8"] = entry(med(lambda: bs.render_rgb8(cfg_obj, tree, out=pinned8), 5),
+                                  "render + bloom + sRGB8 on the device, 6.2 MB RGB8 written into a page-locked host buffer by the last kernel "
+                                  "(doRender up to the PNG encoder), blocking")
+    # Two frames in flight: consecutive frames alternate between two streams (what bs_render_batch does per context), so the end of
+    # one launch -- the ~0.3 ms in which its last tiles drain and the SIMDs empty -- overlaps the start of the next
+    out2 = torch.empty_like(out)
+    s2 = torch.cuda.Stream()
+    lanes = [(out, stream), (out2, s2)]
+    n2 = 20
+    for k in range(4):
+        o, s = lanes[k & 1]
+        bs.render_device(cfg, tree, o.data_ptr(), o.numel(), s.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n2):
+        o, s = lanes[k & 1]
+        bs.render_device(cfg, tree, o.data_ptr(), o.numel(), s.cuda_stream)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) * 1e3 / n2
+    res["two_streams"] = entry(ms2, f"{n2} frames resident in HBM, alternating between two streams (two launches in flight): wall time per frame")
+    # STRICT mode of the same frame, image resident in HBM like the headline
+    tree.set_mode(_lib.BS_MODE_STRICT)
+    try:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+        bs.render_device(cfg, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
+        for a, b in ev:
+            a.record(stream)
+            bs.render_device(cfg, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
+            b.record(stream)
+        torch.cuda.synchronize()
+        st = tree.stats()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        executed = int(st["steps"]) - int(st["rays"])
+        tf = FLOP_PER_STEP * executed / (ms * 1e-3) / 1e12
+        strict = {"ms_per_step": ms, "Mpixel_s": W * H / ms / 1e3, "achieved_TFLOPs": tf, "frac": tf / PEAK_FP64_VALU_TFLOPS,
+                  "note": "BS_MODE_STRICT (bit-exact trajectories), image resident in HBM, 4 launches"}
+    finally:
+        tree.set_mode(_lib.BS_MODE_FAST if args.mode == "fast" else _lib.BS_MODE_STRICT)
+    return res, strict
+
+
+def forms_valid(d2h):
+    """False if any delivered form of this line found frames that should be identical and are not."""
+    if not isinstance(d2h, dict):
+        return True
+    return all(v.get("frames_identical") is not False and v.get("identical_to_one_device") is not False for v in d2h.values() if isinstance(v, dict))
+
+
+def split_headline(args, res, blk, world):
+    """--form split: ONE frame over all GPUs is the result.  The line keeps the contract's keys, read for one frame: steps = 1 frame,
+    ms_per_step = its wall time, scaling = strong (total work fixed as N grows)."""
+    wl = WORKLOADS["lensing-4k"]
+    res.update({"metric": wl["metric"] + ", ONE frame split by rows over all GPUs", "scaling": "strong", "steps": 1, "ms_per_step": blk["ms_per_frame"]})
+    res["config"].update({"workload": blk["workload"], "baseline_config": wl["baseline"], "parallelism": f"row bands x{blk['parts']}",
+                          "frames_per_step_per_gpu": f"1/{blk['parts']}", "image": blk["note"]})
+    res["split"] = {k: blk[k] for k in ("speedup_vs_one_device", "one_device_ms_per_frame", "identical_to_one_device", "bands", "entry_point")}
+    for k in ("rays_per_s", "steps_per_ray", "lane_efficiency", "kernel_ms", "kernel_ms_last_hipevent"):
+        res.pop(k, None)   # they describe the warm-up launches' statistics, not the split frame
+    st1 = blk["one_device_stats"]   # the roofline of this frame: its kernel on ONE device, whole frame (hipEvent time from bs_stats)
+    res["roofline"] = dict(roofline_block(args, st1, st1["kernel_ms"], 3840, 2160), time_basis="the whole frame's kernel on one device (bs_stats.kernel_ms, HIP events)")
+
+
+def result_line(args, world, launcher, value, dt, W, H, frames_cfg, st, kernel_ms, extra_cfg=None, peak_measured=None, cat_note=CATALOGUES["synthetic"]):
+    overlapped = bool(extra_cfg) and extra_cfg.get("launches_in_flight_per_gpu", 1) > 1
+    wl = WORKLOADS[getattr(args, "workload", "default-aa") if frames_cfg is None else "animation"]
+    cfgd = {"workload": wl["label"].format(cat=cat_note), "baseline_config": wl["baseline"], "mode": args.mode, "frames_per_step_per_gpu": 1,
+            "parallelism": f"frame-sharded x{world}", "launcher": launcher,
+            "image": "RGB f64 resident in HBM (no D2H in the timed region)"}
+    if extra_cfg:
+        cfgd.update(extra_cfg)
+    frames = args.steps * world
+    return {
+        "metric": wl["metric"], "value": value, "unit": "Mpixel/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if args.catalogue in CATALOGUES else "synthetic scene + real catalogue file",
+        "config": cfgd,
+        "rays_per_s": frames * st["rays"] / dt, "steps_per_ray": st["steps"] / st["rays"],
+        "lane_efficiency": st["steps"] / (64.0 * st["wave_iters"]),
+        "kernel_ms": kernel_ms, "kernel_ms_last_hipevent": st["kernel_ms"],
+        # launches in flight overlap: a launch's own duration then says nothing about the rate; the step time does
+        "roofline": dict(roofline_block(args, st, kernel_ms if not overlapped else dt / args.steps * 1e3, W, H, peak_measured),
+                         time_basis="mean launch duration (HIP events)" if not overlapped else
+                         "ms_per_step (launches overlap: two in flight per GPU; their own durations are about twice this)"),
+    }
