@@ -338,6 +338,54 @@ def test_c3_c4_full_size_properties(oracle):
     t.close()
 
 
+def test_mirror_symmetry_at_full_size(catalogue_bytes):
+    """A size-independent property that needs no oracle: the scene (hole + disk in the plane y = 0) is mirror-symmetric, IEEE arithmetic is
+    sign-symmetric, and with a power-of-two resolution generateRay's x'/W, y'/H are exact -- so in STRICT mode
+      (1) the scene mirrored in the disk plane (camera, lookAt, stars: y -> -y; upVec: the mirrored vector negated, which keeps the
+          image's handedness) renders the SAME frame upside down, row y of one = row H - y of the other (row 0 has no partner: there
+          is no half-pixel offset, src/Raytracer.hs:40-51), bit for bit where no star is summed and to 1e-12 where the star grid's
+          summation order differs;
+      (2) a camera in the plane x = 0 that looks at the hole with upVec in that plane renders a left-right symmetric frame, column x =
+          column W - x, bit for bit (no stars).
+    8.4 M rays each at 4096 x 2048; FAST holds both within the north_star tolerance."""
+    W, H = 4096, 2048
+    stars = bs.read_map(catalogue_bytes)
+    mirrored = stars.copy()
+    mirrored["y"] = -mirrored["y"]
+    base = dict(scenes.DEFAULT, width=W, height=H)          # default.yaml's camera: position (0, 1, -20), lookAt (2, 0, 0), upVec (-0.2, 1, 0)
+
+    def mirror_y(c):
+        m = dict(c)
+        m["cam_pos"] = (c["cam_pos"][0], -c["cam_pos"][1], c["cam_pos"][2])
+        m["cam_lookat"] = (c["cam_lookat"][0], -c["cam_lookat"][1], c["cam_lookat"][2])
+        m["cam_up"] = (-c["cam_up"][0], c["cam_up"][1], -c["cam_up"][2])     # -(M up)
+        return m
+    ta, tb, t0 = bs.StarTree(stars), bs.StarTree(mirrored), bs.StarTree(None)
+    try:
+        for mode, rt, at in ((_lib.BS_MODE_STRICT, 1e-12, 1e-14), (_lib.BS_MODE_FAST, RTOL_FAST, ATOL_FAST)):
+            for t in (ta, tb, t0):
+                t.set_mode(mode)
+            a = bs.render(base, ta)
+            sa = ta.stats()
+            b = bs.render(mirror_y(base), tb)
+            sb = tb.stats()
+            assert sa["rays"] == sb["rays"] == W * H and sa["capped"] == sb["capped"] == 0 and sa["star_hits"] > 0   # (row 0 has no partner: other totals need not agree)
+            flipped = b[:0:-1]                                   # rows H-1 .. 1 of the mirrored scene = rows 1 .. H-1 of the original
+            assert (np.abs(flipped - a[1:]) <= at + rt * np.abs(a[1:])).all(), mode
+            if mode == _lib.BS_MODE_STRICT:
+                a0, b0 = bs.render(base, t0), bs.render(mirror_y(base), t0)          # no stars: nothing is summed in another order
+                assert np.array_equal(b0[:0:-1], a0[1:]) and a0[1:].any()
+            sym = dict(base, cam_pos=(0.0, 3.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 1.0, 0.0))
+            c = bs.render(sym, t0)
+            if mode == _lib.BS_MODE_STRICT:
+                assert np.array_equal(c[:, 1:], c[:, :0:-1]) and c.any()
+            else:
+                assert (np.abs(c[:, 1:] - c[:, :0:-1]) <= at + rt * np.abs(c[:, 1:])).all()
+    finally:
+        for t in (ta, tb, t0):
+            t.close()
+
+
 def test_bloom_and_srgb8_match_oracle(tree, oracle):
     """the steps after render (app/Main.hs:113-123) on the device."""
     cfg = scenes.with_res(scenes.DEFAULT_AA, 200, 112)

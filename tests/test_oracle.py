@@ -520,3 +520,29 @@ def test_ghc_pin_kit_is_complete_and_consistent():
     verdict = os.path.join(repo, "tests", "golden", "ghc", "shim_typecheck.txt")
     if os.path.exists(verdict):
         assert open(verdict).read().strip() == "OK", "the shim did not type-check against the reference (tests/golden/ghc/shim_typecheck.log)"
+
+
+def test_mirror_symmetry_pins_ray_generation_and_integration(oracle, oracle_stars):
+    """A property no restatement can share a mistake about: the scene (hole + disk in y = 0) is mirror-symmetric and IEEE arithmetic is
+    sign-symmetric, so with a power-of-two resolution (x'/W, y'/H exact) the scene mirrored in the disk plane -- camera, lookAt and stars
+    y -> -y, upVec mirrored and negated -- renders the same frame upside down, row y = row H - y (no half-pixel offset: row 0 has no
+    partner, src/Raytracer.hs:40-51), and a camera in the plane x = 0 looking at the hole renders a left-right symmetric frame.  Bit for
+    bit: a wrong sign, a swapped axis or an off-by-one in generateRay / lookAt / findColor's crossing test breaks it."""
+    W, H = 128, 64
+    base = dict(scenes.DEFAULT_AA, width=W, height=H, supersampling=False)
+    m = dict(base, cam_pos=(base["cam_pos"][0], -base["cam_pos"][1], base["cam_pos"][2]),
+             cam_lookat=(base["cam_lookat"][0], -base["cam_lookat"][1], base["cam_lookat"][2]),
+             cam_up=(-base["cam_up"][0], base["cam_up"][1], -base["cam_up"][2]))
+    mirrored = oracle_stars.copy()
+    mirrored["y"] = -mirrored["y"]
+    a, sa = oracle.render(base, oracle.Index(oracle_stars), threads=0)
+    b, sb = oracle.render(m, oracle.Index(mirrored), threads=0)
+    assert sa["rays"] == sb["rays"] and sa["star_hits"] > 0 and sa["disk_hits"] > 0    # (row 0 of either frame has no partner: the totals need not agree)
+    np.testing.assert_allclose(b[:0:-1], a[1:], rtol=1e-13, atol=0)     # (the stars of a lookup are summed in index order: the same here)
+    empty = oracle.Index(None)
+    a0, _ = oracle.render(base, empty, threads=0)
+    b0, _ = oracle.render(m, empty, threads=0)
+    assert np.array_equal(b0[:0:-1], a0[1:]) and a0[1:].any()
+    assert not np.array_equal(b0[1:], a0[1:])                          # (negative control: not simply the same image)
+    c, _ = oracle.render(dict(base, cam_pos=(0.0, 3.0, -20.0), cam_lookat=(0.0, 0.0, 0.0), cam_up=(0.0, 1.0, 0.0)), empty, threads=0)
+    assert np.array_equal(c[:, 1:], c[:, :0:-1]) and c.any() and not np.array_equal(c[:, 1:], c[:, :-1])
