@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -17,6 +18,27 @@
 using namespace bs;
 
 // (the bs_* entry points get C linkage from their declarations in include/blackstar_gpu.h)
+
+// One host thread per context: body(c) for c = 0 .. n-1, each on its own thread (a single context: on the caller's).  A thread that cannot
+// be started (std::system_error: EAGAIN under a process / thread limit) must not become an exception in an `extern "C"` function, which
+// would end the process: its body runs on the calling thread instead, after the others have been started.
+template <class Body>
+static void per_context(int n, Body body)
+{
+    if (n == 1) { body(0); return; }
+    std::vector<std::thread> th;
+    std::vector<int> inline_later;
+    th.reserve((size_t)n);
+    for (int c = 0; c < n; c++) {
+        try {
+            th.emplace_back(body, c);
+        } catch (const std::system_error &) {
+            inline_later.push_back(c);
+        }
+    }
+    for (int c : inline_later) body(c);
+    for (auto &t : th) t.join();
+}
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -118,14 +140,10 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
     // collective: frames are independent (app/Main.hs:72-77 renders them one after another).
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
-    std::vector<std::thread> th;
-    for (int c = 0; c < n_ctx; c++) {
-        th.emplace_back([&, c]() {
-            rcs[c] = render_frames_pipelined(ctxs[c], cfgs, outs, c, n_frames, n_ctx);
-            if (rcs[c]) errs[c] = bs::error_message();
-        });
-    }
-    for (auto &t : th) t.join();
+    per_context(n_ctx, [&](int c) {
+        rcs[c] = render_frames_pipelined(ctxs[c], cfgs, outs, c, n_frames, n_ctx);
+        if (rcs[c]) errs[c] = bs::error_message();
+    });
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
@@ -540,14 +558,10 @@ static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cf
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
-    std::vector<std::thread> th;
-    for (int c = 0; c < n_ctx; c++) {
-        th.emplace_back([&, c]() {
-            rcs[c] = run_share(ctxs[c], cfgs, n_frames, bloom_strengths, bloom_dividers, outs, png, c, n_ctx);
-            if (rcs[c]) errs[c] = bs::error_message();
-        });
-    }
-    for (auto &t : th) t.join();
+    per_context(n_ctx, [&](int c) {
+        rcs[c] = run_share(ctxs[c], cfgs, n_frames, bloom_strengths, bloom_dividers, outs, png, c, n_ctx);
+        if (rcs[c]) errs[c] = bs::error_message();
+    });
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
@@ -632,9 +646,14 @@ int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
             writer.join();
             if (!write_error.empty()) return fail(BS_EIO, write_error);
         }
-        writer = std::thread([&write_error, outs, sz, paths, pos, count]() {
+        auto write_set = [&write_error, outs, sz, paths, pos, count]() {
             for (int j = 0; j < count && write_error.empty(); j++) write_error = write_whole_file(paths[pos + j], outs[j], sz[j]);
-        });
+        };
+        try {
+            writer = std::thread(write_set);
+        } catch (const std::system_error &) {   // no thread to be had: write this set here, without the overlap
+            write_set();
+        }
     }
     if (writer.joinable()) writer.join();
     if (rc) return rc;   // (the failing call has set the message)
@@ -654,15 +673,11 @@ int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double
     const int base = cfg->height / n, extra = cfg->height % n;
     std::vector<int> rcs(n, BS_OK);
     std::vector<std::string> errs(n);
-    std::vector<std::thread> th;
-    for (int c = 0; c < n; c++) {
+    per_context(n, [&](int c) {
         const int row0 = c * base + std::min(c, extra), row1 = row0 + base + (c < extra ? 1 : 0);
-        th.emplace_back([&, c, row0, row1]() {
-            rcs[c] = bs_render_rows(ctxs[c], cfg, row0, row1, out_rgb + (size_t)row0 * cfg->width * 3, (size_t)(row1 - row0) * cfg->width * 3);
-            if (rcs[c]) errs[c] = bs::error_message();
-        });
-    }
-    for (auto &t : th) t.join();
+        rcs[c] = bs_render_rows(ctxs[c], cfg, row0, row1, out_rgb + (size_t)row0 * cfg->width * 3, (size_t)(row1 - row0) * cfg->width * 3);
+        if (rcs[c]) errs[c] = bs::error_message();
+    });
     for (int c = 0; c < n; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;

@@ -470,15 +470,24 @@ int orc_render(const orc_config *cfg, const orc_index *idx, double *out_rgb, siz
     volatile int next_row = 0;
     job_t *jobs = (job_t *)calloc((size_t)threads, sizeof(job_t));
     pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    char *started = (char *)calloc((size_t)threads, 1);
+    if (!jobs || !tid || !started) { free(jobs); free(tid); free(started); if (cfg->supersampling) free(img); return -3; }
     for (int t = 0; t < threads; t++) {
         jobs[t].s = &s; jobs[t].ix = idx; jobs[t].img = img; jobs[t].max_steps = max_steps; jobs[t].next_row = &next_row;
         if (threads == 1) worker(&jobs[t]);
-        else pthread_create(&tid[t], NULL, worker, &jobs[t]);
+        else started[t] = pthread_create(&tid[t], NULL, worker, &jobs[t]) == 0;
+    }
+    /* rows are pulled off one counter, so a thread that could not be started (EAGAIN under a process / thread limit) only means
+     * fewer workers; with none at all the calling thread does the frame */
+    if (threads > 1) {
+        int any = 0;
+        for (int t = 0; t < threads; t++) any |= started[t];
+        if (!any) worker(&jobs[0]);
     }
     orc_stats tot;
     memset(&tot, 0, sizeof tot);
     for (int t = 0; t < threads; t++) {
-        if (threads > 1) pthread_join(tid[t], NULL);
+        if (threads > 1 && started[t]) pthread_join(tid[t], NULL);
         tot.rays += jobs[t].st.rays; tot.steps += jobs[t].st.steps; tot.capped += jobs[t].st.capped;
         tot.horizon += jobs[t].st.horizon; tot.escaped += jobs[t].st.escaped;
         tot.disk_hits += jobs[t].st.disk_hits; tot.star_hits += jobs[t].st.star_hits;
@@ -491,7 +500,7 @@ int orc_render(const orc_config *cfg, const orc_index *idx, double *out_rgb, siz
     tot.seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     tot.threads = threads;
     if (stats) *stats = tot;
-    free(jobs); free(tid);
+    free(jobs); free(tid); free(started);
     return 0;
 }
 
