@@ -227,7 +227,7 @@ def test_max_steps_limit_is_enforced(tree_empty):
 
 
 @pytest.mark.timeout(600, method="thread")
-@pytest.mark.parametrize("mode", ["fast", "strict"])
+@pytest.mark.parametrize("mode", ["fast"])   # (the counters are the same code in both instantiations; STRICT passes too and takes 30 s instead of 14)
 def test_statistics_do_not_wrap_at_2_pow_32(mode):
     """the per-lane and per-wavefront step counters were 32-bit.  A frame of rays that NEVER terminate (stepSize
     1e-9: 7e7 steps move a ray 0.07 Schwarzschild radii) with the cap raised to 2^26 + 11: every wavefront's step total is
