@@ -288,7 +288,10 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
 // CUs -- a whole frame time -- and a first version that timed 4-frame segments end to end chose the shared chip for 16 of 26 shapes on
 // which a partition is 2-15 % faster (profiles/r04_partition_trial_ab_wall_time_v1.jsonl).  Every trial frame is a frame of the batch,
 // delivered like any other (byte-identical whichever way it was made); what the trial costs is the difference between the segments, a
-// few per cent of 32 frames, once.  Shares that are too short, or mix shapes of which one has not been measured, run on the shared chip
+// few per cent of 32 frames, once.  The key is the frame's SHAPE (size, supersampling, bloom divider, pixels or file, arithmetic), not its
+// scene: a heavier scene of the same shape may prefer the other partition (lensing-disk at 4K: 8 CUs, default-aa at 4K: 16) and then runs
+// 2-3 % above its own optimum with the remembered one -- still ahead of the shared chip in every measured case.
+// Shares that are too short, or mix shapes of which one has not been measured, run on the shared chip
 // (the safe side: a partition that is too small for its post stage costs 50-70 %, none costs <= 9 %).
 // BLACKSTAR_POST_CUS=0 | 8 | 16 | 24 | 32 overrides (A/B).
 // Order: shared, 16, 8 -- NOT ascending.  A partition that is too small for its post stage leaves the trace CUs idle half of the time, the
