@@ -133,7 +133,7 @@ static int distinct_contexts(bs_ctx *const *ctxs, int n_ctx)
 }
 
 int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, double *const *outs)
-{
+try {
     if (!ctxs || n_ctx <= 0 || (n_frames > 0 && (!cfgs || !outs))) return fail(BS_EINVAL, "null argument");
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     // One host thread per context (= per device); frame i goes to context i % n_ctx.  No data-path
@@ -147,7 +147,7 @@ int bs_render_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_render_batch"); }
 
 // Where a batch's frames go: RGB8 pixels (png == nullptr) or finished PNG files (bs_render_png_batch).
 struct PngSink {
@@ -572,17 +572,17 @@ static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cf
 
 int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
                          unsigned char *const *outs)
-{
+try {
     return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, nullptr);
-}
+} catch (...) { return bs::abi_exception("bs_render_rgb8_batch"); }
 
 int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
                         unsigned char *const *outs, const size_t *caps, size_t *out_bytes)
-{
+try {
     if (n_frames > 0 && (!caps || !out_bytes)) return fail(BS_EINVAL, "null argument");
     const PngSink sink{caps, out_bytes};
     return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, &sink);
-}
+} catch (...) { return bs::abi_exception("bs_render_png_batch"); }
 
 // One file: create / truncate, write, close.  Empty string on success, else what failed.
 static std::string write_whole_file(const char *path, const unsigned char *data, size_t n)
@@ -597,7 +597,7 @@ static std::string write_whole_file(const char *path, const unsigned char *data,
 
 int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
                         const char *const *paths, int pipe)
-{
+try {
     if (!ctxs || n_ctx <= 0 || n_frames < 0 || (n_frames > 0 && (!cfgs || !paths))) return fail(BS_EINVAL, "null argument");
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     size_t cap = 0;
@@ -662,10 +662,10 @@ int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
     if (rc) return rc;   // (the failing call has set the message)
     if (!write_error.empty()) return fail(BS_EIO, write_error);
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_render_png_files"); }
 
 int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
-{
+try {
     if (!ctxs || n_ctx <= 0 || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
@@ -684,4 +684,4 @@ int bs_render_split(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfg, double
     for (int c = 0; c < n; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_render_split"); }

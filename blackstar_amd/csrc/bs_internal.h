@@ -83,6 +83,10 @@ struct TraceParams {
     unsigned long long *counters;  // device, kCounters
 };
 
+// context.cpp: the catch-all of every `extern "C"` entry point (each is a function-try-block): no C++ exception crosses the ABI.  Must be
+// called from inside a catch handler; sets the thread's bs_last_error() and returns BS_ENOMEM for std::bad_alloc, else BS_EINTERNAL.
+int abi_exception(const char *where) noexcept;
+
 // Host-side strict math (host_math.cpp, compiled -ffp-contract=off).
 void host_hsi_to_rgb(double hue, double s, double i, double rgb[3], bool *ok);
 // writeImg's pixel map x -> toWord8 (sRGB x) (Raytracer.hs:23-32) as its 255 thresholds: T[k] (k = 1..255) = the smallest double

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -25,6 +26,25 @@ int fail(int code, const std::string &msg)
 }
 
 const std::string &error_message() { return g_err; }
+
+int abi_exception(const char *where) noexcept
+{
+    int code = BS_EINTERNAL;
+    try {
+        try {
+            throw;   // (the exception the caller's catch (...) is handling)
+        } catch (const std::bad_alloc &) {
+            code = BS_ENOMEM;
+            g_err = std::string(where) + ": out of host memory";
+        } catch (const std::exception &e) {
+            g_err = std::string(where) + ": unexpected C++ exception: " + e.what();
+        } catch (...) {
+            g_err = std::string(where) + ": unexpected C++ exception";
+        }
+    } catch (...) {  // building the message failed too: the code alone has to do
+    }
+    return code;
+}
 
 size_t ctx_layout_bytes() { return sizeof(bs_ctx); }
 
@@ -166,7 +186,7 @@ int bs_abi_version(void) { return BS_ABI_VERSION; }
 const char *bs_last_error(void) { return bs::error_message().c_str(); }
 
 bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
-{
+try {
     if (device < 0) { fail(BS_EDEVICE, "this library has no CPU backend: device must be a HIP device ordinal >= 0"); return nullptr; }
     if (n_stars && !stars) { fail(BS_EINVAL, "stars is null"); return nullptr; }
     if (n_stars >= (size_t(1) << 30)) { fail(BS_EINVAL, "too many stars"); return nullptr; }
@@ -246,18 +266,18 @@ bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars)
         return nullptr;
     }
     return ctx;
-}
+} catch (...) { (void)bs::abi_exception("bs_create"); return nullptr; }
 int bs_device_count(void)
-{
+try {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e == hipErrorNoDevice) return 0;
     if (e != hipSuccess) return fail(BS_EDEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     return count;
-}
+} catch (...) { return bs::abi_exception("bs_device_count"); }
 
 void bs_destroy(bs_ctx *ctx)
-{
+try {
     if (!ctx) return;
     if (ctx->device >= 0 && hipSetDevice(ctx->device) == hipSuccess) {
         (void)hipDeviceSynchronize();
@@ -306,42 +326,42 @@ void bs_destroy(bs_ctx *ctx)
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
-}
+} catch (...) { (void)bs::abi_exception("bs_destroy"); }
 
 int bs_set_mode(bs_ctx *ctx, int mode)
-{
+try {
     if (!ctx || (mode != BS_MODE_STRICT && mode != BS_MODE_FAST)) return fail(BS_EINVAL, "bad mode");
     ctx->mode = mode;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_set_mode"); }
 
 int bs_get_mode(const bs_ctx *ctx) { return ctx ? ctx->mode : BS_EINVAL; }
 int bs_validate_config(const bs_config *cfg)
-{
+try {
     if (!cfg) return fail(BS_EINVAL, "null argument");
     bs::TraceParams p;
     std::memset(&p, 0, sizeof p);
     std::string err;
     if (!bs::derive_params(*cfg, p, err)) return fail(BS_EINVAL, err);
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_validate_config"); }
 
 int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg)
-{
+try {
     if (!ctx || !cfg) return fail(BS_EINVAL, "null argument");
     return bs::effective_mode(ctx, cfg);
-}
+} catch (...) { return bs::abi_exception("bs_effective_mode"); }
 
 int bs_set_max_steps(bs_ctx *ctx, int max_steps)
-{
+try {
     if (!ctx || max_steps <= 0) return fail(BS_EINVAL, "bad max_steps");
     // the kernel counts a ray's steps in an int and the frame's in 64 bits: 2^30 rays (the largest frame) x 2^30 steps = 2^60
     if (max_steps > BS_MAX_STEPS_LIMIT) return fail(BS_EINVAL, "max_steps above BS_MAX_STEPS_LIMIT (2^30): the step counters could not hold a frame of capped rays");
     ctx->max_steps = max_steps;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_set_max_steps"); }
 void *bs_host_alloc(bs_ctx *ctx, size_t bytes)
-{
+try {
     if (!ctx || bytes == 0) { fail(BS_EINVAL, "null context or zero size"); return nullptr; }
     void *p = nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
@@ -349,11 +369,11 @@ void *bs_host_alloc(bs_ctx *ctx, size_t bytes)
         return nullptr;
     }
     return p;
-}
+} catch (...) { (void)bs::abi_exception("bs_host_alloc"); return nullptr; }
 
 void bs_host_free(void *p)
-{
+try {
     if (p) (void)hipHostFree(p);
-}
+} catch (...) { (void)bs::abi_exception("bs_host_free"); }
 
 }  // extern "C"

@@ -174,15 +174,15 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
 }  // namespace bs
 
 extern "C" int bs_hsi_to_rgb(double hue, double sat, double intensity, double rgb[3])
-{
+try {
     if (!rgb) return BS_EINVAL;
     bool ok;
     bs::host_hsi_to_rgb(hue, sat, intensity, rgb, &ok);
     return ok ? BS_OK : BS_EINVAL;
-}
+} catch (...) { return bs::abi_exception("bs_hsi_to_rgb"); }
 
 extern "C" long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size_t cap)
-{
+try {
     // readMap (StarMap.hs:45-58): skip 28; replicateM (remaining `div` 28) of
     //   getFloat64be ra, getFloat64be dec, getWord8 spectral, skip 1, getInt16be mag, skip 8
     if (!bytes || nbytes < 28) return BS_EINVAL;
@@ -216,4 +216,4 @@ extern "C" long bs_read_ppm(const void *bytes, size_t nbytes, bs_star *out, size
         }
     }
     return (long)n;
-}
+} catch (...) { return bs::abi_exception("bs_read_ppm"); }

@@ -44,7 +44,7 @@ static int release_post(bs_ctx *ctx, hipStream_t s)
 }
 
 int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int height, double strength, int divider, void *hip_stream)
-{
+try {
     if (!ctx || !d_in || !d_out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
     if (divider <= 0 || width / divider == 0)  // the reference crashes here: foldl1' over an empty window (ImageFilters.hs:59)
         return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
@@ -58,10 +58,10 @@ int bs_bloom_device(bs_ctx *ctx, const void *d_in, void *d_out, int width, int h
                          ctx->bloom_plan_cus > 0 ? ctx->bloom_plan_cus : ctx->n_cu, hip_stream))
         return fail(BS_EDEVICE, "bloom launch failed");
     return release_post(ctx, static_cast<hipStream_t>(hip_stream));
-}
+} catch (...) { return bs::abi_exception("bs_bloom_device"); }
 
 int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider)
-{
+try {
     if (!ctx || !in || !out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     size_t n = (size_t)width * height * 3;
@@ -74,10 +74,10 @@ int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, 
     HIP_TRY(hipMemcpyAsync(out, ctx->d_post[2], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_bloom"); }
 
 int bs_supersample(bs_ctx *ctx, const double *in, double *out, int width2, int height2)
-{
+try {
     if (!ctx || !in || !out || width2 < 0 || height2 < 0) return fail(BS_EINVAL, "bad argument");
     const size_t n_in = (size_t)width2 * height2 * 3, n_out = (size_t)(width2 / 2) * (height2 / 2) * 3;
     if (n_out == 0) return BS_OK;
@@ -94,18 +94,18 @@ int bs_supersample(bs_ctx *ctx, const double *in, double *out, int width2, int h
     HIP_TRY(hipMemcpyAsync(out, ctx->d_post[0], n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_supersample"); }
 
 int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream)
-{
+try {
     if (!ctx || (n_values && (!d_in || !d_out_u8))) return fail(BS_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     if (bs::launch_srgb8((const double *)d_in, (unsigned char *)d_out_u8, n_values, ctx->d_srgb_table, hip_stream)) return fail(BS_EDEVICE, "srgb8 launch failed");
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_srgb8_device"); }
 
 int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
-{
+try {
     if (!ctx || (n_values && (!in || !out))) return fail(BS_EINVAL, "bad argument");
     if (n_values == 0) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -125,7 +125,7 @@ int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
     HIP_TRY(hipMemcpyAsync(out, ctx->d_u8, n_values, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_srgb8"); }
 
 int bs::check_bloom_args(int width, double strength, int divider)
 {
@@ -151,7 +151,7 @@ int bs::enqueue_post_rgb8(bs_ctx *ctx, const double *d_img, int w, int h, double
 }
 
 int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_rgb8, size_t out_bytes)
-{
+try {
     if (!ctx || !cfg || !out_rgb8) return fail(BS_EINVAL, "null argument");
     if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
     auto t0 = std::chrono::steady_clock::now();
@@ -178,7 +178,7 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
     ctx->last_zero_copy = u8_target != ctx->d_u8;
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_render_rgb8"); }
 
 // ---- writeImg's file on the device (png_kernels.hip) --------------------------------------------------------------------------------
 
@@ -191,12 +191,12 @@ int bs::check_png_frame(int width, int height)
 }
 
 int bs_png_bound(int width, int height, size_t *out_bytes)
-{
+try {
     if (!out_bytes) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     *out_bytes = (size_t)bs::png_file_bound(width, height);
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_png_bound"); }
 
 // PNG slot k of the context sized for a w x h frame: the encoder's scratch, the page-locked size slots, and (device_file) a device copy
 // of the file for a caller whose buffer the GPU cannot write.
@@ -236,7 +236,7 @@ static int release_png(bs_ctx *ctx, hipStream_t s)
 }
 
 int bs_encode_png_device(bs_ctx *ctx, const void *d_rgb8, int width, int height, void *d_png, size_t cap, void *d_file_bytes, void *hip_stream)
-{
+try {
     if (!ctx || !d_rgb8 || !d_png || !d_file_bytes) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
@@ -250,7 +250,7 @@ int bs_encode_png_device(bs_ctx *ctx, const void *d_rgb8, int width, int height,
                               static_cast<uint64_t *>(d_file_bytes), s))
         return fail(BS_EDEVICE, "PNG encoder launch failed");
     return release_png(ctx, s);
-}
+} catch (...) { return bs::abi_exception("bs_encode_png_device"); }
 
 // d_u8 (w x h RGB8 in HBM) -> the PNG file in the caller's out_png, on ctx->stream, blocking.  A page-locked out_png is written by the
 // encoder's last kernel itself; otherwise the file is assembled in HBM and exactly its bytes are copied.
@@ -281,7 +281,7 @@ static int png_to_host(bs_ctx *ctx, const unsigned char *d_u8, int w, int h, uns
 }
 
 int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned char *out_png, size_t cap, size_t *out_bytes)
-{
+try {
     if (!ctx || !rgb8 || !out_png || !out_bytes) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
@@ -291,9 +291,9 @@ int bs_encode_png(bs_ctx *ctx, const unsigned char *rgb8, int width, int height,
     StreamDrain drain(ctx);
     HIP_TRY(hipMemcpyAsync(ctx->d_u8, rgb8, n, hipMemcpyHostToDevice, ctx->stream));
     return png_to_host(ctx, ctx->d_u8, width, height, out_png, out_bytes);
-}
+} catch (...) { return bs::abi_exception("bs_encode_png"); }
 int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_png, size_t cap, size_t *out_bytes)
-{
+try {
     if (!ctx || !cfg || !out_png || !out_bytes) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(cfg->width, cfg->height)) return rc;
     auto t0 = std::chrono::steady_clock::now();
@@ -314,5 +314,5 @@ int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int 
     if (rc) return rc;
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_render_png"); }
 

@@ -118,23 +118,23 @@ using namespace bs;
 extern "C" {
 
 int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t out_doubles, void *hip_stream)
-{
+try {
     return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream));
-}
+} catch (...) { return bs::abi_exception("bs_render_device"); }
 int bs_render_rows_device(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, void *d_out_rgb, size_t out_doubles, void *hip_stream)
-{
+try {
     if (row1 < 0) return fail(BS_EINVAL, "row band must satisfy 0 <= row0 < row1 <= height");
     return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream), row0, row1);
-}
+} catch (...) { return bs::abi_exception("bs_render_rows_device"); }
 
 int bs_render(bs_ctx *ctx, const bs_config *cfg, double *out_rgb, size_t out_doubles)
-{
+try {
     if (!cfg) return fail(BS_EINVAL, "null argument");
     return bs_render_rows(ctx, cfg, 0, cfg->height, out_rgb, out_doubles);
-}
+} catch (...) { return bs::abi_exception("bs_render"); }
 
 int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double *out_rgb, size_t out_doubles)
-{
+try {
     if (!ctx || !cfg || !out_rgb) return fail(BS_EINVAL, "null argument");
     if (cfg->width <= 0 || cfg->height <= 0) return fail(BS_EINVAL, "resolution must be positive");
     if (row0 < 0 || row1 > cfg->height || row0 >= row1) return fail(BS_EINVAL, "row band must satisfy 0 <= row0 < row1 <= height");
@@ -196,9 +196,9 @@ int bs_render_rows(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, double
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_render_rows"); }
 int bs_stats(bs_ctx *ctx, bs_stats_t *out)
-{
+try {
     if (!ctx || !out) return fail(BS_EINVAL, "null argument");
     int rc = resolve_stats(ctx);
     if (rc) return rc;
@@ -206,10 +206,10 @@ int bs_stats(bs_ctx *ctx, bs_stats_t *out)
     ctx->stats.zero_copy = ctx->last_zero_copy;
     *out = ctx->stats;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_stats"); }
 
 int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const double *dirs, size_t n, double *out_rgb, int32_t *out_hits)
-{
+try {
     if (!ctx || (n && (!dirs || !out_rgb))) return fail(BS_EINVAL, "null argument");
     if (n == 0) return BS_OK;
     bs::TraceParams p;
@@ -234,6 +234,6 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
     if (out_hits) HIP_TRY(hipMemcpyAsync(out_hits, dh, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_star_lookup"); }
 
 }  // extern "C"

@@ -519,3 +519,30 @@ def test_validate_config_property():
             assert rc == 0, _lib.last_error()
 
     check()
+
+
+def test_no_cpp_exception_can_cross_the_c_abi():
+    """The header promises "never throws across the ABI".  Structural check: every entry point of the product library that has a body of
+    more than one line is a function-try-block ending in bs::abi_exception (std::bad_alloc -> BS_ENOMEM, anything else -> BS_EINTERNAL,
+    message in bs_last_error), and the threads the batch entry points start cannot throw out of them either."""
+    import re
+    csrc = os.path.join(ROOT, "blackstar_amd", "csrc")
+    guarded, bare = set(), set()
+    for fn in ("context.cpp", "render.cpp", "post.cpp", "batch.cpp", "host_math.cpp"):
+        lines = open(os.path.join(csrc, fn)).read().split("\n")
+        for i, ln in enumerate(lines):
+            m = re.match(r'^(?:extern "C" )?(?:int|long|void \*|bs_ctx \*|void|const char \*) ?(bs_\w+)\(', ln)
+            if not m or ln.rstrip().endswith(";"):
+                continue
+            if ln.rstrip().endswith("}"):   # one-line accessors: nothing in them can throw
+                bare.add(m.group(1))
+                continue
+            j = next(k for k in range(i, i + 6) if lines[k] in ("{", "try {"))
+            assert lines[j] == "try {", f"{fn}: {m.group(1)} is not a function-try-block"
+            end = next(k for k in range(j, len(lines)) if lines[k].startswith("}"))
+            assert "bs::abi_exception(\"%s\")" % m.group(1) in lines[end], f"{fn}: {m.group(1)}"
+            guarded.add(m.group(1))
+    assert guarded | bare == set(_lib.SYMBOLS), (guarded | bare) ^ set(_lib.SYMBOLS)
+    assert bare <= {"bs_abi_version", "bs_last_error", "bs_get_mode"}
+    batch = open(os.path.join(csrc, "batch.cpp")).read()
+    assert batch.count("catch (const std::system_error &)") >= 2 and "th.emplace_back(body, c)" in batch   # thread creation failures are handled
