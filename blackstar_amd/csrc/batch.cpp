@@ -115,8 +115,8 @@ static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *c
             HIP_TRY(hipEventRecord(ctx->ev_frame[(k + 1) & 1], cs[(k + 1) & 1]));
         }
         HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_frame[k & 1], 0));
-        HIP_TRY(hipMemcpyAsync(outs[i], buf[k & 1], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+        rc = copy_out(ctx, outs[i], buf[k & 1], (size_t)cfgs[i].width * cfgs[i].height * 3 * sizeof(double), ctx->copy_stream);
+        if (rc) return rc;
     }
     return BS_OK;
 }
@@ -204,8 +204,7 @@ struct PngSlots {
         const size_t bytes = (size_t)ctx->h_png_bytes[k];
         png.sizes[frame[k]] = bytes;
         if (staged[k]) {
-            HIP_TRY(hipMemcpyAsync(outs[frame[k]], ctx->d_png_file[k], bytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            if (int rc = copy_out(ctx, outs[frame[k]], ctx->d_png_file[k], bytes, s)) return rc;
         }
         frame[k] = -1;
         return BS_OK;
@@ -236,6 +235,14 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
     unsigned char *stage[2] = {ctx->d_u8, ctx->d_u8b};
     hipStream_t cs[2] = {ctx->stream, ctx->stream2};
     PngSlots files;
+    // RGB8 frames for PAGEABLE outputs wait in their staging image until the slot is retired: { where to, how many bytes }
+    struct Pending { unsigned char *out = nullptr; size_t bytes = 0; } pageable[2];
+    auto deliver = [&](int b) -> int {   // (the slot's frame has left the device: bs::copy_out moves it without letting the runtime pin caller pages)
+        if (!pageable[b].out) return BS_OK;
+        const int r = copy_out(ctx, pageable[b].out, stage[b], pageable[b].bytes, cs[b]);
+        pageable[b] = Pending{};
+        return r;
+    };
     StreamDrain drain(ctx);  // the caller's outs[] are DMA targets from here on: every return path drains the streams first
     int k = 0;
     for (int i = first; i < n_frames; i += step, k++) {
@@ -244,6 +251,7 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
             HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
             if (done_ms) done_ms->push_back(now_ms());       // (the partition trial: when each frame of the pipeline completed)
             if (png && (rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
+            if ((rc = deliver(b))) return rc;
         }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
         unsigned char *target = stage[b];
@@ -260,16 +268,20 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
             rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], cs[b]);
             if (rc) return rc;
         } else if (target == stage[b]) {
-            HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, cs[b]));
+            pageable[b] = Pending{outs[i], n};
         }
         HIP_TRY(hipEventRecord(ctx->ev_frame[b], cs[b]));
     }
     HIP_TRY(hipStreamSynchronize(cs[0]));
     HIP_TRY(hipStreamSynchronize(cs[1]));
-    for (int b = 0; png && b < 2; b++)
-        if ((rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
+    for (int b = 0; b < 2; b++) {   // (in frame order: the older of the two slots first)
+        const int slot = (k + b) & 1;
+        if (png && (rc = files.retire(ctx, slot, outs, *png, cs[slot]))) return rc;
+        if ((rc = deliver(slot))) return rc;
+    }
     return BS_OK;
 }
+
 // ---- the CU partition: measured, not modelled -----------------------------------------------------------------------------------
 // With the chip partitioned a frame costs trace x n_cu / (n_cu - M), provided the post stage (bloom + sRGB8, + the PNG encoder) confined
 // to M CUs keeps up; on the shared chip it costs trace + post + a hand-over stall (a blur workgroup only ever gets a CU in the drain of a
@@ -457,8 +469,8 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         if (png) {
             rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], ps);
             if (rc) return rc;
-        } else if (target == stage[b]) {
-            HIP_TRY(hipMemcpyAsync(outs[i], stage[b], n, hipMemcpyDeviceToHost, ps));
+        } else if (target == stage[b]) {   // (run_share only partitions shares whose outputs are all page-locked)
+            return fail(BS_EINTERNAL, "the partitioned pipeline was given a pageable output buffer");
         }
         HIP_TRY(hipEventRecord(ctx->ev_posted[b], ps));
     }

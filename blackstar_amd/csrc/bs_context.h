@@ -133,6 +133,11 @@ struct bs_ctx {
     bool png_busy = false;
     // page-locked file buffers bs_render_png_files keeps between calls (page-locking 6 MB costs 1-2 ms): (pointer, capacity)
     std::vector<std::pair<unsigned char *, size_t>> file_pool;
+    // Staging for caller memory that is NOT page-locked (context.cpp: copy_in / copy_out): two page-locked pieces, used alternately
+    static constexpr size_t kStageBytes = size_t(8) << 20;
+    unsigned char *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};   // ev_stage[b] has been recorded behind a DMA that reads stage b and nobody has waited for it yet
     struct VerifiedRange { const void *host = nullptr; size_t bytes = 0; };
     VerifiedRange verified[8];  // host buffers device_alias_of_pinned has walked page by page (registered memory without a queryable range)
     int verified_next = 0;
@@ -180,6 +185,15 @@ bool grow_device(T *&buf, size_t &cap, size_t elems)
     return true;
 }
 
+// Host <-> device copies of CALLER memory.  Page-locked caller memory and pieces of at most 1 MiB go to hipMemcpyAsync as they are; larger
+// PAGEABLE memory is moved through the context's own page-locked staging pieces with a host memcpy, because above 1 MiB the runtime pins the
+// caller's pages on the fly and DMAs them at the caller's address ("HSA Copy Using Pinned resource", 55 GB/s) -- a path on which a GPU memory
+// fault at a host heap address was caught twice in ~30 runs of the GPU suite (a process that allocates and frees multi-megabyte buffers all
+// the time; profiles/EXPERIMENTS.md section 5).  A fault ends the process; 10 GB/s on the path the header calls the slow one does not.
+//   copy_in : enqueued on s; returns once h_src has been consumed (the last pieces may still be in flight ON s, from the staging pieces)
+//   copy_out: BLOCKING -- returns when everything enqueued on s before it has finished and h_dst holds the bytes
+int copy_in(bs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t s);
+int copy_out(bs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, hipStream_t s);
 int ensure_scratch(bs_ctx *ctx, size_t bytes);
 int post_cus_setting(int v);  // BLACKSTAR_POST_CUS as a number: 0 = never partition, otherwise a multiple of 4 in [8, 32]
 int effective_mode(const bs_ctx *ctx, const bs_config *cfg);

@@ -44,13 +44,12 @@ int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int h
     uint64_t *d_bytes = png_bytes_slot(ctx, bs_ctx::kPngSingle);
     if (!d_bytes) return fail(BS_EDEVICE, "hipHostGetDevicePointer failed");
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->d_u8, rgb8, n, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = copy_in(ctx, ctx->d_u8, rgb8, n, ctx->stream))) return rc;
     HIP_TRY(hipDeviceSynchronize());  // (an enqueue-only user of the slot on a caller's stream: a probe may simply wait)
     if (bs::launch_png_encode(ctx->d_u8, width, height, ctx->d_png_scratch[bs_ctx::kPngSingle], ctx->d_png_file[bs_ctx::kPngSingle], d_bytes, ctx->stream,
                               static_cast<unsigned long long *>(ctx->d_scratch)))
         return fail(BS_EDEVICE, "PNG encoder launch failed");
-    HIP_TRY(hipMemcpyAsync(clocks, ctx->d_scratch, nb * bs::kPngPhases * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = copy_out(ctx, clocks, ctx->d_scratch, nb * bs::kPngPhases * sizeof(unsigned long long), ctx->stream))) return rc;
     return BS_OK;
 }
 int bs_debug_set_disk_slots(bs_ctx *ctx, int slots)
@@ -115,10 +114,9 @@ int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n
     int32_t *d_yx = static_cast<int32_t *>(ctx->d_scratch);
     bs_ray_record *d_out = reinterpret_cast<bs_ray_record *>(static_cast<char *>(ctx->d_scratch) + yx_bytes);
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(d_yx, yx, n_rays * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = copy_in(ctx, d_yx, yx, n_rays * 2 * sizeof(int32_t), ctx->stream))) return rc;
     if (bs::launch_trace_records(p, effective_mode(ctx, cfg), d_yx, n_rays, d_out, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
-    HIP_TRY(hipMemcpyAsync(out, d_out, n_rays * sizeof(bs_ray_record), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = copy_out(ctx, out, d_out, n_rays * sizeof(bs_ray_record), ctx->stream))) return rc;
     return BS_OK;
 }
 int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr)
@@ -149,13 +147,12 @@ int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, d
     HIP_TRY(hipSetDevice(ctx->device));
     double *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 4 * n * sizeof(double)));
-    hipError_t e = hipMemcpy(d, a, n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d + n, b, n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && bs::launch_sqrt_div(d, d + n, n, d + 2 * n, d + 3 * n, bare, ctx->stream)) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(out_sqrt, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out_div, d + 3 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    int rc = copy_in(ctx, d, a, n * sizeof(double), ctx->stream);
+    if (!rc) rc = copy_in(ctx, d + n, b, n * sizeof(double), ctx->stream);
+    if (!rc && bs::launch_sqrt_div(d, d + n, n, d + 2 * n, d + 3 * n, bare, ctx->stream)) rc = fail(BS_EDEVICE, "bs_debug_sqrt_div: launch failed");
+    if (!rc) rc = copy_out(ctx, out_sqrt, d + 2 * n, n * sizeof(double), ctx->stream);
+    if (!rc) rc = copy_out(ctx, out_div, d + 3 * n, n * sizeof(double), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(BS_EDEVICE, std::string("bs_debug_sqrt_div: ") + hipGetErrorString(e));
-    return BS_OK;
+    return rc;
 }

@@ -147,6 +147,102 @@ double *device_alias_of_pinned(bs_ctx *ctx, const void *host, size_t bytes, bool
 const char *const kStraddleMsg = "output buffer starts in page-locked memory but is not contained in it (it runs past the end of its hipHostMalloc / "
                                  "hipHostRegister range, e.g. into pageable memory between two registered ranges): neither the kernel nor the runtime's copy can deliver into it";
 
+namespace {
+
+constexpr size_t kDirectCopyBytes = size_t(1) << 20;   // up to here the runtime stages a pageable copy itself (measured: "HSA Copy Using Staging resource")
+
+bool page_locked(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// may the runtime have this caller buffer as it is?
+bool direct_ok(const void *h, size_t bytes)
+{
+    if (bytes <= kDirectCopyBytes) return true;
+    return page_locked(h) && page_locked(static_cast<const char *>(h) + bytes - 1);
+}
+
+int ensure_stage(bs_ctx *ctx)
+{
+    for (int b = 0; b < 2; b++) {
+        if (!ctx->h_stage[b] && hipHostMalloc((void **)&ctx->h_stage[b], bs_ctx::kStageBytes, hipHostMallocDefault) != hipSuccess)
+            return fail(BS_ENOMEM, "hipHostMalloc staging failed");
+        if (!ctx->ev_stage[b]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_stage[b], hipEventDisableTiming));
+    }
+    return BS_OK;
+}
+
+int wait_stage(bs_ctx *ctx, int b)
+{
+    if (ctx->stage_busy[b]) {
+        HIP_TRY(hipEventSynchronize(ctx->ev_stage[b]));
+        ctx->stage_busy[b] = false;
+    }
+    return BS_OK;
+}
+
+}  // namespace
+
+int copy_in(bs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return BS_OK;
+    if (direct_ok(h_src, bytes)) {
+        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+        return BS_OK;
+    }
+    if (int rc = ensure_stage(ctx)) return rc;
+    size_t off = 0;
+    for (int k = 0; off < bytes; k++) {
+        const int b = k & 1;
+        const size_t len = std::min(bs_ctx::kStageBytes, bytes - off);
+        if (int rc = wait_stage(ctx, b)) return rc;   // the DMA that last read this piece has finished
+        std::memcpy(ctx->h_stage[b], static_cast<const char *>(h_src) + off, len);
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_dst) + off, ctx->h_stage[b], len, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(ctx->ev_stage[b], s));
+        ctx->stage_busy[b] = true;
+        off += len;
+    }
+    return BS_OK;
+}
+
+int copy_out(bs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) {
+        HIP_TRY(hipStreamSynchronize(s));
+        return BS_OK;
+    }
+    if (direct_ok(h_dst, bytes)) {
+        HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return BS_OK;
+    }
+    if (int rc = ensure_stage(ctx)) return rc;
+    // piece k lands in staging piece k & 1 while piece k - 1 is copied out of the other one by the host
+    size_t off = 0, prev_off = 0, prev_len = 0;
+    int prev_b = -1;
+    for (int k = 0; off < bytes; k++) {
+        const int b = k & 1;
+        const size_t len = std::min(bs_ctx::kStageBytes, bytes - off);
+        if (int rc = wait_stage(ctx, b)) return rc;   // (a copy_in's last DMA may still be reading it)
+        HIP_TRY(hipMemcpyAsync(ctx->h_stage[b], static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(ctx->ev_stage[b], s));
+        ctx->stage_busy[b] = true;
+        if (prev_b >= 0) {
+            if (int rc = wait_stage(ctx, prev_b)) return rc;
+            std::memcpy(static_cast<char *>(h_dst) + prev_off, ctx->h_stage[prev_b], prev_len);
+        }
+        prev_b = b; prev_off = off; prev_len = len;
+        off += len;
+    }
+    if (int rc = wait_stage(ctx, prev_b)) return rc;
+    std::memcpy(static_cast<char *>(h_dst) + prev_off, ctx->h_stage[prev_b], prev_len);
+    return BS_OK;
+}
+
 // BLACKSTAR_POST_CUS as a number: 0 = never partition, otherwise a multiple of 4 in [8, 32] (rounded down, at least 8)
 int post_cus_setting(int v)
 {
@@ -227,6 +323,11 @@ try {
         fail(BS_EDEVICE, std::string(what) + ": " + hipGetErrorString(r));
         return false;
     };
+    auto up = [&](void *d_dst, const void *h_src, size_t bytes, const char *what) {   // (after the stream exists: the && chain below makes it first)
+        if (bs::copy_in(ctx, d_dst, h_src, bytes, ctx->stream) == BS_OK) return true;
+        fail(BS_EDEVICE, std::string(what) + ": " + bs::error_message());
+        return false;
+    };
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
@@ -237,15 +338,15 @@ try {
                 ok(hipMalloc((void **)&ctx->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(bs::StarNode)), "hipMalloc nodes") &&
                 ok(hipMalloc((void **)&ctx->d_colors, std::max<size_t>(1, colors.size()) * sizeof(bs::StarColor)), "hipMalloc colors") &&
                 ok(hipMalloc((void **)&ctx->d_cell_start, cell_start.size() * sizeof(uint32_t)), "hipMalloc cell_start") &&
-                ok(hipMemcpy(ctx->d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "upload cell_start") &&
+                up(ctx->d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), "upload cell_start") &&
                 ok(hipMalloc((void **)&ctx->d_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long)), "hipMalloc counters") &&
                 ok(hipHostMalloc((void **)&ctx->h_counters, bs_ctx::kSlots * bs::kCounters * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc") &&
-                ok(hipMemcpy(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), hipMemcpyHostToDevice), "upload nodes") &&
-                ok(hipMemcpy(ctx->d_colors, colors.data(), colors.size() * sizeof(bs::StarColor), hipMemcpyHostToDevice), "upload colors");
+                up(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(bs::StarNode), "upload nodes") &&
+                up(ctx->d_colors, colors.data(), colors.size() * sizeof(bs::StarColor), "upload colors");
     if (good) {
         static const std::vector<double> table = [] { std::vector<double> t(257); bs::srgb8_thresholds(t.data()); return t; }();
         good = ok(hipMalloc((void **)&ctx->d_srgb_table, 257 * sizeof(double)), "hipMalloc srgb table") &&
-               ok(hipMemcpy(ctx->d_srgb_table, table.data(), 257 * sizeof(double), hipMemcpyHostToDevice), "upload srgb table");
+               up(ctx->d_srgb_table, table.data(), 257 * sizeof(double), "upload srgb table");
     }
     for (int k = 0; good && k < bs_ctx::kSlots; k++) {
         bs_ctx::LaunchSlot &sl = ctx->slots[k];
@@ -254,10 +355,8 @@ try {
         good = ok(hipEventCreate(&sl.ev0), "hipEventCreate") && ok(hipEventCreate(&sl.ev1), "hipEventCreate") &&
                ok(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming), "hipEventCreate");
     }
-    // The uploads above are hipMemcpy from PAGEABLE host memory on the NULL stream; every kernel of this context runs on NON-BLOCKING
-    // streams, which do not order themselves behind the NULL stream.  A blocking copy may return once the pageable source has been
-    // staged (the documented behaviour of the API family), so the context is only handed out when the device has really finished:
-    // a first kernel that read a half-uploaded cell_start would index the star grid out of bounds (a GPU fault ends the process).
+    // The uploads above are enqueued on the context's stream through its own page-locked staging pieces (bs::copy_in: the std::vectors
+    // are pageable and go out of scope below); the context is only handed out when the device has really finished with them.
     if (good) good = ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
     if (!good) {
         const std::string keep = bs::error_message();
@@ -320,6 +419,10 @@ try {
             if (e) (void)hipEventDestroy(e);
         if (ctx->ev_post) (void)hipEventDestroy(ctx->ev_post);
         if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
+        for (int b = 0; b < 2; b++) {
+            if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
+            if (ctx->ev_stage[b]) (void)hipEventDestroy(ctx->ev_stage[b]);
+        }
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         if (ctx->ev_u0) (void)hipEventDestroy(ctx->ev_u0);
         if (ctx->ev_u1) (void)hipEventDestroy(ctx->ev_u1);

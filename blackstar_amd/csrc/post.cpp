@@ -68,11 +68,12 @@ try {
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = copy_in(ctx, ctx->d_post[2], in, n * sizeof(double), ctx->stream);
+    if (rc) return rc;
     rc = bs_bloom_device(ctx, ctx->d_post[2], ctx->d_post[2], width, height, strength, divider, ctx->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_post[2], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rc = copy_out(ctx, out, ctx->d_post[2], n * sizeof(double), ctx->stream);
+    if (rc) return rc;
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_bloom"); }
 
@@ -85,14 +86,15 @@ try {
     int rc = ensure_post(ctx, n_in);
     if (rc) return rc;
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = copy_in(ctx, ctx->d_post[2], in, n_in * sizeof(double), ctx->stream);
+    if (rc) return rc;
     rc = acquire_post(ctx, ctx->stream);
     if (rc) return rc;
     if (bs::launch_supersample(ctx->d_post[2], ctx->d_post[0], width2, height2, ctx->stream)) return fail(BS_EDEVICE, "supersample launch failed");
     rc = release_post(ctx, ctx->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_post[0], n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rc = copy_out(ctx, out, ctx->d_post[0], n_out * sizeof(double), ctx->stream);
+    if (rc) return rc;
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_supersample"); }
 
@@ -119,11 +121,12 @@ try {
         ctx->u8_cap = n_values;
     }
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->d_post[2], in, n_values * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = copy_in(ctx, ctx->d_post[2], in, n_values * sizeof(double), ctx->stream);
+    if (rc) return rc;
     rc = bs_srgb8_device(ctx, ctx->d_post[2], ctx->d_u8, n_values, ctx->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_u8, n_values, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rc = copy_out(ctx, out, ctx->d_u8, n_values, ctx->stream);
+    if (rc) return rc;
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_srgb8"); }
 
@@ -173,7 +176,10 @@ try {
     if (rc) return rc;
     rc = enqueue_post_rgb8(ctx, ctx->d_post[2], cfg->width, cfg->height, bloom_strength, bloom_divider, u8_target, ctx->n_cu, ctx->stream);
     if (rc) return rc;
-    if (u8_target == ctx->d_u8) HIP_TRY(hipMemcpyAsync(out_rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (u8_target == ctx->d_u8) {
+        rc = copy_out(ctx, out_rgb8, ctx->d_u8, n, ctx->stream);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_zero_copy = u8_target != ctx->d_u8;
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -272,8 +278,8 @@ static int png_to_host(bs_ctx *ctx, const unsigned char *d_u8, int w, int h, uns
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t bytes = (size_t)ctx->h_png_bytes[bs_ctx::kPngSingle];
     if (!alias) {
-        HIP_TRY(hipMemcpyAsync(out_png, ctx->d_png_file[bs_ctx::kPngSingle], bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        rc = copy_out(ctx, out_png, ctx->d_png_file[bs_ctx::kPngSingle], bytes, ctx->stream);
+        if (rc) return rc;
     }
     ctx->last_zero_copy = alias != nullptr;
     *out_bytes = bytes;
@@ -289,7 +295,7 @@ try {
     const size_t n = (size_t)width * height * 3;
     if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(ctx->d_u8, rgb8, n, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = copy_in(ctx, ctx->d_u8, rgb8, n, ctx->stream)) return rc;
     return png_to_host(ctx, ctx->d_u8, width, height, out_png, out_bytes);
 } catch (...) { return bs::abi_exception("bs_encode_png"); }
 int bs_render_png(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, unsigned char *out_png, size_t cap, size_t *out_bytes)

@@ -183,15 +183,15 @@ try {
         if (nb > 1) HIP_TRY(hipEventRecord(ctx->ev_band[b], ctx->stream));
     }
     if (nb == 1) {
-        HIP_TRY(hipMemcpyAsync(out_rgb, ctx->d_img, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (int rc = copy_out(ctx, out_rgb, ctx->d_img, need * sizeof(double), ctx->stream)) return rc;
     } else {
-        for (int b = 0; b < nb; b++) {
+        for (int b = 0; b < nb; b++) {   // (every band's kernel is enqueued already: band b reaches the caller while band b + 1 is traced)
             const int a = cut(b), e = cut(b + 1);
             HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[b], 0));
-            HIP_TRY(hipMemcpyAsync(out_rgb + (size_t)(a - row0) * row_doubles, ctx->d_img + (size_t)(a - row0) * row_doubles,
-                                   (size_t)(e - a) * row_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+            if (int rc = copy_out(ctx, out_rgb + (size_t)(a - row0) * row_doubles, ctx->d_img + (size_t)(a - row0) * row_doubles,
+                                  (size_t)(e - a) * row_doubles * sizeof(double), ctx->copy_stream))
+                return rc;
         }
-        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -228,11 +228,12 @@ try {
     double *d = static_cast<double *>(ctx->d_scratch);
     int32_t *dh = reinterpret_cast<int32_t *>(d + 6 * n);
     StreamDrain drain(ctx);
-    HIP_TRY(hipMemcpyAsync(d, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = copy_in(ctx, d, dirs, 3 * n * sizeof(double), ctx->stream);
+    if (rc) return rc;
     if (bs::launch_star_lookup(p, d, n, d + 3 * n, dh, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
-    HIP_TRY(hipMemcpyAsync(out_rgb, d + 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (out_hits) HIP_TRY(hipMemcpyAsync(out_hits, dh, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rc = copy_out(ctx, out_rgb, d + 3 * n, 3 * n * sizeof(double), ctx->stream);
+    if (rc) return rc;
+    if (out_hits && (rc = copy_out(ctx, out_hits, dh, n * sizeof(int32_t), ctx->stream))) return rc;
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_star_lookup"); }
 
