@@ -128,8 +128,11 @@ int bs_device_count(void);
  * unclamped, already supersample-reduced -- the `Image S RGB Double` layout the Haskell shim wraps.
  * If out_rgb is page-locked memory (bs_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) the kernel writes it
  * directly over PCIe -- no device image and no copy: the call costs the kernel time (C3 frame: 4.6 ms).  Into pageable memory the
- * frame is traced as two consecutive launches of half the rows each, so that the first half's copy to the host overlaps the
- * second half's kernel (5.4 ms into a buffer that has been touched before, 9 ms into a fresh one: first-touch page faults).
+ * frame is traced as two consecutive launches of half the rows each, so that the first half's way to the host overlaps the
+ * second half's kernel (about 6 ms into a buffer that has been touched before, 9 ms into a fresh one: first-touch page faults).
+ * Pageable caller memory is never handed to the HIP runtime in pieces above 1 MiB: it travels through the context's own page-locked
+ * staging pieces and a host memcpy -- the runtime would pin the caller's pages on the fly and DMA at the caller's address, a path
+ * on which a GPU memory fault (which ends the process) was observed under heavy allocate / free traffic of the host application.
  * Pixels and bs_stats are those of the whole frame either way (bs_stats_t.zero_copy says which way it went).
  * A buffer that STARTS in page-locked memory must be contained in that one page-locked range: one that runs past its end (into
  * pageable memory, or across a gap between two hipHostRegister ranges) is refused with BS_EINVAL -- the kernel's stores would fault
@@ -143,8 +146,8 @@ int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t 
 
 /* Page-locked host memory for images ("pinned buffers, no per-frame hipMalloc").  Any host pointer works
  * as an output buffer, but a FRESH pageable buffer costs the operating system's first-touch page faults on top of the copy
- * (measured for a 1080p f64 frame: 9.0 ms per bs_render into newly allocated memory, 5.4 ms into a pageable buffer that is
- * reused, 4.6 ms into one from here; kernel 4.4 ms).  Memory from bs_host_alloc never faults and is written by the trace kernel
+ * (measured for a 1080p f64 frame: 9.0 ms per bs_render into newly allocated memory, about 6 ms into a pageable buffer that is
+ * reused, 4.5 ms into one from here; kernel 4.3 ms).  Memory from bs_host_alloc never faults and is written by the trace kernel
  * itself (zero copy) in bs_render / bs_render_rows / bs_render_split / bs_render_batch.
  * It belongs to the caller until bs_host_free (it may outlive the context; Haskell: newForeignPtr with bs_host_free as
  * finalizer).  Returns NULL on failure. */
