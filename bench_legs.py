@@ -360,7 +360,16 @@ def sustained_leg(bs, torch, np, trees, cfgs, outs, streams, devs, n_frames):
 def frame_digest(np, frame):
     """sha256 of a frame's bytes (a torch tensor resident on any device, or a numpy array).  Untimed: the image crosses PCIe once."""
     import hashlib
-    a = frame.detach().cpu().numpy() if hasattr(frame, "detach") else np.asarray(frame)
+    if hasattr(frame, "detach"):
+        t = frame.detach()
+        if t.is_cuda:   # into PAGE-LOCKED host memory: a pageable destination makes the runtime pin pages on the fly (profiles/EXPERIMENTS.md section 5)
+            import torch
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t)
+            t = host
+        a = t.numpy()
+    else:
+        a = np.asarray(frame)
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
