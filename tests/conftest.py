@@ -25,6 +25,24 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.timeout(240, method="thread"))
 
 
+def to_host(t):
+    """A device tensor as a numpy array, through PAGE-LOCKED host memory when it is large: `.cpu()` into pageable memory above 1 MiB makes
+    the HIP runtime pin pages on the fly and DMA at their address -- the path on which a GPU memory fault was caught in round 4
+    (profiles/EXPERIMENTS.md section 5).  The library avoids it; the tests' own torch copies should too."""
+    import torch
+    if t.is_cuda and t.numel() * t.element_size() > (1 << 20):
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t)
+        return h.numpy()
+    return t.cpu().numpy()
+
+
+def to_device(a):
+    """A numpy array as a device tensor, through page-locked host memory (see to_host)."""
+    import torch
+    return torch.from_numpy(a).pin_memory().cuda()
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     d = {k: z[k] for k in z.files}

@@ -13,7 +13,7 @@ import pytest
 
 import blackstar_amd as bs
 from blackstar_amd import _lib, synthetic
-from conftest import IMAGE_GOLDENS, TRACE_GOLDENS, load_golden
+from conftest import IMAGE_GOLDENS, TRACE_GOLDENS, load_golden, to_device, to_host
 from oracle import scenes
 
 pytestmark = pytest.mark.gpu
@@ -277,7 +277,7 @@ def test_render_device_matches_render_and_batch(tree):
     with torch.cuda.stream(s):
         bs.render_device(cfg, tree, out.data_ptr(), out.numel(), s.cuda_stream)
     s.synchronize()
-    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(to_host(out), ref)
     # batch mode: frames round-robin over contexts (one here)
     L = _lib.lib()
     cfgs = (_lib.BsConfig * 3)(*[_lib.make_config(scenes.with_res(scenes.ani_frame(i, 600), 40, 24)) for i in (0, 300, 599)])
@@ -405,7 +405,7 @@ def test_bloom_and_srgb8_match_oracle(tree, oracle):
     o = torch.empty_like(t)
     _lib.check(_lib.lib().bs_bloom_device(tree.handle, t.data_ptr(), o.data_ptr(), 200, 112, 0.15, 25, None), "bloom_device")
     torch.cuda.synchronize()
-    assert np.array_equal(o.cpu().numpy(), ref)
+    assert np.array_equal(to_host(o), ref)
 
 
 def test_cpp_host_mirror(tmp_path, oracle):
@@ -499,7 +499,7 @@ def test_maximum_size_frame_2_pow_28_pixels(tree):
         for y, x in ((0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (H // 2, W // 2), (12345, 6789)):
             rec = bs.trace_rays(cfg, tree, [2 * y, 2 * y + 1, 2 * y, 2 * y + 1], [2 * x, 2 * x, 2 * x + 1, 2 * x + 1])   # the order of ImageFilters.hs:94-96
             want = 0.25 * (((rec["rgba"][0, :3] + rec["rgba"][1, :3]) + rec["rgba"][2, :3]) + rec["rgba"][3, :3])
-            assert np.array_equal(out[y, x].cpu().numpy(), want), (y, x)
+            assert np.array_equal(to_host(out[y, x]), want), (y, x)
         del out, band
         torch.cuda.empty_cache()
     finally:
@@ -1043,7 +1043,7 @@ def test_renders_on_different_streams_of_one_context_are_independent(tree):
             bs.render_device(cfg_b if i % 2 else cfg_a, tree, o.data_ptr(), o.numel(), s.cuda_stream)
         torch.cuda.synchronize()
         for i, o in enumerate(outs):
-            assert np.array_equal(o.cpu().numpy(), ref_b if i % 2 else ref_a), f"launch {i} on its own stream lost tiles"
+            assert np.array_equal(to_host(o), ref_b if i % 2 else ref_a), f"launch {i} on its own stream lost tiles"
         st = tree.stats()
         assert (st["rays"], st["steps"], st["escaped"]) == (st_b["rays"], st_b["steps"], st_b["escaped"])
     finally:
@@ -1127,7 +1127,7 @@ def test_batch_split_and_stats_on_every_visible_device(catalogue_bytes):
             o = torch.empty((54, 96, 3), dtype=torch.float64, device=f"cuda:{d}")
             bs.render_device(cfgs[0], t, o.data_ptr(), o.numel(), torch.cuda.current_stream(d).cuda_stream)
             torch.cuda.synchronize(d)
-            assert np.array_equal(o.cpu().numpy(), ref[0])
+            assert np.array_equal(to_host(o), ref[0])
     finally:
         for t in trees:
             t.close()
@@ -1188,7 +1188,7 @@ def test_bloom_device_unaligned_and_aliased_buffers(tree, oracle):
     t = torch.from_numpy(img).to("cuda:0")
     _lib.check(L.bs_bloom_device(tree.handle, t.data_ptr(), t.data_ptr(), 160, 90, 0.15, 25, None), "bloom in place")
     torch.cuda.synchronize()
-    assert np.array_equal(t.cpu().numpy(), ref)
+    assert np.array_equal(to_host(t), ref)
     big = torch.zeros(img.size + 1, dtype=torch.float64, device="cuda:0")
     view = big[1:]
     assert view.data_ptr() % 16 == 8
@@ -1196,7 +1196,7 @@ def test_bloom_device_unaligned_and_aliased_buffers(tree, oracle):
     out = torch.empty(img.size, dtype=torch.float64, device="cuda:0")
     _lib.check(L.bs_bloom_device(tree.handle, view.data_ptr(), out.data_ptr(), 160, 90, 0.15, 25, None), "bloom unaligned")
     torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy().reshape(90, 160, 3), ref)
+    assert np.array_equal(to_host(out).reshape(90, 160, 3), ref)
 
 
 def test_bloom_on_different_streams_of_one_context_is_ordered(tree, oracle):
@@ -1218,7 +1218,7 @@ def test_bloom_on_different_streams_of_one_context_is_ordered(tree, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(host, refs[0])
     for i, (o, r) in enumerate(zip(outs, refs)):
-        assert np.array_equal(o.cpu().numpy(), r), f"bloom {i} on its own stream saw another call's scratch"
+        assert np.array_equal(to_host(o), r), f"bloom {i} on its own stream saw another call's scratch"
 
 
 def test_stats_survive_the_reuse_of_their_launch_slot(tree):

@@ -10,6 +10,8 @@ import zlib
 import numpy as np
 import pytest
 
+from conftest import to_device, to_host  # noqa: E402
+
 from tests import png_emul
 from tests.conftest import load_golden
 
@@ -472,7 +474,7 @@ def test_encode_png_device_is_enqueue_only(tree):
     import blackstar_amd as bs
     from blackstar_amd import _lib
     img = frame_like(120, 200, 11)
-    d_img = torch.from_numpy(img).cuda()
+    d_img = to_device(img)
     d_png = torch.zeros(bs.png_bound(120, 200), dtype=torch.uint8, device="cuda")
     d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
     s = torch.cuda.Stream()
