@@ -18,6 +18,7 @@ from oracle import scenes
 
 pytestmark = pytest.mark.gpu
 
+_KEEP_REGISTERED_REGIONS = []   # see test_zero_copy_only_inside_one_page_locked_range
 RTOL_STRICT, ATOL_STRICT = 1e-12, 1e-14
 RTOL_FAST, ATOL_FAST = 1e-4, 1e-7  # BASELINE.json north_star / SURVEY 8d "Parity check"
 
@@ -1585,7 +1586,14 @@ def test_zero_copy_only_inside_one_page_locked_range(tree):
         hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
         hip.hipHostUnregister.argtypes = [C.c_void_p]
         page = 4096
-        raw = np.zeros(4 * (1 << 20) + page, np.uint8)
+        # An anonymous mapping of its own that lives until the process ends -- NOT a malloc'ed numpy buffer: after hipHostUnregister of a
+        # part of a malloc'ed block, ANY later pageable hipMemcpy above 1 MiB that touches the recycled address faults on the GPU (a runtime
+        # issue reproduced without this library: scripts/pageable_copy_stress.py, profiles/r04_pageable_copy_stress.txt).
+        import mmap
+        region = mmap.mmap(-1, 4 * (1 << 20) + page)
+        _KEEP_REGISTERED_REGIONS.append(region)
+        raw = np.frombuffer(region, np.uint8)
+        raw[:] = 0
         base = (raw.ctypes.data + page - 1) // page * page
         a0, a1, b0, b1 = 0, 512 << 10, 1 << 20, 3 << 20          # [a0,a1) and [b0,b1) page-locked, [a1,b0) left pageable
         assert hip.hipHostRegister(base + a0, a1 - a0, 0) == 0 and hip.hipHostRegister(base + b0, b1 - b0, 0) == 0
