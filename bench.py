@@ -309,15 +309,20 @@ def run_ranks(args):
         def validate():
             vcfg = cfg if frames_cfg is None else frames_cfg[0]
             digests = []
-            for _ in range(2 if rank == 0 else 1):   # rank 0 twice: run-to-run determinism
-                out.zero_()
-                bs.render_device(vcfg, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
-                torch.cuda.synchronize()
-                digests.append(frame_digest(np, out))
-            vst = tree.stats()
-            got = gather_objs((digests[0], {k: int(vst[k]) for k in COUNTERS}))
+            try:   # a rank that fails here still takes part in the gather below (with a digest no other rank can have): the line says invalid, nobody hangs
+                for _ in range(2 if rank == 0 else 1):   # rank 0 twice: run-to-run determinism
+                    out.zero_()
+                    bs.render_device(vcfg, tree, out.data_ptr(), out.numel(), stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    digests.append(frame_digest(np, out))
+                vst = tree.stats()
+                mine = (digests[0], {k: int(vst[k]) for k in COUNTERS})
+            except Exception as e:
+                print(f"bench.py: validation render failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                mine = (f"rank {rank} failed: {type(e).__name__}: {e}", {k: 0 for k in COUNTERS})
+            got = gather_objs(mine)
             what = "the workload's frame" if frames_cfg is None else "frame 0 of the animation"
-            return validation_block(got, what + ", rendered once more on every rank after the timed region (untimed)", digests[1] if rank == 0 else None)
+            return validation_block(got, what + ", rendered once more on every rank after the timed region (untimed)", digests[1] if rank == 0 and len(digests) > 1 else None)
         validation = optional_leg("validation", world == 1, validate)
 
     d2h = None
