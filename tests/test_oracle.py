@@ -514,7 +514,29 @@ def test_ghc_pin_kit_is_complete_and_consistent():
     assert shim in quoted
     header = open(os.path.join(repo, "include", "blackstar_gpu.h")).read()
     bound = re.findall(r'foreign import ccall (?:safe|unsafe)\s+"&?(bs_\w+)"', shim)
-    assert len(bound) >= 9 and all(re.search(r"\b%s\(" % b, header) for b in bound), bound
+    assert len(bound) >= 11 and all(re.search(r"\b%s\(" % b, header) for b in bound), bound
+    # the multi-GPU batch path (north_star: frames sharded over the GPUs of a node) is bound too, and every import is USED
+    assert {"bs_device_count", "bs_render_png_files", "bs_render_batch", "bs_create", "bs_render", "bs_destroy"} <= set(bound)
+    for hs_name in re.findall(r'foreign import ccall (?:safe|unsafe)\s+"[^"]+"\s+(\w+)', shim):
+        assert len(re.findall(r"\b%s\b" % hs_name, shim)) >= 2, f"{hs_name} is imported and never used"
+    # arity of each import = the number of parameters the header declares for it
+    for name, sig in re.findall(r'foreign import ccall (?:safe|unsafe)\s+"(bs_\w+)"\s+\w+\s*::\s*(.*?)(?=\nforeign|\n--|\n\n)', shim, re.S):
+        depth, arrows = 0, 0
+        for a, b in zip(sig, sig[1:] + " "):
+            depth += a == "("
+            depth -= a == ")"
+            arrows += depth == 0 and a == "-" and b == ">"
+        decl = re.search(r"\b%s\(([^;]*?)\);" % name, header, re.S).group(1).strip()
+        n_params = 0 if decl in ("", "void") else decl.count(",") + 1
+        assert arrows == n_params, (name, arrows, n_params, sig)
+    batch = open(os.path.join(root, "BatchMain.hs")).read()
+    assert batch in quoted and "BatchMain.hs" in stanza
+    exported = re.search(r"module RaytracerFFI \((.*?)\) where", shim, re.S).group(1).replace("\n", " ")
+    for fn in ("withGpuTrees", "renderScenesToFiles", "renderBatch", "renderPure"):
+        assert fn in exported and re.search(r"^%s ::" % fn, shim, re.M), fn
+    assert "renderScenesToFiles gpus jobs" in batch
+    # massiv re-exports Prelude / Control.Monad names: the shim must not import it unqualified wholesale (ambiguous `zip`, `forM_` ...)
+    assert not re.search(r"^import\s+Data\.Massiv\.Array\s*(as \w+)?\s*$", shim, re.M)
     version = re.search(r"#define BS_ABI_VERSION (\d+)", header).group(1)
     assert f"this shim expects {version}" in shim and "RaytracerFFI.hs" in stanza and "-fno-code" in stanza
     verdict = os.path.join(repo, "tests", "golden", "ghc", "shim_typecheck.txt")

@@ -29,9 +29,10 @@ for set in uniform clustered; do
   mkdir -p "$REPO/tests/golden/ghc"
   rm -rf "$REPO/tests/golden/ghc/$set" && cp -r "$REF/tools/ghc_pin/out/$set" "$REPO/tests/golden/ghc/$set"
 done
-# the FFI shim of INTEGRATION.md section 1: type-checked against the reference's own modules (no GPU, no library needed for that)
-cp "$HERE/RaytracerFFI.hs" "$REF/tools/ghc_pin/RaytracerFFI.hs"
-if (cd "$REF" && stack ghc -- -fno-code -isrc tools/ghc_pin/RaytracerFFI.hs) > "$REPO/tests/golden/ghc/shim_typecheck.log" 2>&1; then
+# the FFI shim of INTEGRATION.md section 1 and the batch-mode edit of doStart (BatchMain imports RaytracerFFI, so one command checks
+# both): type-checked against the reference's own modules (no GPU, no library needed for that)
+cp "$HERE/RaytracerFFI.hs" "$HERE/BatchMain.hs" "$REF/tools/ghc_pin/"
+if (cd "$REF" && stack ghc -- -fno-code -Wall -isrc -itools/ghc_pin tools/ghc_pin/RaytracerFFI.hs tools/ghc_pin/BatchMain.hs) > "$REPO/tests/golden/ghc/shim_typecheck.log" 2>&1; then
   echo "OK" > "$REPO/tests/golden/ghc/shim_typecheck.txt"
 else
   echo "FAILED (see shim_typecheck.log)" > "$REPO/tests/golden/ghc/shim_typecheck.txt"
