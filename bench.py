@@ -53,8 +53,40 @@ from bench_legs import *  # noqa: E402,F401,F403  (the legs, the workloads table
 from bench_legs import CATALOGUES, COUNTERS, WORKLOADS  # noqa: E402,F401  (named for the readers of this file)
 
 
-def cpu_baseline(cfg, star_bytes, budget_s):
-    """Time the C oracle (restatement of the reference CPU path; GHC is unavailable) on a bounded sample."""
+PARITY_TOLERANCE = "|gpu - cpu| <= 1e-4 * |cpu| + 1e-7 per channel per output pixel (SURVEY.md 8d 'Parity check'; north_star: 1e-4 relative)"
+PARITY_COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
+
+
+def parity_block(np, what, ref, ref_st, got, got_st, mode):
+    """One config's frame from the HIP library (got) against the CPU oracle's frame of the SAME config and catalogue (ref): the numbers
+    SURVEY.md 8d / BASELINE.md section 3 ask for beside the timing.  The oracle is the checker here, never the thing measured."""
+    ref = np.asarray(ref, np.float64)
+    got = np.asarray(got, np.float64)
+    if ref.shape != got.shape:
+        return {"config": what, "mode": mode, "error": f"shapes differ: oracle {ref.shape}, gpu {got.shape}", "outside_1e-4": int(ref.size)}
+    diff = np.abs(got - ref)
+    finite = np.isfinite(got)
+    bad = ~(diff <= 1e-4 * np.abs(ref) + 1e-7)   # (a NaN on either side counts as outside)
+    big = np.abs(ref) > 1e-3
+    counters = {k: [int(ref_st[k]), int(got_st[k])] for k in PARITY_COUNTERS}
+    blk = {"config": what, "mode": mode, "values": int(ref.size), "outside_1e-4": int(bad.sum()), "nonfinite": int((~finite).sum()),
+           "max_abs": float(np.nanmax(diff)) if diff.size else 0.0,
+           "max_rel_where_ref>1e-3": float(np.nanmax(diff[big] / np.abs(ref[big]))) if big.any() else 0.0,
+           "bit_identical": bool(np.array_equal(ref, got)),
+           "steps_equal": counters["steps"][0] == counters["steps"][1] and counters["rays"][0] == counters["rays"][1],
+           "fates_equal": all(counters[k][0] == counters[k][1] for k in ("capped", "horizon", "escaped", "disk_hits", "star_hits")),
+           "counters_oracle_gpu": counters}
+    if blk["outside_1e-4"]:
+        ys, xs, cs = np.nonzero(bad)
+        blk["first_outside"] = [{"y": int(y), "x": int(x), "channel": int(c), "oracle": float(ref[y, x, c]), "gpu": float(got[y, x, c])}
+                                for y, x, c in list(zip(ys, xs, cs))[:4]]
+    return blk
+
+
+def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None):
+    """Time the C oracle (restatement of the reference CPU path; GHC is unavailable) on a bounded sample -- and, since the oracle's
+    frames are computed anyway, compare them with the frames the HIP library renders of the same configs (gpu_render(cfg, stars, mode)
+    -> (image, stats), the product called through its C ABI): the `parity` list.  No extra oracle time."""
     from oracle import c_oracle, scenes
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # a container CPU quota (cgroup v2 cpu.max = "<quota> <period>") caps the cores that really run
@@ -73,20 +105,39 @@ def cpu_baseline(cfg, star_bytes, budget_s):
     w = max(16, int(cfg["width"] * scale) // 16 * 16)
     h = max(9, w * cfg["height"] // cfg["width"])
     sample = scenes.with_res(cfg, w, h)
-    _, st = c_oracle.render(sample, ix, threads=threads)
+    img, st = c_oracle.render(sample, ix, threads=threads)
     # BASELINE configs[0] (the reference's own CPU-runnable case), whole: default.yaml at 640x480, no supersampling, no star map
-    _, st1 = c_oracle.render(scenes.with_res(scenes.DEFAULT, 640, 480), c_oracle.Index(None), threads=threads)
+    cfg1 = scenes.with_res(scenes.DEFAULT, 640, 480)
+    img1, st1 = c_oracle.render(cfg1, c_oracle.Index(None), threads=threads)
     c1 = {"value": 640 * 480 / st1["seconds"] / 1e6, "unit": "Mpixel/s", "seconds": st1["seconds"], "rays": int(st1["rays"]),
           "config": "scenes/default.yaml 640x480, no supersampling, no star map (BASELINE configs[0]), the whole frame"}
     # BASELINE configs[1], whole: default.yaml 1920x1080, no supersampling, no star map (SURVEY 8d asks for C1, C2 and C3)
-    _, st2 = c_oracle.render(scenes.DEFAULT, c_oracle.Index(None), threads=threads)
+    img2, st2 = c_oracle.render(scenes.DEFAULT, c_oracle.Index(None), threads=threads)
     c2 = {"value": 1920 * 1080 / st2["seconds"] / 1e6, "unit": "Mpixel/s", "seconds": st2["seconds"], "rays": int(st2["rays"]),
           "config": "scenes/default.yaml 1920x1080, no supersampling, no star map (BASELINE configs[1]), the whole frame"}
-    return {"value": w * h / st["seconds"] / 1e6, "unit": "Mpixel/s", "cores": int(st["threads"]), "kind": "port", "configs0": c1, "configs1": c2,
-            "rays_per_s": st["rays"] / st["seconds"], "seconds": st["seconds"],
-            "sample": f"the workload's camera and scene at {w}x{h} output px ({'4x supersampled = ' if ss > 1 else ''}{st['rays']} rays), "
-                      f"{'same %d-star catalogue' % len(ix.stars) if star_bytes else 'no star map'}, "
-                      f"C restatement of the reference CPU path (oracle/blackstar_oracle.c, -O2, pthreads over rows)"}
+    res = {"value": w * h / st["seconds"] / 1e6, "unit": "Mpixel/s", "cores": int(st["threads"]), "kind": "port", "configs0": c1, "configs1": c2,
+           "rays_per_s": st["rays"] / st["seconds"], "seconds": st["seconds"],
+           "sample": f"the workload's camera and scene at {w}x{h} output px ({'4x supersampled = ' if ss > 1 else ''}{st['rays']} rays), "
+                     f"{'same %d-star catalogue' % len(ix.stars) if star_bytes else 'no star map'}, "
+                     f"C restatement of the reference CPU path (oracle/blackstar_oracle.c, -O2, pthreads over rows)"}
+    if gpu_render is not None:
+        whole = (w, h) == (cfg["width"], cfg["height"])
+        jobs = [("the timed workload" + ("" if whole else f" at the CPU sample's resolution {w}x{h}") + " (BASELINE configs[2] camera, scene and catalogue)"
+                 if star_bytes else "the timed workload" + ("" if whole else f" at {w}x{h}"), sample, bool(star_bytes), img, st, ("fast",)),
+                ("scenes/default.yaml 1920x1080, no supersampling, no star map (BASELINE configs[1]), the whole frame", dict(scenes.DEFAULT), False, img2, st2,
+                 ("fast", "strict")),
+                ("scenes/default.yaml 640x480, no supersampling, no star map (BASELINE configs[0]), the whole frame", cfg1, False, img1, st1, ("fast",))]
+        res["parity"] = []
+        for what, c, stars_, ref, ref_st, modes in jobs:
+            for mode in modes:
+                try:
+                    got, got_st = gpu_render(c, stars_, mode)
+                    res["parity"].append(parity_block(np, what, ref, ref_st, got, got_st, mode))
+                except Exception as e:  # a leg that cannot run is reported as failing parity, not dropped
+                    res["parity"].append({"config": what, "mode": mode, "error": f"{type(e).__name__}: {e}", "outside_1e-4": -1})
+        res["parity_tolerance"] = PARITY_TOLERANCE
+        res["parity_ok"] = all(p.get("outside_1e-4") == 0 and p.get("steps_equal") and p.get("fates_equal") for p in res["parity"])
+    return res
 
 
 def parse_args():
@@ -173,7 +224,18 @@ def run_ranks(args):
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     rccl = None
-    if world > 1:
+    # BLACKSTAR_BENCH_FORCE_DIST=1 (set by `--launcher torchrun --gpus 1`): one rank still goes through init_process_group, the all_gathers,
+    # the barrier, all_gather_object, --gather's dist.gather and destroy_process_group -- the RCCL branch executed on ONE GPU, so that an
+    # API misuse surfaces on a 1-GPU box instead of on the 8-GPU lease.  The numbers are those of world 1.
+    dist_on = world > 1 or os.environ.get("BLACKSTAR_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:   # no launcher around a forced world-1 run
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -224,12 +286,12 @@ def run_ranks(args):
         # every rank's GPU work has finished BEFORE any rank passes the barrier (a rank that is still executing must not overlap a
         # neighbour's timed region when ranks share a device in the smoke modes), and RCCL's own barrier kernel has finished after it
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
     def all_ranks(x):  # every rank's value of a float, in rank order
-        if world == 1:
+        if not dist_on:
             return [float(x)]
         dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
         t = torch.tensor([x], dtype=torch.float64, device=dev)
@@ -238,7 +300,7 @@ def run_ranks(args):
         return [float(v.item()) for v in allt]
 
     def gather_objs(o):  # every rank's (small, picklable) object, in rank order -- validation only, never inside a timed region
-        if world == 1:
+        if not dist_on:
             return [o]
         objs = [None] * world
         dist.all_gather_object(objs, o)
@@ -266,7 +328,7 @@ def run_ranks(args):
         gc.disable()
         for _ in range(args.warmup):
             step()
-        if world > 1 and args.gather:
+        if dist_on and args.gather:
             gather_to_root()  # also establishes RCCL's point-to-point channels outside the timed region
         fence()
         t0 = time.perf_counter()
@@ -276,7 +338,7 @@ def run_ranks(args):
             step()
             b.record(s)
         t_gather = None
-        if world > 1 and args.gather:
+        if dist_on and args.gather:
             torch.cuda.synchronize()
             tg = time.perf_counter()
             gather_to_root()
@@ -330,7 +392,7 @@ def run_ranks(args):
     if want:
         d2h = optional_leg("with_d2h", world == 1 and resident,
                            lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x)),
-                                             same_frames=frames_obj is None, all_ranks=all_ranks if world > 1 else None,
+                                             same_frames=frames_obj is None, all_ranks=all_ranks if dist_on else None,
                                              split=lambda: split_leg(bs, np, [tree], rank, world, fence, lambda x: max(all_ranks(x)), gather_objs)))
 
     def sustained_block():
@@ -342,7 +404,7 @@ def run_ranks(args):
         fence()
         ms_all = all_ranks(per_dev[0]["ms_per_frame"])
         devices = smp.summary()
-        if world > 1:  # every rank sampled its own device: collect them in rank order
+        if dist_on:  # every rank sampled its own device: collect them in rank order
             objs = [None] * world
             dist.all_gather_object(objs, devices)
             devices = [d for o in objs for d in (o or [None])]
@@ -360,7 +422,8 @@ def run_ranks(args):
         if world == 1 and not args.no_boundary and frames_cfg is None and resident:
             peak = optional_leg("measure_peak", True, lambda: measure_peak(tree, _lib))
             peak = None if isinstance(peak, dict) and "error" in peak else peak
-        extra = {"backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else "none (single rank)",
+        extra = {"backend": ("RCCL (nccl)" if backend == "nccl" else backend) + ("" if world > 1 else " -- forced at world 1: BLACKSTAR_BENCH_FORCE_DIST")
+                            if dist_on else "none (single rank)",
                  "devices_visible": ndev, "oversubscribed": world > ndev, "launches_in_flight_per_gpu": n_streams,
                  "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])]}
         if n_streams > 1:
@@ -401,7 +464,21 @@ def run_ranks(args):
             both = optional_leg("boundary", True, lambda: boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream))
             res["boundary"], res["strict"] = both if isinstance(both, tuple) else (both, both)
         if world == 1 and args.cpu_seconds > 0:
-            res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds))
+            def gpu_render(c, with_stars_, mode):   # the product, through bs_render (C ABI), in the named arithmetic; the oracle only checks it
+                t = tree if with_stars_ else bs.StarTree(None, device=local_rank)
+                before = t.get_mode()
+                try:
+                    t.set_mode(_lib.BS_MODE_FAST if mode == "fast" else _lib.BS_MODE_STRICT)
+                    image = bs.render(c, t)
+                    return image, t.stats()
+                finally:
+                    if t is tree:
+                        t.set_mode(before)
+                    else:
+                        t.close()
+            res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds, gpu_render, np))
+            if isinstance(res["cpu_baseline"], dict) and "parity_ok" in res["cpu_baseline"] and "valid" in res:
+                res["valid"] = bool(res["valid"]) and bool(res["cpu_baseline"]["parity_ok"])   # a fast frame that differs from the reference's is not a result
         if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and args.workload == "default-aa":
             # LAST: the profiler's child processes run after every timed leg of this process (a PMC session may leave the device in
             # another clock state for a while), and only the counter values are taken from them
@@ -413,7 +490,7 @@ def run_ranks(args):
             res["roofline"].update({k: fresh[k] for k in ("traffic", "traffic_kind", "traffic_source")})
         print(json.dumps(res), flush=True)
     tree.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
@@ -603,6 +680,8 @@ def reexec_under_torchrun(args):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus == 1:
+        env["BLACKSTAR_BENCH_FORCE_DIST"] = "1"   # one rank, and still every torch.distributed call of the N > 1 path (see run_ranks)
     if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
         env.setdefault("BLACKSTAR_BENCH_BACKEND", "gloo")  # smoke mode: ranks share devices, RCCL needs one device per rank
     argv = [a for a in sys.argv[1:]]
@@ -613,10 +692,12 @@ def reexec_under_torchrun(args):
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" in os.environ or args.gpus == 1:
+    if "WORLD_SIZE" in os.environ:
         run_ranks(args)
     elif args.launcher == "torchrun":
         reexec_under_torchrun(args)
+    elif args.gpus == 1:
+        run_ranks(args)
     else:
         run_single_process(args)
 

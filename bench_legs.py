@@ -8,7 +8,7 @@ import subprocess
 import sys
 import time
 
-__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "d2h_forms", "png_files_leg", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "COUNTERS", "validation_block", "per_config_block", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "split_headline", "result_line"]
+__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "d2h_forms", "png_files_leg", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "split_headline", "result_line"]
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -446,6 +446,53 @@ def per_config_block(bs, torch, np, _lib, tree, args, device):
     return res
 
 
+def predict_bands(bs, np, tree, cfg, H, W, n_bands=8, reps=2):
+    """What an n_bands-GPU split of this frame will be limited by, measured on ONE device: each of the n_bands
+    contiguous row bands bs_render_split would hand to a GPU is rendered alone (bs_render_rows into a page-locked band, like the split
+    itself) and its executed steps, kernel time (hipEvent, bs_stats) and blocking-call time are recorded.  Two bounds follow: the WORK
+    bound sum(steps) / (n * max band steps) -- what equal-height bands cost because central rows trace longer geodesics -- and the
+    MEASURED bound sum(band call ms) / max(band call ms), which also carries the fixed cost per launch (each band pays the ~0.25 ms
+    launch tail a whole frame pays once).  predicted_speedup_bound = one device's whole-frame call / the slowest band's call."""
+    from blackstar_amd.distributed import shard_rows
+    bands = [shard_rows(H, k, n_bands) for k in range(n_bands)]
+    buf = bs.alloc_image(tree, max(b - a for a, b in bands), W)
+    steps, kernel_ms, call_ms = [], [], []
+    for a, b in bands:
+        out = buf[: b - a]
+        bs.render_rows(cfg, tree, a, b, out=out)   # untimed
+        ks, cs = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            bs.render_rows(cfg, tree, a, b, out=out)
+            cs.append((time.perf_counter() - t0) * 1e3)
+            st = tree.stats()
+            ks.append(float(st["kernel_ms"]))
+        steps.append(int(st["steps"]))
+        kernel_ms.append(float(np.mean(ks)))
+        call_ms.append(float(np.mean(cs)))
+    whole = []
+    full = bs.alloc_image(tree, H, W)
+    bs.render(cfg, tree, out=full)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        bs.render(cfg, tree, out=full)
+        whole.append((time.perf_counter() - t0) * 1e3)
+    st = tree.stats()
+    whole_ms, whole_kernel = float(np.mean(whole)), float(st["kernel_ms"])
+    tot = float(sum(steps))
+    return {"n_bands": n_bands, "bands": [list(b) for b in bands], "band_steps": steps, "band_kernel_ms": [round(x, 4) for x in kernel_ms],
+            "band_call_ms": [round(x, 4) for x in call_ms], "whole_frame_call_ms": whole_ms, "whole_frame_kernel_ms": whole_kernel,
+            "steps_max_over_mean": max(steps) / (tot / n_bands) if tot else None,
+            "work_bound": tot / (n_bands * max(steps)) * n_bands if tot else None,
+            "kernel_bound": whole_kernel / max(kernel_ms) if max(kernel_ms) > 0 else None,
+            "predicted_speedup_bound": whole_ms / max(call_ms) if max(call_ms) > 0 else None,
+            "fixed_ms_per_band": (sum(kernel_ms) - whole_kernel) / n_bands,
+            "note": f"every one of the {n_bands} row bands an {n_bands}-GPU bs_render_split cuts, rendered alone on ONE device (mean of {reps}): "
+                    "work_bound = sum(steps) / max(band steps) (equal-height bands, central rows cost more); kernel_bound and "
+                    "predicted_speedup_bound = the whole frame on one device / the slowest band (kernel time; blocking call) -- the latter two "
+                    "include the fixed cost every launch pays (fixed_ms_per_band = (sum of band kernels - whole-frame kernel) / bands)"}
+
+
 def split_leg(bs, np, trees, rank, world, fence, max_over_ranks, gather_objs, reps=3):
     """ONE frame of BASELINE configs[3] (lensing-disk at 3840x2160, 4x supersample) cut into row bands over all GPUs -- SURVEY 8e's
     fallback for a single huge frame.  One process with N contexts: bs_render_split (one host thread per context, every GPU writes its
@@ -492,7 +539,11 @@ def split_leg(bs, np, trees, rank, world, fence, max_over_ranks, gather_objs, re
         bands = [g[2] for g in got]
         entry = "bs_render_rows (one band per rank)"
     dt, dt_one = float(np.mean(ts)), float(np.mean(one))
-    return {"Mpixel_s": W * H / dt / 1e6, "ms_per_frame": dt * 1e3, "ms_each": [round(t * 1e3, 4) for t in ts], "seconds": dt, "frames": 1,
+    try:   # (after the timed calls; one device, no collective: every rank may do it, rank 0's is printed)
+        prediction = predict_bands(bs, np, trees[0], cfg, H, W, 8, reps=2) if rank == 0 else None
+    except Exception as e:
+        prediction = {"error": f"{type(e).__name__}: {e}"}
+    return {"prediction_8_gpus": prediction, "Mpixel_s": W * H / dt / 1e6, "ms_per_frame": dt * 1e3, "ms_each": [round(t * 1e3, 4) for t in ts], "seconds": dt, "frames": 1,
             "parts": n_parts, "bands": [list(b) for b in bands], "entry_point": entry,
             "one_device_ms_per_frame": dt_one * 1e3, "one_device_Mpixel_s": W * H / dt_one / 1e6, "speedup_vs_one_device": dt_one / dt,
             "identical_to_one_device": identical, "one_device_steps": ref_steps, "bytes_to_host_per_frame": W * H * 24,

@@ -64,6 +64,9 @@ class StarTree:
     def set_mode(self, mode: int) -> None:
         _lib.check(_lib.lib().bs_set_mode(self.handle, mode), "bs_set_mode")
 
+    def get_mode(self) -> int:
+        return int(_lib.lib().bs_get_mode(self.handle))
+
     def set_max_steps(self, n: int) -> None:
         _lib.check(_lib.lib().bs_set_max_steps(self.handle, n), "bs_set_max_steps")
 

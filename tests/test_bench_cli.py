@@ -322,6 +322,11 @@ def test_split_leg_single_process_and_per_rank():
     assert r["identical_to_one_device"] and r["parts"] == 3 and r["entry_point"] == "bs_render_split" and r["bands"] == [[0, 720], [720, 1440], [1440, 2160]]
     assert ("split", 3) in calls and r["one_device_steps"] == 123456789 and abs(r["speedup_vs_one_device"] - r["one_device_ms_per_frame"] / r["ms_per_frame"]) < 1e-9
     assert r["frames"] == 1 and abs(r["Mpixel_s"] - W * H / r["seconds"] / 1e6) < 1e-6
+    # ... and what an 8-GPU split will be limited by, from one device: the 8 bands rendered alone, their steps and times, the bounds
+    p = r["prediction_8_gpus"]
+    assert p["n_bands"] == 8 and p["bands"][0] == [0, 270] and p["bands"][-1] == [1890, 2160] and len(p["band_steps"]) == len(p["band_kernel_ms"]) == len(p["band_call_ms"]) == 8
+    assert [c for c in calls if c[0] == "rows"][:2] == [("rows", 0, 270), ("rows", 0, 270)] and p["steps_max_over_mean"] == 1.0 and p["work_bound"] == 8.0
+    assert p["predicted_speedup_bound"] > 0 and abs(p["kernel_bound"] - 1.0) < 1e-12 and abs(p["fixed_ms_per_band"] - (8 * 19.0 - 19.0) / 8) < 1e-9
     calls.clear()
     # rank 1 of 4: its band against its own whole frame, and every rank's whole frame is the same frame
     gathered = []
@@ -342,3 +347,84 @@ def test_split_leg_single_process_and_per_rank():
     assert res["scaling"] == "strong" and res["steps"] == 1 and res["config"]["baseline_config"] == "configs[3]" and "split" in res and "roofline" in res
     assert res["config"]["parallelism"] == "row bands x4" and "lensing-disk" in res["metric"]
     json.dumps(res)
+
+
+def test_parity_block_counts_what_is_outside_the_bar():
+    """SURVEY.md 8d 'Parity check': per config, the count of values outside |gpu - cpu| <= 1e-4 |cpu| + 1e-7, max abs / rel error, and
+    whether the step and fate counters equal the oracle's -- in the driver-run line, not only in builder-run reports."""
+    rng = np.random.default_rng(5)
+    ref = rng.random((9, 16, 3)) * 2
+    st = {"rays": 144, "steps": 32000, "capped": 0, "horizon": 10, "escaped": 134, "disk_hits": 20, "star_hits": 30}
+    same = bench.parity_block(np, "cfg", ref, st, ref.copy(), dict(st), "strict")
+    assert same["outside_1e-4"] == 0 and same["bit_identical"] and same["steps_equal"] and same["fates_equal"] and same["max_abs"] == 0 and same["values"] == ref.size
+    near = bench.parity_block(np, "cfg", ref, st, ref * (1 + 5e-5), dict(st), "fast")
+    assert near["outside_1e-4"] == 0 and not near["bit_identical"] and 4e-5 < near["max_rel_where_ref>1e-3"] < 6e-5
+    got = ref.copy()
+    got[3, 5, 1] *= 1 + 3e-4
+    got[0, 0, 0] = np.nan
+    off = bench.parity_block(np, "cfg", ref, st, got, dict(st, steps=st["steps"] - 1, horizon=11), "fast")
+    assert off["outside_1e-4"] == 2 and off["nonfinite"] == 1 and not off["steps_equal"] and not off["fates_equal"]
+    assert {(p["y"], p["x"], p["channel"]) for p in off["first_outside"]} == {(3, 5, 1), (0, 0, 0)}
+    assert off["counters_oracle_gpu"]["steps"] == [32000, 31999]
+    assert bench.parity_block(np, "cfg", ref, st, ref[:4], dict(st), "fast")["outside_1e-4"] == ref.size
+    json.dumps(off)
+
+
+def test_cpu_baseline_carries_parity_for_the_timed_frame_and_configs_0_and_1(monkeypatch):
+    """cpu_baseline keeps the oracle's frames (it used to throw them away) and compares them with what the product renders of the same
+    configs: FAST on the timed workload's sample, FAST + STRICT on configs[1], FAST on configs[0].  One value outside the bar, or a step
+    count that differs, makes parity_ok False (and bench.py then prints "valid": false)."""
+    from oracle import c_oracle, scenes
+    from blackstar_amd import synthetic
+    monkeypatch.setattr(scenes, "DEFAULT", scenes.with_res(scenes.DEFAULT, 160, 90))    # (the whole 1080p frames take the oracle seconds each)
+    star_bytes = synthetic.catalogue_bytes("synthetic")
+    ix = c_oracle.Index(c_oracle.read_ppm(star_bytes))
+    calls = []
+
+    def product(c, with_stars, mode):   # stands in for bs_render here (no GPU): the same arithmetic as the checker
+        calls.append((c["width"], c["height"], with_stars, mode))
+        return c_oracle.render(c, ix if with_stars else c_oracle.Index(None), threads=0)
+
+    cfg = dict(scenes.DEFAULT_AA)
+    blk = bench.cpu_baseline(cfg, star_bytes, 0.05, product, np)
+    assert blk["kind"] == "port" and blk["cores"] >= 1 and blk["value"] > 0
+    assert [(p["mode"]) for p in blk["parity"]] == ["fast", "fast", "strict", "fast"] and blk["parity_ok"]
+    assert all(p["outside_1e-4"] == 0 and p["bit_identical"] and p["steps_equal"] and p["fates_equal"] for p in blk["parity"])
+    assert "BASELINE configs[2]" in blk["parity"][0]["config"] and "configs[1]" in blk["parity"][1]["config"] and "configs[0]" in blk["parity"][3]["config"]
+    assert calls[0][2] is True and calls[1][2] is False and calls[3][:2] == (640, 480) and "1e-4" in blk["parity_tolerance"]
+
+    def wrong(c, with_stars, mode):
+        img, st = product(c, with_stars, mode)
+        img.flat[int(np.argmax(img))] *= 1.001      # (one value of each frame, 10x outside the bar)
+        return img, st
+
+    assert not bench.cpu_baseline(cfg, star_bytes, 0.05, wrong, np)["parity_ok"]
+
+    def crashes(c, with_stars, mode):
+        raise RuntimeError("bs_render: BS_EDEVICE")
+
+    blk = bench.cpu_baseline(cfg, star_bytes, 0.05, crashes, np)
+    assert not blk["parity_ok"] and all("BS_EDEVICE" in p["error"] for p in blk["parity"])
+    assert "parity" not in bench.cpu_baseline(cfg, star_bytes, 0.05)      # no product to check (nothing renders on the CPU instead)
+
+
+def test_launcher_torchrun_with_one_gpu_forces_the_distributed_branch(monkeypatch):
+    """`bench.py --gpus 1 --launcher torchrun` = one rank under torch.distributed.run with BLACKSTAR_BENCH_FORCE_DIST=1: the whole RCCL
+    branch of run_ranks (init_process_group, all_gathers, barrier, all_gather_object, gather, destroy) executes on a 1-GPU box."""
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--launcher", "torchrun", "--gather"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    assert seen["env"]["BLACKSTAR_BENCH_FORCE_DIST"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "--nproc-per-node=1" in seen["cmd"] and "127.0.0.1" in seen["cmd"] and seen["cmd"][-5:] == ["--gpus", "1", "--launcher", "torchrun", "--gather"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'dist_on = world > 1 or os.environ.get("BLACKSTAR_BENCH_FORCE_DIST") == "1"' in src
+    assert "if world > 1:\n        dist." not in src            # every collective of run_ranks hangs on dist_on, so the forced run executes them all
