@@ -293,8 +293,13 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
     err, dt_local, size, files = None, float("inf"), 0, None
     try:
         paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
+        # untimed warm-up over at least WARM_PER_CONTEXT frames per context (like d2h_forms): bs_render_png_files cuts a call into pieces of
+        # 16 frames per context, and the partition trial (a warm-up segment plus three 8-frame segments, 32-40 frames) must have ENDED
+        # before the timed call -- otherwise the timed region contains trial segments (possibly a starved 8-CU one), not the remembered choice
+        warm_calls = max(1, -(-WARM_PER_CONTEXT * len(trees) // max(len(frame_objs), 1)))
         try:
-            bs.render_png_files(frame_objs, trees, paths)
+            for _ in range(warm_calls):
+                bs.render_png_files(frame_objs, trees, paths)
         except Exception as e:  # a failing rank still goes through the same fences and collectives as the others
             err = f"{type(e).__name__}: {e}"
         fence()
@@ -322,7 +327,7 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
     per_gpu = len(frame_objs) / len(trees)
     return {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
             "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
-            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same,
+            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same, "warm_up_calls": warm_calls,
             "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device, write(2) by a native writer thread while the next frames render "
                     "(app/Main.hs:68-77 incl. writeImg's write)"}
 

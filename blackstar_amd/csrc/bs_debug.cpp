@@ -15,21 +15,24 @@
 
 using namespace bs;
 
+// Every entry point is a function-try-block ending in bs::abi_exception, like the product's (std::vector, std::string and bs::fail can
+// throw; an exception must not travel through ctypes into std::terminate).  The one-line getters cannot throw.
+
 int bs_debug_abi_check(void)
-{
+try {
     if (bs_abi_version() != BS_ABI_VERSION) return fail(BS_EINTERNAL, "libblackstar_gpu_debug.so was built against another BS_ABI_VERSION than the libblackstar_gpu.so that is loaded");
     if (bs::ctx_layout_bytes() != sizeof(bs_ctx)) return fail(BS_EINTERNAL, "libblackstar_gpu_debug.so and libblackstar_gpu.so are builds of different trees (context layout differs): rebuild both");
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_debug_abi_check"); }
 
 int bs_debug_srgb8_table(double table[257])
-{
+try {
     if (!table) return fail(BS_EINVAL, "null argument");
     bs::srgb8_thresholds(table);
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_debug_srgb8_table"); }
 int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int height, unsigned long long *clocks, size_t n_clocks)
-{
+try {
     if (!ctx || !rgb8 || !clocks) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     const size_t nb = bs::png_block_count(width, height);
@@ -51,19 +54,19 @@ int bs_debug_png_phases(bs_ctx *ctx, const unsigned char *rgb8, int width, int h
         return fail(BS_EDEVICE, "PNG encoder launch failed");
     if ((rc = copy_out(ctx, clocks, ctx->d_scratch, nb * bs::kPngPhases * sizeof(unsigned long long), ctx->stream))) return rc;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_debug_png_phases"); }
 int bs_debug_set_disk_slots(bs_ctx *ctx, int slots)
-{
+try {
     if (!ctx || slots < 0 || slots > 4) return fail(BS_EINVAL, "bad slots");
     ctx->disk_slots = slots;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_debug_set_disk_slots"); }
 int bs_debug_last_post_cus(const bs_ctx *ctx) { return ctx ? ctx->last_post_cus : BS_EINVAL; }
 
 int bs_debug_last_trial(const bs_ctx *ctx) { return ctx ? ctx->last_trial : BS_EINVAL; }
 
 int bs_debug_partition_choice(const bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int bloom_divider, int png, double ms[3])
-{
+try {
     if (!ctx || !cfg) return fail(BS_EINVAL, "null argument");
     const bs_ctx::PartitionKey key{cfg->width, cfg->height, cfg->supersampling ? 1 : 0, bloom_strength != 0 ? bloom_divider : 0, png ? 1 : 0,
                                    effective_mode(ctx, cfg)};
@@ -73,23 +76,25 @@ int bs_debug_partition_choice(const bs_ctx *ctx, const bs_config *cfg, double bl
         return c.post_cus;
     }
     return -1;
-}
+} catch (...) { return bs::abi_exception("bs_debug_partition_choice"); }
 
 int bs_debug_pick_partition(const double *ms, const int *cus, int n)
-{
+try {
     if (!ms || !cus || n <= 0) return fail(BS_EINVAL, "bad argument");
     return bs::pick_partition(ms, cus, n);
-}
+} catch (...) { return bs::abi_exception("bs_debug_pick_partition"); }
 
 int bs_debug_forget_partitions(bs_ctx *ctx)
-{
+try {
     if (!ctx) return fail(BS_EINVAL, "null argument");
     ctx->partition_cache.clear();
+    ctx->trial = {};      // a half-finished trial's segment times must not carry into the next measurement
+    ctx->last_trial = 0;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_debug_forget_partitions"); }
 
 long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_start, int32_t *entry_star, size_t cap)
-{
+try {
     if ((n_stars && !stars) || !cell_start || (cap && !entry_star)) return BS_EINVAL;
     std::vector<bs::StarNode> nodes;
     std::vector<bs::StarColor> colors;
@@ -98,10 +103,10 @@ long bs_debug_star_grid(const bs_star *stars, size_t n_stars, uint32_t *cell_sta
     std::copy(cs.begin(), cs.end(), cell_start);
     for (size_t k = 0; k < nodes.size() && k < cap; k++) entry_star[k] = nodes[k].id;
     return (long)nodes.size();
-}
+} catch (...) { return (long)bs::abi_exception("bs_debug_star_grid"); }
 
 int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n_rays, bs_ray_record *out)
-{
+try {
     if (!ctx || !cfg || (n_rays && (!yx || !out))) return fail(BS_EINVAL, "null argument");
     bs::TraceParams p;
     int rc = fill_params(ctx, cfg, p);
@@ -118,9 +123,9 @@ int bs_trace_rays(bs_ctx *ctx, const bs_config *cfg, const int32_t *yx, size_t n
     if (bs::launch_trace_records(p, effective_mode(ctx, cfg), d_yx, n_rays, d_out, ctx->stream)) return fail(BS_EDEVICE, "kernel launch failed");
     if ((rc = copy_out(ctx, out, d_out, n_rays * sizeof(bs_ray_record), ctx->stream))) return rc;
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_trace_rays"); }
 int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr)
-{
+try {
     if (!ctx || !out_ms || blocks <= 0 || iters <= 0) return fail(BS_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     double *d = nullptr;
@@ -138,10 +143,10 @@ int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms
     *out_ms = ms;
     if (out_ginstr) *out_ginstr = (double)blocks * 256.0 * iters * 32.0 / 1e9;  // lane-instructions, in 1e9
     return BS_OK;
-}
+} catch (...) { return bs::abi_exception("bs_debug_ubench"); }
 
 int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, double *out_sqrt, double *out_div, int bare)
-{
+try {
     if (!ctx || (n && (!a || !b || !out_sqrt || !out_div))) return fail(BS_EINVAL, "null argument");
     if (n == 0) return BS_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -155,4 +160,4 @@ int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, d
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-}
+} catch (...) { return bs::abi_exception("bs_debug_sqrt_div"); }

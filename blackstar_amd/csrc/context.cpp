@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "bs_context.h"
 
 namespace bs {
@@ -47,6 +49,21 @@ int abi_exception(const char *where) noexcept
 }
 
 size_t ctx_layout_bytes() { return sizeof(bs_ctx); }
+
+// Waits for everything the context has enqueued anywhere: its own streams, then every event it recorded behind work on a caller's stream.
+// (hipEventSynchronize on an event that was never recorded returns at once.)  The device is set by the caller.
+static void quiesce(bs_ctx *ctx)
+{
+    { StreamDrain own(ctx); }
+    for (bs_ctx::LaunchSlot &sl : ctx->slots)
+        if (sl.used && sl.ev_done) (void)hipEventSynchronize(sl.ev_done);
+    for (hipEvent_t e : {ctx->ev_post, ctx->ev_png, ctx->ev_frame[0], ctx->ev_frame[1], ctx->ev_stage[0], ctx->ev_stage[1]})
+        if (e) (void)hipEventSynchronize(e);
+    for (hipEvent_t e : ctx->ev_traced)
+        if (e) (void)hipEventSynchronize(e);
+    for (hipEvent_t e : ctx->ev_posted)
+        if (e) (void)hipEventSynchronize(e);
+}
 
 StreamDrain::~StreamDrain()
 {
@@ -151,19 +168,33 @@ namespace {
 
 constexpr size_t kDirectCopyBytes = size_t(1) << 20;   // up to here the runtime stages a pageable copy itself (measured: "HSA Copy Using Staging resource")
 
-bool page_locked(const void *p)
+// Is [h, h + bytes) inside ONE page-locked range from end to end?  The same containment test device_alias_of_pinned makes, with the driver's
+// range attributes: probing the two ends is not enough (a buffer that starts in one hipHostRegister range and ends in another, with pageable
+// memory between them, passes that), and the runtime would then either refuse the copy or pin the pageable middle on the fly -- the very
+// path the staging exists to avoid.  Anything that cannot be PROVED contained is staged.
+bool inside_one_page_locked_range(const void *h, size_t bytes)
 {
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost) return true;
-    (void)hipGetLastError();
-    return false;
+    if (hipPointerGetAttributes(&a, h) != hipSuccess || a.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    void *base = nullptr;
+    size_t size = 0;
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, const_cast<void *>(h)) != hipSuccess || !base ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, const_cast<void *>(h)) != hipSuccess || !size) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const char *hb = static_cast<const char *>(base), *hp = static_cast<const char *>(h);
+    return hp >= hb && bytes <= size && static_cast<size_t>(hp - hb) <= size - bytes;
 }
 
 // may the runtime have this caller buffer as it is?
 bool direct_ok(const void *h, size_t bytes)
 {
     if (bytes <= kDirectCopyBytes) return true;
-    return page_locked(h) && page_locked(static_cast<const char *>(h) + bytes - 1);
+    return inside_one_page_locked_range(h, bytes);
 }
 
 int ensure_stage(bs_ctx *ctx)
@@ -296,7 +327,10 @@ try {
         fail(BS_EDEVICE, e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no such HIP device");
         return nullptr;
     }
-    bs_ctx *ctx = new (std::nothrow) bs_ctx();
+    // Owned until the very end: anything below that throws (std::bad_alloc in build_star_index, in a vector or a message string) lands in
+    // the function's catch with the half-made context -- its streams, events and device memory -- destroyed on the way out.
+    std::unique_ptr<bs_ctx, void (*)(bs_ctx *)> owner(new (std::nothrow) bs_ctx(), bs_destroy);
+    bs_ctx *ctx = owner.get();
     if (!ctx) { fail(BS_ENOMEM, "out of host memory"); return nullptr; }
     ctx->device = device;
     ctx->n_stars = n_stars;
@@ -357,14 +391,15 @@ try {
     }
     // The uploads above are enqueued on the context's stream through its own page-locked staging pieces (bs::copy_in: the std::vectors
     // are pageable and go out of scope below); the context is only handed out when the device has really finished with them.
-    if (good) good = ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    // (The context's OWN stream, not the device: a host application with other streams on this device does not stall on a bs_create.)
+    if (good) good = ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     if (!good) {
         const std::string keep = bs::error_message();
-        bs_destroy(ctx);
+        owner.reset();   // bs_destroy
         (void)fail(BS_EDEVICE, keep);
         return nullptr;
     }
-    return ctx;
+    return owner.release();
 } catch (...) { (void)bs::abi_exception("bs_create"); return nullptr; }
 int bs_device_count(void)
 try {
@@ -379,7 +414,11 @@ void bs_destroy(bs_ctx *ctx)
 try {
     if (!ctx) return;
     if (ctx->device >= 0 && hipSetDevice(ctx->device) == hipSuccess) {
-        (void)hipDeviceSynchronize();
+        // Everything THIS context enqueued has finished before its memory goes -- and nothing else is waited for: the context's own streams,
+        // and, for work the caller had enqueued on streams of their own (*_device entry points), the event the context recorded behind it
+        // (every launch slot's ev_done, the blur / PNG scratch's ev_post / ev_png).  No hipDeviceSynchronize: other users of the device
+        // (a host application's own streams, other contexts) are not stalled by a bs_destroy.
+        bs::quiesce(ctx);
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
         if (ctx->d_cell_start) (void)hipFree(ctx->d_cell_start);

@@ -44,7 +44,7 @@ def scene(i):
 
 
 out = dict(scenes=0, values=0, outside_tolerance=0, fate_mismatch_scenes=0, step_mismatch_scenes=0, disk_hit_mismatch_scenes=0,
-           star_hit_mismatch_scenes=0, star_hits=0, escaped=0, fast_scenes_traced_in_strict=0, worst_abs=0.0, worst_rel=0.0, nonfinite_scenes=0, bad=[], sky=SKY, stars=len(tree))
+           star_hit_mismatch_scenes=0, star_hits=0, escaped=0, fast_scenes_traced_in_strict=0, worst_abs=0.0, worst_rel=0.0, worst_rel_scene=None, nonfinite_scenes=0, bad=[], sky=SKY, stars=len(tree))
 for i in range(N):
     cfg = scene(i)
     tree.set_mode(_lib.BS_MODE_STRICT); a = bs.render(cfg, tree); sa = tree.stats()
@@ -57,7 +57,15 @@ for i in range(N):
     out["outside_tolerance"] += bad
     out["worst_abs"] = max(out["worst_abs"], float(np.nanmax(d)))
     m = np.abs(a) > 1e-3
-    if m.any(): out["worst_rel"] = max(out["worst_rel"], float(np.nanmax(d[m] / np.abs(a[m]))))
+    if m.any():
+        rel = np.where(m, d / np.where(m, np.abs(a), 1.0), 0.0)
+        worst = float(np.nanmax(rel))
+        if worst > out["worst_rel"]:   # NAME the worst case: the scene, the pixel, both values -- tests/test_gpu_parity.py replays it against the oracle
+            y, x, c = (int(v) for v in np.unravel_index(int(np.nanargmax(rel)), rel.shape))
+            out["worst_rel"] = worst
+            out["worst_rel_scene"] = dict(index=i, cfg=cfg, pixel=[y, x, c], strict=float(a[y, x, c]), fast=float(b[y, x, c]),
+                                          effective_mode_of_fast=["strict", "fast"][int(sb["effective_mode"])],
+                                          steps=[int(sa["steps"]), int(sb["steps"])], star_hits=[int(sa["star_hits"]), int(sb["star_hits"])])
     f = (sa["horizon"], sa["escaped"], sa["capped"]) != (sb["horizon"], sb["escaped"], sb["capped"])
     out["fate_mismatch_scenes"] += int(f)
     out["step_mismatch_scenes"] += int(sa["steps"] != sb["steps"])

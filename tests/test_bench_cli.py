@@ -109,7 +109,8 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     W = bench.WARM_PER_CONTEXT * 3   # the warm-up call is long enough for every context to measure the frame shape (the partition trial)
     assert W >= 32 * 3
     assert [c[:3] for c in calls] == [("batch", W, 3), ("batch", 30, 3), ("rgb8", W, 3), ("rgb8", 30, 3), ("png", W, 3), ("png", 30, 3),
-                                      ("files", 30, 3), ("files", 30, 3)]  # warm-up call, timed call
+                                      ] + [("files", 30, 3)] * 6  # warm-up call(s), timed call; png-files warms up 5 x 30 >= W frames too
+    assert res["png_files"]["warm_up_calls"] == 5
     assert res["png_files"]["bytes_written_per_frame"] == 77 and res["png_files"]["frames"] == 30 and res["png_files"]["entry_point"] == "bs_render_png_files"
     del calls[6:]
     assert res["png_batch"]["entry_point"] == "bs_render_png_batch" and res["png_batch"]["bytes_to_host_per_frame"] == 40   # the mean file size
