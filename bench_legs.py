@@ -461,38 +461,40 @@ def predict_bands(bs, np, tree, cfg, H, W, n_bands=8, reps=2):
     from blackstar_amd.distributed import shard_rows
     bands = [shard_rows(H, k, n_bands) for k in range(n_bands)]
     buf = bs.alloc_image(tree, max(b - a for a, b in bands), W)
-    steps, kernel_ms, call_ms = [], [], []
-    for a, b in bands:
-        out = buf[: b - a]
-        bs.render_rows(cfg, tree, a, b, out=out)   # untimed
-        ks, cs = [], []
-        for _ in range(reps):
+    full = bs.alloc_image(tree, H, W)
+    for _ in range(3):   # the chip's clocks are up before anything is timed (they drop within a millisecond of idling and need ~8 launches / 35 ms to come back)
+        bs.render(cfg, tree, out=full)
+    # passes over all bands, the FASTEST pass of each band kept: a band is a 2-3 ms launch, so a clock ramp or a host hiccup is a large
+    # relative error, and it is the steady state an 8-GPU run sees that is being predicted
+    steps = [0] * n_bands
+    kernel_ms, call_ms = [float("inf")] * n_bands, [float("inf")] * n_bands
+    for rep in range(reps + 1):   # (pass 0 untimed: buffers touched)
+        for k, (a, b) in enumerate(bands):
+            out = buf[: b - a]
             t0 = time.perf_counter()
             bs.render_rows(cfg, tree, a, b, out=out)
-            cs.append((time.perf_counter() - t0) * 1e3)
+            dt = (time.perf_counter() - t0) * 1e3
             st = tree.stats()
-            ks.append(float(st["kernel_ms"]))
-        steps.append(int(st["steps"]))
-        kernel_ms.append(float(np.mean(ks)))
-        call_ms.append(float(np.mean(cs)))
-    whole = []
-    full = bs.alloc_image(tree, H, W)
-    bs.render(cfg, tree, out=full)
+            steps[k] = int(st["steps"])
+            if rep:
+                kernel_ms[k] = min(kernel_ms[k], float(st["kernel_ms"]))
+                call_ms[k] = min(call_ms[k], dt)
+    whole, whole_k = [], []
     for _ in range(reps):
         t0 = time.perf_counter()
         bs.render(cfg, tree, out=full)
         whole.append((time.perf_counter() - t0) * 1e3)
-    st = tree.stats()
-    whole_ms, whole_kernel = float(np.mean(whole)), float(st["kernel_ms"])
+        whole_k.append(float(tree.stats()["kernel_ms"]))
+    whole_ms, whole_kernel = float(min(whole)), float(min(whole_k))
     tot = float(sum(steps))
     return {"n_bands": n_bands, "bands": [list(b) for b in bands], "band_steps": steps, "band_kernel_ms": [round(x, 4) for x in kernel_ms],
             "band_call_ms": [round(x, 4) for x in call_ms], "whole_frame_call_ms": whole_ms, "whole_frame_kernel_ms": whole_kernel,
             "steps_max_over_mean": max(steps) / (tot / n_bands) if tot else None,
-            "work_bound": tot / (n_bands * max(steps)) * n_bands if tot else None,
+            "work_bound": tot / max(steps) if tot else None,
             "kernel_bound": whole_kernel / max(kernel_ms) if max(kernel_ms) > 0 else None,
             "predicted_speedup_bound": whole_ms / max(call_ms) if max(call_ms) > 0 else None,
             "fixed_ms_per_band": (sum(kernel_ms) - whole_kernel) / n_bands,
-            "note": f"every one of the {n_bands} row bands an {n_bands}-GPU bs_render_split cuts, rendered alone on ONE device (mean of {reps}): "
+            "note": f"every one of the {n_bands} row bands an {n_bands}-GPU bs_render_split cuts, rendered alone on ONE device after a warm-up (fastest of {reps} passes): "
                     "work_bound = sum(steps) / max(band steps) (equal-height bands, central rows cost more); kernel_bound and "
                     "predicted_speedup_bound = the whole frame on one device / the slowest band (kernel time; blocking call) -- the latter two "
                     "include the fixed cost every launch pays (fixed_ms_per_band = (sum of band kernels - whole-frame kernel) / bands)"}
@@ -545,7 +547,7 @@ def split_leg(bs, np, trees, rank, world, fence, max_over_ranks, gather_objs, re
         entry = "bs_render_rows (one band per rank)"
     dt, dt_one = float(np.mean(ts)), float(np.mean(one))
     try:   # (after the timed calls; one device, no collective: every rank may do it, rank 0's is printed)
-        prediction = predict_bands(bs, np, trees[0], cfg, H, W, 8, reps=2) if rank == 0 else None
+        prediction = predict_bands(bs, np, trees[0], cfg, H, W, 8, reps=3) if rank == 0 else None
     except Exception as e:
         prediction = {"error": f"{type(e).__name__}: {e}"}
     return {"prediction_8_gpus": prediction, "Mpixel_s": W * H / dt / 1e6, "ms_per_frame": dt * 1e3, "ms_each": [round(t * 1e3, 4) for t in ts], "seconds": dt, "frames": 1,

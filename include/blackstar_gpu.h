@@ -61,9 +61,12 @@ enum {
  * FAST:   the same discrete RK4 map evaluated in the ray's orbital plane with FMA-accumulated stage sums and
  *         r^-5 from v_rsq_f64 + a 2nd-order series correction.  Step counts, fates and disk crossings equal
  *         STRICT's on every ray tested; pixel values agree with STRICT to 3.4e-8 absolute / 3.7e-7 relative
- *         on the BASELINE frames and to 6.5e-7 relative at worst over the committed fuzz runs (profiles/r02_fuzz_modes_10000.json:
- *         10 000 scenes, 267 M values, worst 6.5e-7; r02_fuzz_modes_20000.json: 20 000 other scenes on the final library, 536 M values, worst 2.8e-7)
- *         -- inside the 1e-4 relative bar, not bit-exact.  Two guards keep it there (without them the fuzz's worst
+ *         on the BASELINE frames; over the committed 100 000-scene fuzz runs (profiles/r05_fuzz_modes_100000.json, 2.7e9 values each) the worst
+ *         is 1.1e-6 relative on a uniform sky and 2.3e-5 on a CLUSTERED one (r05_fuzz_modes_clustered_100000.json) -- inside the 1e-4 relative bar
+ *         by 4x at worst, not bit-exact.  The clustered figure is the star lookup's doing, not the integrator's: a star's weight
+ *         exp(-d^2 / (2 * 0.0005^2)) (src/StarMap.hs:99-110) turns a terminal-direction difference e into up to 6000 e of relative difference,
+ *         and its scene -- stepSize 0.05 from 318 radii away, 14 000 steps per ray, e = 4e-9, a pixel summing a dense cluster band -- is
+ *         replayed by name against the oracle in tests/test_gpu_parity.py (FUZZ_WORST).  Two guards keep it there (without them the fuzz's worst
  *         case was 2.3e-5: rays grazing the photon sphere amplify any rounding difference): a ray that orbits the
  *         hole (more steps than the longest straight path plus one photon-sphere circumference; a few per million)
  *         is re-traced with STRICT arithmetic inside the same kernel, and a frame whose stepSize exceeds 0.5 (the
@@ -213,8 +216,10 @@ int bs_render_rgb8(bs_ctx *ctx, const bs_config *cfg, double bloom_strength, int
  * 16 | 24 | 32 (always that many) overrides.  The CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags):
  * a host application that keeps the NULL stream of the device busy from another thread during this call serialises the pipeline
  * against its own work -- correct, but the overlap is lost; BLACKSTAR_POST_CUS=0 avoids those streams altogether.  Page-locked outs[i]
- * (bs_host_alloc) are written by the last kernel itself.  Blocking; byte-identical to bs_render_rgb8 frame by frame whichever way a
- * frame was made; bs_stats is not updated. */
+ * (bs_host_alloc) are written by the last kernel itself.  PAGEABLE outs[i] are the slow form, here and in bs_render_batch: a frame is
+ * delivered through the context's page-locked staging and a host memcpy (never pinned on the fly, see bs_render) BEFORE the frame after
+ * next is enqueued, so during each delivery only one frame is on the GPU, not two -- use bs_host_alloc buffers for the documented overlap.
+ * Blocking; byte-identical to bs_render_rgb8 frame by frame whichever way a frame was made; bs_stats is not updated. */
 int bs_render_rgb8_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                          const int *bloom_dividers, unsigned char *const *outs);
 

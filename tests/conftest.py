@@ -172,3 +172,41 @@ def disk_inner_edge_offsets_vs_reference_example(img, tau=0.15):
             else:
                 k += 1
     return np.array(out)
+
+
+def disk_law_vs_reference_example(trace_intensity):
+    """The ARGUMENT of the disk's intensity law (src/Raytracer.hs:106-110: sin (pi * ((rO - r)/(rO - rI))^2)) against the reference repository's
+    example.png, via tests/golden/reference_example_disk_colour.npz (make_reference_disk_colour.py): 8 000 pixels of the picture whose ray
+    meets the disk exactly once.  trace_intensity(cfg, ys, xs) -> (I, disk_hits) is the implementation under test tracing THOSE pixels of the
+    example's scene with a white disk of opacity 1 (one crossing: rgba = I exactly).  What is compared is monotone-invariant -- how the
+    picture's blue channel (the one that does not clip) RANKS the pixels, and where along the disk its profile peaks -- because the
+    picture's colour, amplitude and bloom belong to an unknown scene and an older revision.
+    Returns a dict: rho of the implementation's I, rho of alternative laws on the fixture's radii, the peak radius of the picture."""
+    from scipy import stats
+    from oracle import scenes
+    g = np.load(os.path.join(GOLDEN, "reference_example_disk_colour.npz"))
+    ys, xs, rgb, r = g["ys"].astype(np.int64), g["xs"].astype(np.int64), g["rgb"].astype(np.float64), g["r"]
+    rI, rO = float(g["disk_inner"]), float(g["disk_outer"])
+    cfg = dict(scenes.with_res(scenes.DEFAULT, int(g["width"]), int(g["height"])), disk_inner=rI, disk_outer=rO, disk_opacity=1.0,
+               disk_hsi=(0.0, 0.0, 1.0), star_intensity=0.0)
+    I, hits = trace_intensity(cfg, ys, xs)
+    blue = rgb[:, 2]
+    ok = blue < 250                                      # unclipped
+    t = (rO - r) / (rO - rI)
+
+    def rho(v):
+        return float(stats.spearmanr(np.asarray(v)[ok], blue[ok]).statistic)
+
+    lin = np.where(blue / 255 <= 0.04045, blue / 255 / 12.92, ((blue / 255 + 0.055) / 1.055) ** 2.4)
+    edges = np.arange(rI, rO + 1e-9, 0.125)
+    which = np.digitize(r, edges)
+    prof = np.array([np.median(lin[which == k]) if (which == k).sum() > 10 else np.nan for k in range(1, len(edges))])
+    top = (edges[:-1] + 0.0625)[prof >= 0.97 * np.nanmax(prof)]
+    return {"implementation": rho(I), "single_crossing": bool((np.asarray(hits) == 1).all()),
+            "max_dev_from_sin_pi_t2": float(np.abs(np.asarray(I) - np.sin(np.pi * t * t)).max()),
+            "sin(pi t^2)": rho(np.sin(np.pi * t * t)), "sin(pi t)": rho(np.sin(np.pi * t)), "sin(pi t^1.5)": rho(np.sin(np.pi * t ** 1.5)),
+            "sin(pi t^3)": rho(np.sin(np.pi * t ** 3)), "t reversed": rho(np.sin(np.pi * (1 - t) ** 2)),
+            "default.yaml radii 1.8/13": rho(np.sin(np.pi * np.clip((13.0 - r) / (13.0 - 1.8), 0, 1) ** 2)),
+            "premultiplied I^2": rho(np.sin(np.pi * t * t) ** 2),
+            "best_exponent": float(max(np.arange(1.0, 3.01, 0.1), key=lambda p: rho(np.sin(np.pi * t ** p)))),
+            "picture_peak_radius": float(0.5 * (top.min() + top.max())), "law_peak_radius": rO - (rO - rI) / np.sqrt(2.0), "pixels": int(ok.sum())}

@@ -326,7 +326,8 @@ def test_split_leg_single_process_and_per_rank():
     # ... and what an 8-GPU split will be limited by, from one device: the 8 bands rendered alone, their steps and times, the bounds
     p = r["prediction_8_gpus"]
     assert p["n_bands"] == 8 and p["bands"][0] == [0, 270] and p["bands"][-1] == [1890, 2160] and len(p["band_steps"]) == len(p["band_kernel_ms"]) == len(p["band_call_ms"]) == 8
-    assert [c for c in calls if c[0] == "rows"][:2] == [("rows", 0, 270), ("rows", 0, 270)] and p["steps_max_over_mean"] == 1.0 and p["work_bound"] == 8.0
+    assert [c for c in calls if c[0] == "rows"][:2] == [("rows", 0, 270), ("rows", 270, 540)] and p["steps_max_over_mean"] == 1.0 and p["work_bound"] == 8.0
+    assert len([c for c in calls if c[0] == "rows"]) == 8 * 4        # one untimed pass over the bands, then three of which the fastest counts
     assert p["predicted_speedup_bound"] > 0 and abs(p["kernel_bound"] - 1.0) < 1e-12 and abs(p["fixed_ms_per_band"] - (8 * 19.0 - 19.0) / 8) < 1e-9
     calls.clear()
     # rank 1 of 4: its band against its own whole frame, and every rank's whole frame is the same frame

@@ -1861,3 +1861,81 @@ def test_row_bands_and_split_at_full_size(catalogue_bytes):
     finally:
         for t in trees:
             t.close()
+
+
+# FAST's worst cases BY NAME: the scenes on which the 100 000-scene FAST-vs-STRICT fuzz runs of round 5 found their largest
+# relative deviation (scripts/fuzz_modes.py keeps the scene; profiles/r05_fuzz_modes_*.json "worst_rel_scene"), replayed against the ORACLE.
+FUZZ_WORST = {
+    # clustered sky, seed 2026, scene 97062: 2.33e-5 relative at output pixel (23, 43) green.  Not a guard threshold: stepSize 0.05 from a camera
+    # 318 radii out = 14 000 RK4 steps per ray, FAST's terminal direction differs from STRICT's by ~4e-9, and the pixel sums 6 474 star hits in the
+    # frame's densest cluster band -- a star's weight exp(-d^2 / (2 * 0.0005^2)) (src/StarMap.hs:99-110) turns a direction error e into a relative
+    # error of up to 0.0015 e / 0.0005^2 = 6000 e.  4x inside the 1e-4 bar.
+    "clustered_97062": dict(sky="clustered", bar=5e-5, cfg=dict(
+        cam_pos=(-183.92658158364335, -123.67537082561061, 229.1134871778563), cam_lookat=(3.1758390922527284, 1.0246709424977245, -1.9606805116992867),
+        cam_up=(-0.05852695689265586, 0.744980345203766, -0.4292135400524694), fov=0.06657471095116925, step_size=0.05,
+        star_intensity=0.8113562223030997, star_saturation=0.5065801057254387, disk_hsi=(0.9886339013081341, 0.047573446073489956, 0.4312819463717156),
+        disk_opacity=1.0, disk_inner=6.530699256505697, disk_outer=19.311729751407444, width=120, height=41, supersampling=True)),
+    # uniform 2 000-star sky, seed 927, scene 77998: 1.08e-6 relative at (81, 12) green (9 star hits in the whole frame; stepSize 0.05, camera 57 radii out)
+    "uniform_77998": dict(sky="small", bar=5e-6, cfg=dict(
+        cam_pos=(-23.664134929251155, -6.299726048482421, -51.09170315139909), cam_lookat=(1.7405649556910954, 1.202441007623911, -0.8466503232918938),
+        cam_up=(-0.35222849077089735, -0.12308853079066412, -1.3930649278759082), fov=0.15420001002960138, step_size=0.05,
+        star_intensity=0.6847184786833941, star_saturation=0.8223596185261706, disk_hsi=(0.74721762186865, 0.22259267115581877, 0.3281560808114866),
+        disk_opacity=0.5, disk_inner=7.555097840233828, disk_outer=32.995306408235265, width=91, height=98, supersampling=False)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(FUZZ_WORST))
+def test_fasts_worst_fuzz_scenes_against_the_oracle(case, oracle):
+    """The worst scene of each 100 000-scene fuzz, by name, against the ORACLE (the fuzz itself compares FAST with STRICT): every value of the
+    FAST frame inside the 1e-4 bar with the margin the header states (blackstar_gpu.h, BS_MODE_FAST), steps and fates equal, and STRICT on
+    the same scene at its own tolerance -- so the 2.33e-5 is FAST's deviation, not the oracle's."""
+    w = FUZZ_WORST[case]
+    sky = synthetic.ppm_catalogue_bytes(synthetic.N_SMALL) if w["sky"] == "small" else synthetic.clustered_catalogue_bytes(n_uniform=20000, n_clusters=30000)
+    t = bs.StarTree(bs.read_map(sky))
+    try:
+        t.set_max_steps(20000)
+        ref, ost = oracle.render(w["cfg"], oracle.Index(oracle.read_ppm(sky)), threads=0, max_steps=20000)
+        t.set_mode(_lib.BS_MODE_STRICT)
+        strict = bs.render(w["cfg"], t)
+        sst = t.stats()
+        t.set_mode(_lib.BS_MODE_FAST)
+        fast = bs.render(w["cfg"], t)
+        fst = t.stats()
+    finally:
+        t.close()
+    assert fst["effective_mode"] == _lib.BS_MODE_FAST     # stepSize 0.05: FAST really is FAST here
+    for st in (sst, fst):
+        assert (st["steps"], st["horizon"], st["escaped"], st["capped"], st["disk_hits"], st["star_hits"]) == \
+               (ost["steps"], ost["horizon"], ost["escaped"], ost["capped"], ost["disk_hits"], ost["star_hits"])
+    assert (np.abs(strict - ref) <= ATOL_STRICT + RTOL_STRICT * np.abs(ref)).all()
+    d = np.abs(fast - ref)
+    assert (d <= ATOL_FAST + RTOL_FAST * np.abs(ref)).all()
+    big = np.abs(ref) > 1e-3
+    worst = float((d[big] / np.abs(ref[big])).max())
+    print(f"{case}: FAST vs oracle worst relative {worst:.3e} (bar of this scene {w['bar']:.0e}; the parity bar is 1e-4), STRICT vs oracle max abs {np.abs(strict - ref).max():.2e}")
+    assert worst < w["bar"]
+
+
+@pytest.mark.parametrize("mode", [_lib.BS_MODE_STRICT, _lib.BS_MODE_FAST])
+def test_disk_intensity_law_ranks_like_the_reference_repositorys_example_image(mode, tree_empty):
+    """The HIP kernel's own disk intensity at 8 000 pixels of the reference repository's example.png (tests/golden/make_reference_disk_colour.py;
+    bar and negative controls as in tests/test_oracle.py): the picture's unclipped blue channel ranks like the kernel's sin(pi t^2) and peaks
+    where it does -- and not like sin(pi t), p = 1.5 / 3, t reversed or default.yaml's radii."""
+    from conftest import disk_law_vs_reference_example
+
+    def by_gpu(cfg, ys, xs):
+        rec = bs.trace_rays(cfg, tree_empty, ys, xs)
+        return rec["rgba"][:, 0], rec["disk_hits"]
+
+    tree_empty.set_mode(mode)
+    try:
+        o = disk_law_vs_reference_example(by_gpu)
+    finally:
+        tree_empty.set_mode(_lib.BS_MODE_STRICT)
+    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in o.items()})
+    assert o["single_crossing"] and o["pixels"] > 6500
+    assert o["max_dev_from_sin_pi_t2"] < (1e-12 if mode == _lib.BS_MODE_STRICT else 1e-6)
+    assert o["implementation"] > 0.96 and 1.9 <= o["best_exponent"] <= 2.3
+    for control in ("sin(pi t)", "sin(pi t^1.5)", "sin(pi t^3)", "t reversed", "default.yaml radii 1.8/13"):
+        assert o[control] < o["implementation"] - 0.025, control
+    assert abs(o["picture_peak_radius"] - o["law_peak_radius"]) < 0.3

@@ -389,6 +389,33 @@ def _edge_locus_accepted(edge):
     return len(edge) >= 120 and -0.5 < edge[:, 2].mean() < 2.2 and edge[:, 2].std() < 2.0
 
 
+def test_disk_intensity_law_ranks_like_the_reference_repositorys_example_image(oracle, oracle_index_empty):
+    """example.png a third time -- PHOTOMETRIC, as far as the picture allows (tests/golden/make_reference_disk_colour.py): its colour is a
+    hue-60 diskColor of an unknown scene and its brightness goes as I^1.7 of today's I (an older revision), so neither massiv-io's HSI
+    sectors nor blend / opacity / bloom can be pinned by it.  What no monotone post-processing can hide is the ARGUMENT of the law: over
+    7 000 unclipped single-crossing pixels the picture's blue channel ranks like the oracle's own I = sin(pi t^2), t = (rO - r)/(rO - rI) with
+    the ConfigFile default radii 3 / 12 (Spearman rho 0.965; the best exponent in sin(pi t^p) is 2.1), and its profile peaks where the law
+    does (r = 5.64).  Negative controls fail: sin(pi t) (rho 0.54, peak at 7.5), p = 1.5 and 3, t reversed, default.yaml's radii.
+    Control that CANNOT fail (documented, not hidden): a pre-multiplied blend (I^2) ranks identically."""
+    from conftest import disk_law_vs_reference_example
+
+    def by_oracle(cfg, ys, xs):
+        rec = oracle.trace_rays(cfg, oracle_index_empty, ys, xs)
+        return rec["rgba"][:, 0], rec["disk_hits"]
+
+    o = disk_law_vs_reference_example(by_oracle)
+    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in o.items()})
+    assert o["single_crossing"] and o["pixels"] > 6500
+    assert o["max_dev_from_sin_pi_t2"] < 1e-9                     # the fixture's radii (numpy restatement) and the C oracle are the same geometry
+    assert o["implementation"] > 0.96
+    for control in ("sin(pi t)", "sin(pi t^1.5)", "sin(pi t^3)", "t reversed", "default.yaml radii 1.8/13"):
+        assert o[control] < o["implementation"] - 0.025, control
+    assert o["sin(pi t)"] < 0.6 and o["t reversed"] < 0
+    assert 1.9 <= o["best_exponent"] <= 2.3
+    assert abs(o["picture_peak_radius"] - o["law_peak_radius"]) < 0.3 and abs(o["picture_peak_radius"] - 7.5) > 1.5    # sin(pi t) would peak at 7.5
+    assert abs(o["premultiplied I^2"] - o["implementation"]) < 1e-12   # rank statistics cannot tell a pre-multiplied blend: NOT pinned by the picture
+
+
 # ---- the reference itself as the pin (tools/ghc_pin) --------------------------------------------------------------------------
 
 def _oracle_callables(oracle, d):
