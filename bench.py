@@ -398,16 +398,24 @@ def run_ranks(args):
     def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
         fence()
-        with DeviceSampler([pci_bus_of(torch, local_rank)]) as smp:
-            wall, per_dev = sustained_leg(bs, torch, np, [tree], [cfg if frames_cfg is None else frames_cfg[rank % len(frames_cfg)]], [out], [stream],
-                                          [local_rank], n_sus)
+        failed = None   # (a rank that fails here still goes through the fence and the collectives below: nobody hangs, the leg reports the error)
+        per_dev, devices = [{"ms_per_frame": float("inf")}], [None]
+        try:
+            with DeviceSampler([pci_bus_of(torch, local_rank)]) as smp:
+                wall, per_dev = sustained_leg(bs, torch, np, [tree], [cfg if frames_cfg is None else frames_cfg[rank % len(frames_cfg)]], [out], [stream],
+                                              [local_rank], n_sus)
+            devices = smp.summary()
+        except Exception as e:
+            failed = f"{type(e).__name__}: {e}"
+            print(f"bench.py: sustained leg failed on rank {rank}: {failed}", file=sys.stderr, flush=True)
         fence()
         ms_all = all_ranks(per_dev[0]["ms_per_frame"])
-        devices = smp.summary()
         if dist_on:  # every rank sampled its own device: collect them in rank order
             objs = [None] * world
             dist.all_gather_object(objs, devices)
             devices = [d for o in objs for d in (o or [None])]
+        if failed is not None or max(ms_all) == float("inf"):
+            return {"error": failed or "another rank failed"}
         return dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / max(ms_all) / 1e3, per_rank_ms_per_frame=ms_all,
                     device=devices, note="back-to-back launches of the same frame on one stream per GPU, all ranks at once; "
                                          "Mpixel_s from the slowest rank; device = sampled sclk / power, one entry per rank")

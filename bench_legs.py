@@ -223,17 +223,29 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
             res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere)
             continue
         F = FORMS[form]
-        rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
-        outs = [rings[i % n_t][(i // n_t) % 4] for i in range(len(frame_objs))]
+        # A rank on which anything of this form fails (page-locked memory, a device error) still goes through the SAME fences and collectives as
+        # the others -- its time counts as infinite, its frames as absent -- and the form reports {"error"} on every rank instead of taking the
+        # line (whose headline value is already measured) down with it or leaving the other ranks waiting in a barrier.
+        err = None
+        rings = outs = got = None
         call = F["call"]
+        try:
+            rings = [[F["alloc"](t) for _ in range(4)] for t in trees]
+            outs = [rings[i % n_t][(i // n_t) % 4] for i in range(len(frame_objs))]
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
         # untimed warm-up = the same call once, over at least WARM_PER_CONTEXT frames per context: the contexts' second stream, device images
         # and blur scratch get created, every ring buffer is written once, a one-off ~35 ms that the FIRST many-frame batch call of a process
         # pays when no other timed work preceded it (measured: 5.96 ms per frame in the first 20-frame call, 4.10-4.11 in the next three;
         # profiles/EXPERIMENTS.md) is spent -- and every context MEASURES this frame shape once (csrc/batch.cpp: the partition trial, 8 + 3 x 8
         # frames), so that the timed call runs with the context's remembered choice like any later call of a long-lived host would
         n_warm = max(len(frame_objs), WARM_PER_CONTEXT * n_t)
-        call([frame_objs[i % len(frame_objs)] for i in range(n_warm)], [rings[i % n_t][(i // n_t) % 4] for i in range(n_warm)])
-        if os.environ.get("BLACKSTAR_BENCH_D2H_REPS"):  # diagnostic: the same call several times, each timed (stderr)
+        if err is None:
+            try:
+                call([frame_objs[i % len(frame_objs)] for i in range(n_warm)], [rings[i % n_t][(i // n_t) % 4] for i in range(n_warm)])
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
+        if os.environ.get("BLACKSTAR_BENCH_D2H_REPS") and err is None and all_ranks is None:  # diagnostic (one process): the same call several times, each timed (stderr)
             for rep in range(int(os.environ["BLACKSTAR_BENCH_D2H_REPS"])):
                 fence()
                 t0 = time.perf_counter()
@@ -242,9 +254,19 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                 print(f"[d2h {form} rep {rep}] {(time.perf_counter() - t0) / (len(frame_objs) / n_t) * 1e3:.3f} ms per frame per GPU", file=sys.stderr)
         fence()
         t0 = time.perf_counter()
-        got = call(frame_objs, outs)
+        if err is None:
+            try:
+                got = call(frame_objs, outs)
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
         fence()
-        dt = max_over_ranks(time.perf_counter() - t0)
+        dt = max_over_ranks(float("inf") if err is not None else time.perf_counter() - t0)
+        if err is not None or dt == float("inf"):   # (every rank learns it through the max; the comparison below stays a collective for all)
+            identical_everywhere([])
+            print(f"bench.py: delivered form {form!r} failed{'' if err is None else ': ' + err}", file=sys.stderr, flush=True)
+            res[F["key"]] = {"error": err or "another rank failed", "entry_point": F["entry"]}
+            del rings, outs, got
+            continue
         frames = len(frame_objs) * world // 1  # every rank runs the same number of frames
         per_gpu = len(frame_objs) / n_t
         res[F["key"]] = {
@@ -512,40 +534,61 @@ def split_leg(bs, np, trees, rank, world, fence, max_over_ranks, gather_objs, re
     W, H = cfg["width"], cfg["height"]
     n_t = len(trees)
     n_parts = n_t * world
-    ref = bs.alloc_image(trees[0], H, W)
+    errs = []   # a rank on which a render fails keeps taking part in every fence and collective (its times count as infinite): nobody hangs
+
+    def alloc(rows):
+        try:
+            return bs.alloc_image(trees[0], rows, W)
+        except Exception as e:   # (page-locked memory: the placeholder is never rendered into -- every later render is skipped once errs is set)
+            errs.append(f"{type(e).__name__}: {e}")
+            return np.zeros((1, W, 3))
+
+    ref = alloc(H)
+
+    def guarded(fn):
+        if errs:
+            return
+        try:
+            fn()
+        except Exception as e:
+            errs.append(f"{type(e).__name__}: {e}")
 
     def timed(fn):
-        fn()  # untimed: buffers touched, streams made
+        guarded(fn)  # untimed: buffers touched, streams made
         ts = []
         for _ in range(reps):
             fence()
             t0 = time.perf_counter()
-            fn()
+            guarded(fn)
             fence()
-            ts.append(max_over_ranks(time.perf_counter() - t0))
+            ts.append(max_over_ranks(float("inf") if errs else time.perf_counter() - t0))
         return ts
 
     one = timed(lambda: bs.render(cfg, trees[0], out=ref))   # the whole frame on one device (every rank does this: its own reference)
-    st1 = trees[0].stats()
+    st1 = {"steps": 0, "rays": 0, "wave_iters": 0, "kernel_ms": 0.0}
+    guarded(lambda: st1.update(trees[0].stats()))
     ref_steps = int(st1["steps"])
     if world == 1:
-        full = bs.alloc_image(trees[0], H, W)
+        full = alloc(H)
         full[:] = 0
         ts = timed(lambda: bs.render_split(cfg, trees, out=full))
-        identical = bool(np.array_equal(full, ref))
+        identical = not errs and bool(np.array_equal(full, ref))
         bands = [shard_rows(H, k, n_t) for k in range(n_t)]
         entry = "bs_render_split"
     else:
         row0, row1 = shard_rows(H, rank, world)
-        band = bs.alloc_image(trees[0], row1 - row0, W)
+        band = alloc(row1 - row0)
         band[:] = 0
         ts = timed(lambda: bs.render_rows(cfg, trees[0], row0, row1, out=band))
-        mine = bool(np.array_equal(band, ref[row0:row1]))   # this rank's band against this rank's own whole frame ...
-        got = gather_objs((mine, frame_digest(np, ref), (row0, row1)))
+        mine = not errs and bool(np.array_equal(band, ref[row0:row1]))   # this rank's band against this rank's own whole frame ...
+        got = gather_objs((mine, frame_digest(np, ref) if not errs else f"rank {rank} failed: {errs[0]}", (row0, row1)))
         identical = all(g[0] for g in got) and len({g[1] for g in got}) == 1   # ... and every rank's whole frame is the same frame
         bands = [g[2] for g in got]
         entry = "bs_render_rows (one band per rank)"
     dt, dt_one = float(np.mean(ts)), float(np.mean(one))
+    if errs or not np.isfinite(dt) or not np.isfinite(dt_one):   # (an infinite time = a rank failed; every rank sees it through the max)
+        print(f"bench.py: split leg failed{': ' + errs[0] if errs else ' on another rank'}", file=sys.stderr, flush=True)
+        return {"error": errs[0] if errs else "another rank failed", "entry_point": entry, "parts": n_parts, "identical_to_one_device": None}
     try:   # (after the timed calls; one device, no collective: every rank may do it, rank 0's is printed)
         prediction = predict_bands(bs, np, trees[0], cfg, H, W, 8, reps=3) if rank == 0 else None
     except Exception as e:

@@ -148,7 +148,7 @@ def test_two_process_row_sharding_of_one_frame(height):
     assert tagged == [y + (0.001 if y >= split else 0.0) for y in range(height)]  # each row from the rank that owns it
 
 
-def _bench_validation_worker(rank, world, port, poison_rank, q):
+def _bench_validation_worker(rank, world, port, poison_rank, q, crash=False):
     """bench.py's untimed validation as two real processes over gloo: the objects all-gather of the validation block, the float collective
     of the delivered forms' frames_identical, the per-rank split leg.  poison_rank renders a frame that differs in one value."""
     import numpy as np
@@ -187,11 +187,15 @@ def _bench_validation_worker(rank, world, port, poison_rank, q):
 
         @staticmethod
         def render_rows(cfg, tree, row0, row1, out=None):
+            if bad and crash:
+                raise RuntimeError("bs_render_rows: BS_EDEVICE (test)")
             out[:] = frame(row0, row1)
             return out
 
         @staticmethod
         def render_batch(cfgs, trees, outs=None):
+            if bad and crash:
+                raise RuntimeError("bs_render_batch: BS_ENOMEM (test)")
             for o in outs:
                 o[:] = 7 + (1 if bad else 0)
             return outs
@@ -213,8 +217,11 @@ def _bench_validation_worker(rank, world, port, poison_rank, q):
     digest = bench.frame_digest(np, frame(0, 4))
     val = bench.validation_block(gather_objs((digest, {k: (1000 + (1 if bad else 0) if k == "steps" else 5) for k in bench.COUNTERS})), "frame")
     dist.barrier()
-    q.put((rank, split["identical_to_one_device"], split["bands"], split["parts"], forms["batch"]["frames_identical"], val["valid"],
-           val["frames_identical_across_devices"], val["steps_per_device"]))
+    if crash:
+        q.put((rank, split.get("error"), forms["batch"].get("error"), bench.forms_valid({"split": split, "batch": forms["batch"]})))
+    else:
+        q.put((rank, split["identical_to_one_device"], split["bands"], split["parts"], forms["batch"]["frames_identical"], val["valid"],
+               val["frames_identical_across_devices"], val["steps_per_device"]))
     dist.destroy_process_group()
 
 
@@ -245,3 +252,28 @@ def test_two_process_bench_validation_tells_a_wrong_frame_on_one_rank(poison_ran
         assert bands == [[0, 1080], [1080, 2160]] and parts == 2
         assert split_ok is ok and forms_ok is ok and valid is ok and frames_same is ok, (r, res[r])
         assert steps == ([1000, 1000] if ok else [1000, 1001])
+
+
+def test_two_process_bench_legs_survive_a_rank_whose_render_fails():
+    """The N > 1 line must not be lost -- or hang -- because an OPTIONAL leg fails on one rank: rank 1's bs_render_rows / bs_render_batch
+    raise; both ranks still pass every fence and collective, both report {"error": ...} for the split leg and the delivered form (rank 1 its
+    own message, rank 0 "another rank failed"), and an errored optional leg does not by itself make the headline invalid."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_validation_worker, args=(r, 2, port, 1, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        got = q.get(timeout=180)
+        res[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "BS_EDEVICE" in res[1][0] and "BS_ENOMEM" in res[1][1]
+    assert res[0][0] == "another rank failed" and res[0][1] == "another rank failed"
+    assert res[0][2] is True and res[1][2] is True
