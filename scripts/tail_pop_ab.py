@@ -43,9 +43,10 @@ if "--child" in sys.argv:
     sys.exit(0)
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-new, prev = os.path.join(ROOT, "blackstar_amd", "libblackstar_gpu.so"), os.path.join(ROOT, "variants_prev.so")
-variants = [("prev (HEAD before the change)", prev, None)] if os.path.exists(prev) else []
-variants += [(f"new, TAIL_TILES={t}", new, str(t)) for t in (0, 256, 512, 1024, 2048, 4096)]
+tree_lib, patched = os.path.join(ROOT, "blackstar_amd", "libblackstar_gpu.so"), os.path.join(ROOT, "variants_wtail.so")
+variants = [("the tree's library", tree_lib, None)]
+if os.path.exists(patched):   # TAIL_TILES > 0: late pops in the tail; < 0: EXIT mode (slots 1..3 stop taking tiles |T| << {0,2,4} tiles before the end)
+    variants += [(f"patched, TAIL_TILES={t}", patched, str(t)) for t in (os.environ.get("TAIL_SET") or "0,-1024,-2048,-4096,-8192,-16384").split(",")]
 acc = {v[0]: {w[0]: [] for w in WORKLOADS} for v in variants}
 for r in range(rounds):
     for label, lib, tail in variants:
