@@ -571,6 +571,35 @@ def test_ghc_pin_kit_is_complete_and_consistent():
         assert open(verdict).read().strip() == "OK", "the shim did not type-check against the reference (tests/golden/ghc/shim_typecheck.log)"
 
 
+def test_haskell_files_of_the_kit_use_only_names_that_are_in_scope(tmp_path):
+    """No GHC here, so the first thing a compiler would say is checked by a lint (tests/hs_scope.py): every name Dump.hs, RaytracerFFI.hs and
+    BatchMain.hs use is bound in the file or provided by exactly ONE of its imports, per hand-kept export tables of the modules (lts-13.16).
+    Negative controls: the shim as round 4 had it (massiv imported wholesale next to Prelude: ambiguous `zip`, `forM_`), a dropped import, a
+    name base does not export from `Foreign` (unsafeForeignPtrToPtr), a typo in a foreign import's name -- each is caught."""
+    import re
+    import hs_scope
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ghc_pin")
+    shim_src = open(os.path.join(root, "RaytracerFFI.hs")).read()
+    exported = set(re.sub(r"\s+", " ", re.search(r"module RaytracerFFI \((.*?)\) where", shim_src, re.S).group(1)).replace(",", " ").split())
+    for name, extra in (("Dump.hs", None), ("RaytracerFFI.hs", None), ("BatchMain.hs", {"RaytracerFFI": exported})):
+        unknown, ambiguous = hs_scope.check(os.path.join(root, name), extra)
+        assert not unknown and not ambiguous, (name, unknown, ambiguous)
+
+    def variant(edit):
+        p = tmp_path / "V.hs"
+        edited = edit(shim_src)
+        assert edited != shim_src
+        p.write_text(edited)
+        return hs_scope.check(str(p))
+
+    unknown, ambiguous = variant(lambda t: t.replace("import qualified Data.Massiv.Array as A", "import Data.Massiv.Array as A"))
+    assert any(a.startswith("zip ") for a in ambiguous) and any(a.startswith("forM_ ") for a in ambiguous)
+    assert variant(lambda t: t.replace("import Data.List (partition)\n", ""))[0] == {"partition"}
+    assert variant(lambda t: t.replace("withMany withForeignPtr bufs", "withArray (map unsafeForeignPtrToPtr bufs)"))[0] == {"unsafeForeignPtrToPtr"}
+    assert variant(lambda t: t.replace("c_bs_render_batch pctxs", "c_bs_render_batchh pctxs"))[0] == {"c_bs_render_batchh"}
+    assert variant(lambda t: t.replace("import Control.Monad (when, forM, forM_)", "import Control.Monad (forM, forM_)"))[0] == {"when"}
+
+
 def test_mirror_symmetry_pins_ray_generation_and_integration(oracle, oracle_stars):
     """A property no restatement can share a mistake about: the scene (hole + disk in y = 0) is mirror-symmetric and IEEE arithmetic is
     sign-symmetric, so with a power-of-two resolution (x'/W, y'/H exact) the scene mirrored in the disk plane -- camera, lookAt and stars
