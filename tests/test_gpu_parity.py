@@ -1939,3 +1939,37 @@ def test_disk_intensity_law_ranks_like_the_reference_repositorys_example_image(m
     for control in ("sin(pi t)", "sin(pi t^1.5)", "sin(pi t^3)", "t reversed", "default.yaml radii 1.8/13"):
         assert o[control] < o["implementation"] - 0.025, control
     assert abs(o["picture_peak_radius"] - o["law_peak_radius"]) < 0.3
+
+
+def test_destroy_waits_for_work_enqueued_on_a_callers_stream_and_create_does_not_stall_the_device(catalogue_bytes):
+    """bs_destroy no longer synchronises the device (a host application's other streams must not stall on it): it waits for the context's
+    own streams and for the events it recorded behind work on the CALLER's streams.  A render and a bloom enqueued on two foreign streams,
+    then the context destroyed at once: both results are complete, and the star data was not freed under the kernel (repeated, with a
+    second context created and destroyed meanwhile -- bs_create synchronises its own stream only)."""
+    import torch
+    stars = bs.read_map(catalogue_bytes)
+    cfg = scenes.with_res(scenes.DEFAULT_AA, 960, 540)     # ~2 M rays: about a millisecond of kernel
+    ref_tree = bs.StarTree(stars)
+    ref_tree.set_mode(_lib.BS_MODE_FAST)
+    ref = bs.render(cfg, ref_tree)
+    ref_bloom = bs.bloom(0.3, 25, ref, ref_tree)
+    try:
+        for rep in range(6):
+            t = bs.StarTree(stars)
+            t.set_mode(_lib.BS_MODE_FAST)
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            img = torch.full((540, 960, 3), -1.0, dtype=torch.float64, device="cuda:0")
+            blo = torch.full((540, 960, 3), -1.0, dtype=torch.float64, device="cuda:0")
+            src = to_device(ref)
+            torch.cuda.synchronize()
+            bs.render_device(cfg, t, img.data_ptr(), img.numel(), s1.cuda_stream)
+            _lib.check(_lib.lib().bs_bloom_device(t.handle, src.data_ptr(), blo.data_ptr(), 960, 540, 0.3, 25, C.c_void_p(s2.cuda_stream)), "bs_bloom_device")
+            if rep % 2:
+                other = bs.StarTree(stars)      # a bs_create while foreign work is in flight ...
+                other.close()                   # ... and a bs_destroy of an idle context
+            t.close()                           # no synchronisation between the enqueues and this
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(img), ref), f"rep {rep}: the render on the caller's stream did not survive bs_destroy"
+            assert np.array_equal(to_host(blo), ref_bloom), f"rep {rep}: the bloom on the caller's stream did not survive bs_destroy"
+    finally:
+        ref_tree.close()
