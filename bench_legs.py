@@ -8,7 +8,7 @@ import subprocess
 import sys
 import time
 
-__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "d2h_forms", "png_files_leg", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "split_headline", "result_line"]
+__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "d2h_forms", "png_files_leg", "write_rate_probe", "host_block", "predict_frames_8_gpus", "Stopwatch", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "split_headline", "result_line"]
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -178,7 +178,113 @@ def pmc_traffic_live(mode, catalogue, timeout_s=60):
                                                                    "launches_per_pass": 3}
 
 
-def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ranks, same_frames=False, all_ranks=None, split=None):
+class Stopwatch:
+    """Wall seconds per leg of a bench run (`leg_seconds` in the result line): where the driver's run time goes."""
+
+    def __init__(self):
+        self.seconds = {}
+
+    def leg(self, name):
+        sw = self
+
+        class _Leg:
+            def __enter__(self):
+                self.t0 = time.perf_counter()
+
+            def __exit__(self, *exc):
+                sw.seconds[name] = round(sw.seconds.get(name, 0.0) + time.perf_counter() - self.t0, 3)
+        return _Leg()
+
+
+def write_rate_probe(directory, nbytes, threads=(1, 8), files_per_thread=24):
+    """What the HOST can do for bs_render_png_files' writers, measured in the target directory: `threads` concurrent threads each create /
+    write / close files_per_thread files of nbytes bytes (a frame's PNG), like the library's per-context writers do.  Python threads: the
+    write(2) of a multi-megabyte buffer releases the interpreter lock, which is all the loop spends time in.  GB/s and files/s per count."""
+    import threading
+    out = {}
+    buf = bytes(bytearray(os.urandom(4096)) * (max(int(nbytes), 4096) // 4096))
+    for n in threads:
+        errs = []
+
+        def work(tid):
+            try:
+                for i in range(files_per_thread):
+                    fn = os.path.join(directory, f"probe_{tid}_{i % 4}.bin")
+                    with open(fn, "wb", buffering=0) as f:
+                        f.write(buf)
+            except OSError as e:
+                errs.append(str(e))
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(n)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        for k in range(n):
+            for i in range(4):
+                try:
+                    os.unlink(os.path.join(directory, f"probe_{k}_{i}.bin"))
+                except OSError:
+                    pass
+        out[n] = {"error": errs[0]} if errs else {"GBs": n * files_per_thread * len(buf) / dt / 1e9, "files_per_s": n * files_per_thread / dt}
+    return out
+
+
+def host_block(bs, trees, buffers, bytes_per_frame, frames_per_s_per_gpu):
+    """Where the host side of a delivered form lives and what it has to sustain PER GPU: the NUMA node of each context's GPU
+    (bs_numa_node), the node its page-locked output buffers landed on (bs_host_page_node of their first and last page), and bytes/s."""
+    from blackstar_amd import _lib
+    L = _lib.lib()
+    gpu_nodes = [t.numa_node() for t in trees]
+    buf_nodes = []
+    for ring in buffers:
+        nodes = set()
+        for b in ring:
+            base, n = b.ctypes.data, b.nbytes
+            nodes.update((int(L.bs_host_page_node(base)), int(L.bs_host_page_node(base + max(n - 1, 0)))))
+        buf_nodes.append(sorted(nodes))
+    return {"bytes_per_frame": int(bytes_per_frame), "GBs_needed_per_gpu": bytes_per_frame * frames_per_s_per_gpu / 1e9,
+            "numa_node_gpu": gpu_nodes, "numa_node_buffers": buf_nodes,
+            "buffers_on_gpu_node": all(g < 0 or nodes == [g] for g, nodes in zip(gpu_nodes, buf_nodes)),
+            "threads": "one host thread per context inside the call, bound to the CPUs of the GPU's NUMA node by the library (bs::NumaBind; BLACKSTAR_NUMA_BIND=0 turns it off)"}
+
+
+def predict_frames_8_gpus(frames_per_s_per_gpu, bytes_per_frame, host_GBs_per_gpu, host_GBs_total, what):
+    """Frames are independent and every GPU renders whole frames with its own context, host thread, buffers (and writer): the GPU side of
+    an 8-GPU run is 8x one GPU by construction.  What can fall short is the HOST side, which this measures on the box it runs on:
+    host_GBs_per_gpu = what one GPU's delivery path sustains (its PCIe link / its writer thread), host_GBs_total = what the shared part
+    sustains with 8 at once (None: nothing shared was measured).  predicted_speedup = min(8, per-GPU bound, shared bound) in units of
+    one GPU's measured rate -- like split's prediction, a bound from one device, not a measurement of eight."""
+    need = frames_per_s_per_gpu * bytes_per_frame / 1e9
+    per_gpu = host_GBs_per_gpu / need if need > 0 and host_GBs_per_gpu else None          # x the rate one GPU needs
+    shared = host_GBs_total / need if need > 0 and host_GBs_total else None              # GPUs' worth of the shared resource
+    bound = 8.0
+    if per_gpu is not None:
+        bound = min(bound, 8.0 * min(1.0, per_gpu))
+    if shared is not None:
+        bound = min(bound, shared)
+    return {"gpu_bound": 8.0, "GBs_needed_per_gpu": need, "host_GBs_per_gpu_measured": host_GBs_per_gpu, "host_GBs_shared_measured_8_at_once": host_GBs_total,
+            "host_headroom_per_gpu": per_gpu, "host_bound": None if shared is None and per_gpu is None else (min(8.0 * min(1.0, per_gpu or 1e9), shared or 1e9)),
+            "predicted_speedup": bound, "what": what}
+
+
+def pcie_zero_copy_probe(bs, np, tree):
+    """GB/s one GPU's kernels sustain writing a frame straight into page-locked host memory: BASELINE configs[1] (1920x1080, no
+    supersampling: 49.8 MB of f64 from a 1.3 ms kernel -- the densest store stream this library produces) through bs_render into a
+    bs_host_alloc buffer, best of 3 blocking calls.  A LOWER bound of the link (the kernel, not PCIe, sets the pace)."""
+    cfg = workload_config(bs, "default").to_bs_config()
+    buf = bs.alloc_image(tree, cfg["height"], cfg["width"])
+    best = float("inf")
+    for rep in range(4):
+        t0 = time.perf_counter()
+        bs.render(cfg, tree, out=buf)
+        if rep:
+            best = min(best, time.perf_counter() - t0)
+    return buf.nbytes / best / 1e9
+
+
+def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ranks, same_frames=False, all_ranks=None, split=None, extras=True):
     """The product's own batch entry points with every frame DELIVERED to the host (SURVEY 8d/7.6 "with and without D2H"):
     frame_objs[i] (a Config; its scene carries bloomStrength / bloomDivider) goes to trees[i % len(trees)].  Output buffers are
     page-locked (bs_host_alloc), a ring of 4 per context: two frames are in flight per context, so frame k's buffer is free again
@@ -189,6 +295,16 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
     all_ranks(x) -> every rank's x; split() -> the `split` block (split_leg), supplied by the caller who knows the ranks."""
     n_t = len(trees)
     res = {}
+    pcie = {}
+
+    def pcie_GBs():   # measured once, on the first context, when the first form asks (untimed, after that form's own timed call)
+        if "v" not in pcie:
+            try:
+                pcie["v"] = pcie_zero_copy_probe(bs, np, trees[0])
+            except Exception as e:
+                print(f"bench.py: PCIe probe failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                pcie["v"] = None
+        return pcie["v"]
 
     def identical_everywhere(blobs):
         """blobs: this process's delivered frames (arrays or bytes).  All equal here, and -- through 48 bits of a digest -- on every rank.
@@ -220,7 +336,7 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                 res["split"] = split()
             continue
         if form == "png-files":
-            res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere)
+            res["png_files"] = png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere, probe_host=extras)
             continue
         F = FORMS[form]
         # A rank on which anything of this form fails (page-locked memory, a device error) still goes through the SAME fences and collectives as
@@ -274,8 +390,20 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
             "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"],
             # (ring buffers: the distinct ones hold the last frame written into each; PNG: every file of the call)
             "frames_identical": identical_everywhere([bytes(g) for g in got] if form == "png-batch" else list({id(o): o for o in outs}.values()))}
-        if form == "png-batch" and hasattr(bs, "render_rgb8"):
-            # what the same file costs the way the reference makes it (JuicyPixels over zlib, one core): this frame's pixels through zlib
+        if extras:   # where the host side lives and what an 8-GPU run asks of it (this rank's view; untimed)
+            try:
+                fps = per_gpu / dt
+                nb = res[F["key"]]["bytes_to_host_per_frame"]
+                res[F["key"]]["host"] = host_block(bs, trees, rings, nb, fps)
+                res[F["key"]]["prediction_8_gpus"] = predict_frames_8_gpus(
+                    fps, nb, pcie_GBs(), None,
+                    "per GPU: its own PCIe link, measured as the rate this GPU's kernels write a frame into page-locked host memory (bs_render of BASELINE "
+                    "configs[1], a lower bound of the link); shared: host DRAM takes 8x GBs_needed_per_gpu -- not measurable from one GPU, two sockets' "
+                    "worth of DDR5 is several hundred GB/s")
+            except Exception as e:
+                res[F["key"]]["host"] = {"error": f"{type(e).__name__}: {e}"}
+        if form == "png-batch" and hasattr(bs, "render_rgb8") and os.environ.get("BLACKSTAR_BENCH_HOST_ENCODER") == "1":
+            # (BLACKSTAR_BENCH_HOST_ENCODER=1) what the same file costs the way the reference makes it (JuicyPixels over zlib, one core): this frame's pixels through zlib
             # on ONE host core, the Sub-filtered scanlines at levels 1 and 6 -- a reported baseline like cpu_baseline, outside every timed region
             import zlib
             px = bs.render_rgb8(frame_objs[0], trees[0])
@@ -292,10 +420,12 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
     return res
 
 
-def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere=None):
+def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, identical_everywhere=None, probe_host=True):
     """The reference's batch loop to the very end: every frame rendered, bloomed, encoded AND written to a file by ONE bs_render_png_files
-    call (frames in flight on the GPUs, a native writer thread on page-locked buffers), into a fresh directory on the RAM disk (or the
-    temp directory) that is removed afterwards.  One untimed call first, like the other delivered forms."""
+    call (per context: a rolling pipeline of frames in flight, a ring of page-locked file buffers and a native writer thread of its own),
+    into a fresh directory on the RAM disk (or the temp directory) that is removed afterwards.  Untimed calls first, like the other
+    delivered forms.  host = what every context's writer did in the timed call (bs_files_stats) and what this box's file system takes
+    from 1 and from 8 writer threads at once in the same directory; prediction_8_gpus follows from those."""
     import shutil
     import tempfile
     # A directory with room for the files (a container's /dev/shm can be 64 MB): RAM disk if it has 4x what the frames need, else the temp
@@ -312,12 +442,12 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
     if max_over_ranks(0.0 if base else 1.0) > 0:
         return {"skipped": f"no directory with {need >> 20} MiB free on some rank (/dev/shm, {tempfile.gettempdir()})"}
     d = tempfile.mkdtemp(prefix="blackstar_bench_", dir=base)
-    err, dt_local, size, files = None, float("inf"), 0, None
+    err, dt_local, size, files, fstats, probe = None, float("inf"), 0, None, None, None
     try:
         paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
-        # untimed warm-up over at least WARM_PER_CONTEXT frames per context (like d2h_forms): bs_render_png_files cuts a call into pieces of
-        # 16 frames per context, and the partition trial (a warm-up segment plus three 8-frame segments, 32-40 frames) must have ENDED
-        # before the timed call -- otherwise the timed region contains trial segments (possibly a starved 8-CU one), not the remembered choice
+        # untimed warm-up over at least WARM_PER_CONTEXT frames per context (like d2h_forms): the partition trial (a warm-up segment plus
+        # three 8-frame segments, 32-40 frames) must have ENDED before the timed call -- otherwise the timed region contains trial segments
+        # (possibly a starved 8-CU one), not the remembered choice
         warm_calls = max(1, -(-WARM_PER_CONTEXT * len(trees) // max(len(frame_objs), 1)))
         try:
             for _ in range(warm_calls):
@@ -330,6 +460,7 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
             try:
                 bs.render_png_files(frame_objs, trees, paths)
                 dt_local = time.perf_counter() - t0
+                fstats = [bs.files_stats(t) for t in trees] if hasattr(bs, "files_stats") else None
                 size = sum(os.path.getsize(p) for p in paths)
                 if identical_everywhere is not None:  # read back before the directory goes (untimed; a few distinct files would do, all is simplest)
                     files = []
@@ -339,6 +470,11 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
             except Exception as e:
                 err = f"{type(e).__name__}: {e}"
         fence()
+        if probe_host and err is None and size:   # untimed, same directory: one writer alone, and eight at once (what eight contexts' writers ask of this file system)
+            try:
+                probe = write_rate_probe(d, size // max(len(paths), 1))
+            except Exception as e:
+                probe = {"error": f"{type(e).__name__}: {e}"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     dt = max_over_ranks(dt_local)
@@ -347,11 +483,33 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
         return {"error": err or "another rank failed"}
     frames = len(frame_objs) * world
     per_gpu = len(frame_objs) / len(trees)
-    return {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
-            "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
-            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same, "warm_up_calls": warm_calls,
-            "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device, write(2) by a native writer thread while the next frames render "
-                    "(app/Main.hs:68-77 incl. writeImg's write)"}
+    out = {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
+           "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
+           "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same, "warm_up_calls": warm_calls,
+           "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device; per context one rolling pipeline, a ring of page-locked file "
+                   "buffers and a native writer thread of its own, no cross-context synchronisation (app/Main.hs:68-77 incl. writeImg's write)"}
+    if fstats:
+        nb = out["bytes_written_per_frame"]
+        fps = per_gpu / dt
+        out["host"] = {"writers": sum(s["writer_threads"] for s in fstats), "contexts": len(fstats), "ring_per_context": [s["ring"] for s in fstats],
+                       "files_per_writer": [s["files"] for s in fstats],
+                       "writer_busy_frac": max(s["writer_busy_frac"] for s in fstats), "writer_busy_frac_per_context": [round(s["writer_busy_frac"], 4) for s in fstats],
+                       "buffer_wait_ms_per_context": [round(s["buffer_wait_ms"], 3) for s in fstats],
+                       "bytes_per_frame": nb, "GBs_needed_per_gpu": nb * fps / 1e9,
+                       "numa_node_gpu": [s["numa_node_gpu"] for s in fstats], "numa_node_buffers": [s["numa_node_buffers"] for s in fstats],
+                       "threads_bound_to_gpu_node": [bool(s["threads_bound"]) for s in fstats],
+                       "buffers_on_gpu_node": all(s["numa_node_gpu"] < 0 or s["numa_node_buffers"] == s["numa_node_gpu"] for s in fstats)}
+        if isinstance(probe, dict) and all(isinstance(v, dict) and "GBs" in v for v in probe.values()) and probe:
+            one, eight = probe.get(1), probe.get(8)
+            out["host"]["one_thread_write_GBs"] = one["GBs"] if one else None
+            out["host"]["eight_threads_write_GBs"] = eight["GBs"] if eight else None
+            out["prediction_8_gpus"] = predict_frames_8_gpus(
+                fps, nb, one["GBs"] if one else None, eight["GBs"] if eight else None,
+                "per GPU: its own writer thread, measured as ONE thread creating / writing / closing files of this size in the target directory; shared: the "
+                "file system under EIGHT such threads at once (same directory, same file size) -- both measured on this box after the timed call")
+        elif probe is not None:
+            out["host"]["write_probe"] = probe
+    return out
 
 
 def sustained_leg(bs, torch, np, trees, cfgs, outs, streams, devs, n_frames):

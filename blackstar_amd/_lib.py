@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BLACKSTAR_LIB") or os.path.join(_HERE, "libblackstar_gpu.so")  # BLACKSTAR_LIB: A/B builds of the same ABI
 
 BS_MODE_STRICT, BS_MODE_FAST = 0, 1
-BS_ABI_VERSION = 4  # include/blackstar_gpu.h
+BS_ABI_VERSION = 5  # include/blackstar_gpu.h
 BS_MAX_STEPS_LIMIT = 1 << 30
 # The test hooks (include/blackstar_gpu_debug.h) live in a library of their own, next to the product it was built with; only tests,
 # scripts/ and bench.py's issue-rate probe load it (debug_lib()).
@@ -35,6 +35,13 @@ class BsStats(C.Structure):
                [("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("effective_mode", C.c_int32), ("zero_copy", C.c_int32)]
 
 
+class BsFilesStats(C.Structure):
+    """struct bs_files_stats_t."""
+    _fields_ = [("files", C.c_uint64), ("bytes", C.c_uint64), ("wall_ms", C.c_double), ("writer_busy_ms", C.c_double),
+                ("buffer_wait_ms", C.c_double), ("ring", C.c_int32), ("writer_threads", C.c_int32), ("numa_node_gpu", C.c_int32),
+                ("numa_node_buffers", C.c_int32), ("threads_bound", C.c_int32), ("_pad", C.c_int32)]
+
+
 # struct bs_star / struct bs_ray_record as numpy structured dtypes (same layout as the C structs)
 STAR_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("hue", "<f8"), ("sat", "<f8"), ("mag", "<i4"), ("_pad", "<i4")])
 RECORD_DTYPE = np.dtype([("vel", "<f8", 3), ("pos", "<f8", 3), ("rgba", "<f8", 4), ("steps", "<i4"), ("fate", "<i4"),
@@ -45,7 +52,8 @@ SYMBOLS = ("bs_create", "bs_destroy", "bs_device_count", "bs_render", "bs_render
            "bs_render_rows_device", "bs_render_split", "bs_render_batch", "bs_bloom_device", "bs_bloom", "bs_supersample", "bs_srgb8_device",
            "bs_srgb8", "bs_render_rgb8", "bs_render_rgb8_batch", "bs_png_bound", "bs_encode_png_device", "bs_encode_png", "bs_render_png",
            "bs_render_png_batch", "bs_render_png_files", "bs_star_lookup", "bs_set_mode", "bs_get_mode", "bs_effective_mode",
-           "bs_set_max_steps", "bs_stats", "bs_last_error", "bs_abi_version", "bs_read_ppm", "bs_validate_config", "bs_hsi_to_rgb")
+           "bs_set_max_steps", "bs_stats", "bs_last_error", "bs_abi_version", "bs_read_ppm", "bs_validate_config", "bs_hsi_to_rgb",
+           "bs_files_stats", "bs_numa_node", "bs_host_page_node")
 # every symbol include/blackstar_gpu_debug.h declares (libblackstar_gpu_debug.so)
 DEBUG_SYMBOLS = ("bs_debug_abi_check", "bs_trace_rays", "bs_debug_sqrt_div", "bs_debug_set_disk_slots", "bs_debug_ubench", "bs_debug_png_phases",
                  "bs_debug_last_post_cus", "bs_debug_last_trial", "bs_debug_partition_choice", "bs_debug_pick_partition",
@@ -142,6 +150,9 @@ def lib() -> C.CDLL:
     L.bs_render_png.argtypes = [vp, C.POINTER(BsConfig), dp, C.c_int, vp, sz, C.POINTER(sz)]
     L.bs_render_png_files.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int]
     L.bs_render_png_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.bs_files_stats.argtypes = [vp, C.POINTER(BsFilesStats)]
+    L.bs_numa_node.argtypes = [vp]
+    L.bs_host_page_node.argtypes = [vp]
     _lib = L
     return L
 

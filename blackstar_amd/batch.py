@@ -95,8 +95,9 @@ def render_png_batch(cfgs: Sequence[Config], trees: Sequence[StarTree], outs: Se
 
 def render_png_files(cfgs: Sequence[Config], trees: Sequence[StarTree], paths: Sequence[str], pipe: int = 16) -> None:
     """The reference's batch loop to the very end, in the library (`bs_render_png_files`): cfgs[i] rendered, bloomed, mapped to sRGB8 and
-    PNG-encoded on trees[i % len(trees)] and written to paths[i] -- frames in flight on the GPUs, files written by a native writer thread
-    from page-locked buffers while the next frames are rendered.  Raises BlackstarError (BS_EIO) if a file cannot be written."""
+    PNG-encoded on trees[i % len(trees)] and written to paths[i] -- per tree one rolling pipeline of frames in flight, a ring of `pipe`
+    page-locked file buffers and a native writer thread of its own (on the GPU's NUMA node); no tree waits for another.  Raises
+    BlackstarError (BS_EIO) if a file cannot be written.  `files_stats(tree)` tells what each tree's writer did."""
     if not trees:
         raise ValueError("need at least one StarTree")
     if any(not isinstance(c, Config) for c in cfgs):
@@ -112,6 +113,16 @@ def render_png_files(cfgs: Sequence[Config], trees: Sequence[StarTree], paths: S
     cpaths = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
     ctxs = (C.c_void_p * len(trees))(*[t.handle for t in trees])
     _lib.check(_lib.lib().bs_render_png_files(ctxs, len(trees), arr, n, strengths, dividers, cpaths, int(pipe)), "bs_render_png_files")
+
+
+def files_stats(tree: StarTree) -> dict:
+    """`bs_files_stats`: the host side of this tree's share of the last render_png_files call (files, bytes, wall_ms, writer_busy_ms,
+    buffer_wait_ms, ring, writer_threads, numa_node_gpu, numa_node_buffers, threads_bound) plus writer_busy_frac = busy / wall."""
+    st = _lib.BsFilesStats()
+    _lib.check(_lib.lib().bs_files_stats(tree.handle, C.byref(st)), "bs_files_stats")
+    d = {k: getattr(st, k) for k, _ in _lib.BsFilesStats._fields_ if k != "_pad"}
+    d["writer_busy_frac"] = st.writer_busy_ms / st.wall_ms if st.wall_ms > 0 else 0.0
+    return d
 
 
 def render_split(cfg, trees: Sequence[StarTree], out: np.ndarray = None) -> np.ndarray:

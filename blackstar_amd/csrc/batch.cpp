@@ -1,12 +1,17 @@
 // batch.cpp -- many frames and many contexts: the reference's batch loop (app/Main.hs:68-77) as pipelines of frames in flight per
-// context, one host thread per context, frame i on context i % n_ctx; the post stage on its own CUs where that measures faster; files
-// written by a writer thread; one huge frame split into row bands.  No data-path collective anywhere: frames and bands are independent.
+// context, one host thread per context (on the CPUs of the GPU's NUMA node), frame i on context i % n_ctx; the post stage on its own CUs
+// where that measures faster; files written by a writer thread PER CONTEXT out of that context's ring of page-locked buffers; one huge
+// frame split into row bands.  No data-path collective and no cross-context synchronisation anywhere: frames and bands are independent.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -22,9 +27,14 @@ using namespace bs;
 // One host thread per context: body(c) for c = 0 .. n-1, each on its own thread (a single context: on the caller's).  A thread that cannot
 // be started (std::system_error: EAGAIN under a process / thread limit) must not become an exception in an `extern "C"` function, which
 // would end the process: its body runs on the calling thread instead, after the others have been started.
+// Whichever thread runs body(c) does so on the CPUs of context c's NUMA node (bs::NumaBind; the caller's own thread gets its affinity back).
 template <class Body>
-static void per_context(int n, Body body)
+static void per_context(bs_ctx *const *ctxs, int n, Body inner)
 {
+    auto body = [&](int c) {
+        bs::NumaBind on_node(ctxs[c]);
+        inner(c);
+    };
     if (n == 1) { body(0); return; }
     std::vector<std::thread> th;
     std::vector<int> inline_later;
@@ -140,7 +150,7 @@ try {
     // collective: frames are independent (app/Main.hs:72-77 renders them one after another).
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
-    per_context(n_ctx, [&](int c) {
+    per_context(ctxs, n_ctx, [&](int c) {
         rcs[c] = render_frames_pipelined(ctxs[c], cfgs, outs, c, n_frames, n_ctx);
         if (rcs[c]) errs[c] = bs::error_message();
     });
@@ -149,10 +159,160 @@ try {
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_render_batch"); }
 
-// Where a batch's frames go: RGB8 pixels (png == nullptr) or finished PNG files (bs_render_png_batch).
+// One file: create / truncate, write, close.  Empty string on success, else what failed.
+static std::string write_whole_file(const char *path, const unsigned char *data, size_t n)
+{
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return std::string(path) + ": " + std::strerror(errno);
+    const size_t wrote = n ? std::fwrite(data, 1, n, f) : 0;
+    const int close_rc = std::fclose(f);
+    if (wrote != n || close_rc != 0) return std::string(path) + ": " + std::strerror(errno ? errno : EIO);
+    return std::string();
+}
+
+// ---- bs_render_png_files: one context's file buffers and its writer ---------------------------------------------------------------
+// The reference's batch loop ends every scene with writeImg's write (app/Main.hs:119-123, src/Raytracer.hs:29-32).  Here each context has
+// a RING of page-locked file buffers of its own (bs_host_alloc on its device: pages on the GPU's NUMA node) and a WRITER thread of its
+// own (on that node's CPUs): the render pipeline takes a free buffer for the frame it is about to enqueue (acquire), the PNG encoder
+// writes the file into it over PCIe, and when the frame has left the device the buffer goes to the writer (submit), which creates /
+// writes / closes the file and gives the buffer back.  The pipeline only ever waits for ITS writer, and only when every buffer of the
+// ring is still to be written -- a context never waits for another context's frames or files, and there is no chunk boundary at which
+// the pipeline drains (round 5 had one writer thread for all contexts and a barrier across them every 16 frames per context).
+// An error anywhere -- a file that cannot be written, a device error -- raises the call's `stop` flag: every pipeline stops taking new
+// frames (acquire returns nullptr -> kCancelled), drains what it has in flight, and every writer is joined before the call returns.
+constexpr int kCancelled = -1000;   // internal: never crosses the ABI
+constexpr int kMinRing = 4;         // frames in flight per context (<= 3) + one with the writer: the pipeline can always make progress
+constexpr int kDefaultRing = 16;
+
+struct FileRing {
+    struct Job { int frame; int buf; size_t bytes; };
+    bs_ctx *ctx = nullptr;
+    const char *const *paths = nullptr;
+    std::vector<unsigned char *> bufs;
+    size_t cap = 0;
+    std::atomic<bool> *stop = nullptr;   // the call's
+    std::mutex m;
+    std::condition_variable cv_free, cv_work;
+    std::vector<int> free_bufs;
+    std::vector<std::pair<int, int>> taken;   // (frame, buffer) of frames acquired and not yet submitted
+    std::deque<Job> jobs;
+    bool closing = false;
+    bool threaded = false;
+    std::thread writer;
+    std::string error;                   // the writer's (read after join, or under m)
+    // what bs_files_stats reports
+    uint64_t files = 0, bytes = 0;
+    double busy_ms = 0, wait_ms = 0, t_last = 0;
+    bool writer_bound = false;
+
+    void start()
+    {
+        for (int b = (int)bufs.size() - 1; b >= 0; b--) free_bufs.push_back(b);
+        try {
+            writer = std::thread([this] { loop(); });
+            threaded = true;
+        } catch (const std::system_error &) {   // no thread to be had: submit() writes the file itself, without the overlap
+            threaded = false;
+        }
+    }
+
+    // A free buffer for frame `frame`; blocks while the writer still owns all of them.  nullptr: the call is being stopped.
+    unsigned char *acquire(int frame)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (free_bufs.empty()) {
+            const double t0 = now_ms();
+            cv_free.wait(lk, [&] { return !free_bufs.empty() || stop->load(); });
+            wait_ms += now_ms() - t0;
+        }
+        if (stop->load() || free_bufs.empty()) return nullptr;
+        const int b = free_bufs.back();
+        free_bufs.pop_back();
+        taken.emplace_back(frame, b);
+        return bufs[(size_t)b];
+    }
+
+    // Frame `frame`'s file (bytes long) is complete in the buffer it acquired: over to the writer.
+    int submit(int frame, size_t n)
+    {
+        int b = -1;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t k = 0; k < taken.size(); k++)
+                if (taken[k].first == frame) { b = taken[k].second; taken.erase(taken.begin() + (long)k); break; }
+            if (b < 0) return fail(BS_EINTERNAL, "file ring: frame without a buffer");
+            if (threaded) {
+                jobs.push_back(Job{frame, b, n});
+                cv_work.notify_one();
+                return BS_OK;
+            }
+        }
+        write_one(Job{frame, b, n});   // (no writer thread: here, on the pipeline's)
+        std::lock_guard<std::mutex> lk(m);
+        free_bufs.push_back(b);
+        return error.empty() ? BS_OK : kCancelled;
+    }
+
+    void write_one(const Job &j)
+    {
+        if (!error.empty()) return;   // after the first failure nothing more is written
+        const double t0 = now_ms();
+        std::string e = write_whole_file(paths[j.frame], bufs[(size_t)j.buf], j.bytes);
+        t_last = now_ms();
+        busy_ms += t_last - t0;
+        if (e.empty()) {
+            files++;
+            bytes += j.bytes;
+        } else {
+            std::lock_guard<std::mutex> lk(m);   // (not held by either caller at this point)
+            error = std::move(e);
+            stop->store(true);
+        }
+    }
+
+    void loop()
+    {
+        bs::NumaBind on_node(ctx);
+        writer_bound = on_node.bound();
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return !jobs.empty() || closing; });
+            if (jobs.empty()) return;   // closing, and everything handed over has been dealt with
+            const Job j = jobs.front();
+            jobs.pop_front();
+            lk.unlock();
+            write_one(j);
+            lk.lock();
+            free_bufs.push_back(j.buf);
+            cv_free.notify_all();
+        }
+    }
+
+    // No more frames will be submitted: the writer finishes what it has and is joined.  Called on every exit path (the destructor does).
+    void close()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            closing = true;
+        }
+        cv_work.notify_all();
+        cv_free.notify_all();
+        if (writer.joinable()) writer.join();
+    }
+    void wake()   // (the call's stop flag was raised by somebody else; m is taken so that a pipeline between its check and its wait is not missed)
+    {
+        { std::lock_guard<std::mutex> lk(m); }
+        cv_free.notify_all();
+    }
+    ~FileRing() { close(); }
+};
+
+// Where a batch's frames go: RGB8 pixels (png == nullptr), finished PNG files in the caller's buffers (bs_render_png_batch: caps / sizes),
+// or files on disk through the context's ring (bs_render_png_files: ring; the pipelines' outs[] is null then).
 struct PngSink {
     const size_t *caps;   // capacity of outs[i]
     size_t *sizes;        // receives the size of file i
+    FileRing *ring;
 };
 
 // What every frame of a context's share must satisfy before anything is launched; returns the largest frame (values) in *need.
@@ -161,13 +321,14 @@ static int check_rgb8_share(const bs_config *cfgs, const double *strengths, cons
 {
     *need = 0;
     for (int i = first; i < n_frames; i += step) {
-        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
+        const bool to_ring = png && png->ring;
+        if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || (!to_ring && !outs[i])) return fail(BS_EINVAL, "bad frame");
         const double st = strengths ? strengths[i] : 0.0;
         if (st != 0 && !dividers) return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
         if (int rc = check_bloom_args(cfgs[i].width, st, st != 0 ? dividers[i] : 1)) return rc;
         if (png) {
             if (int rc = check_png_frame(cfgs[i].width, cfgs[i].height)) return rc;
-            if (png->caps[i] < bs::png_file_bound(cfgs[i].width, cfgs[i].height))
+            if ((to_ring ? png->ring->cap : png->caps[i]) < bs::png_file_bound(cfgs[i].width, cfgs[i].height))
                 return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
         }
         *need = std::max(*need, (size_t)cfgs[i].width * cfgs[i].height * 3);
@@ -181,11 +342,15 @@ static int check_rgb8_share(const bs_config *cfgs, const double *strengths, cons
 struct PngSlots {
     int frame[3] = {-1, -1, -1};   // (the context's PNG slots 0..2; slot bs_ctx::kPngSingle belongs to the single-frame entry points)
     bool staged[3] = {false, false, false};
+    unsigned char *out[3] = {nullptr, nullptr, nullptr};   // where slot k's file goes: the caller's outs[i], or the ring buffer the frame acquired
 
-    int enqueue(bs_ctx *ctx, int k, int i, const unsigned char *d_u8, const bs_config &cfg, unsigned char *out, hipStream_t s)
+    // frame i's file buffer: the caller's, or -- files on disk -- a free one of the context's ring (may wait for the writer; nullptr: stopped)
+    static unsigned char *target_of(const PngSink &png, unsigned char *const *outs, int i) { return png.ring ? png.ring->acquire(i) : outs[i]; }
+
+    int enqueue(bs_ctx *ctx, int k, int i, const unsigned char *d_u8, const bs_config &cfg, unsigned char *file_out, hipStream_t s)
     {
         bool straddles = false;
-        double *alias = device_alias_of_pinned(ctx, out, (size_t)bs::png_file_bound(cfg.width, cfg.height), &straddles);
+        double *alias = device_alias_of_pinned(ctx, file_out, (size_t)bs::png_file_bound(cfg.width, cfg.height), &straddles);
         if (straddles) return fail(BS_EINVAL, kStraddleMsg);
         int rc = ensure_png(ctx, k, cfg.width, cfg.height, alias == nullptr);
         if (rc) return rc;
@@ -195,18 +360,21 @@ struct PngSlots {
         if (bs::launch_png_encode(d_u8, cfg.width, cfg.height, ctx->d_png_scratch[k], target, d_bytes, s)) return fail(BS_EDEVICE, "PNG encoder launch failed");
         frame[k] = i;
         staged[k] = alias == nullptr;
+        out[k] = file_out;
         return BS_OK;
     }
 
-    int retire(bs_ctx *ctx, int k, unsigned char *const *outs, const PngSink &png, hipStream_t s)
+    int retire(bs_ctx *ctx, int k, const PngSink &png, hipStream_t s)
     {
         if (frame[k] < 0) return BS_OK;
         const size_t bytes = (size_t)ctx->h_png_bytes[k];
-        png.sizes[frame[k]] = bytes;
         if (staged[k]) {
-            if (int rc = copy_out(ctx, outs[frame[k]], ctx->d_png_file[k], bytes, s)) return rc;
+            if (int rc = copy_out(ctx, out[k], ctx->d_png_file[k], bytes, s)) return rc;
         }
+        const int i = frame[k];
         frame[k] = -1;
+        if (png.ring) return png.ring->submit(i, bytes);
+        png.sizes[i] = bytes;
         return BS_OK;
     }
 };
@@ -250,22 +418,24 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
         if (k >= 2) {
             HIP_TRY(hipEventSynchronize(ctx->ev_frame[b]));  // frame k-2 (same image, same staging) has left the device
             if (done_ms) done_ms->push_back(now_ms());       // (the partition trial: when each frame of the pipeline completed)
-            if (png && (rc = files.retire(ctx, b, outs, *png, cs[b]))) return rc;
+            if (png && (rc = files.retire(ctx, b, *png, cs[b]))) return rc;
             if ((rc = deliver(b))) return rc;
         }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
-        unsigned char *target = stage[b];
+        unsigned char *target = stage[b], *file_out = nullptr;
         if (!png) {
             bool straddles = false;
             if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);  // page-locked: written in place
             if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        } else if (!(file_out = PngSlots::target_of(*png, outs, i))) {
+            return kCancelled;   // (only a ring says no: the call is being stopped)
         }
         rc = enqueue_render(ctx, &cfgs[i], img[b], n, cs[b], 0, -1, true, true, /*quiet=*/true);
         if (rc) return rc;
         rc = enqueue_post_rgb8(ctx, img[b], cfgs[i].width, cfgs[i].height, strengths ? strengths[i] : 0.0, dividers ? dividers[i] : 1, target, ctx->n_cu, cs[b]);
         if (rc) return rc;
         if (png) {
-            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], cs[b]);
+            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], file_out, cs[b]);
             if (rc) return rc;
         } else if (target == stage[b]) {
             pageable[b] = Pending{outs[i], n};
@@ -276,7 +446,7 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
     HIP_TRY(hipStreamSynchronize(cs[1]));
     for (int b = 0; b < 2; b++) {   // (in frame order: the older of the two slots first)
         const int slot = (k + b) & 1;
-        if (png && (rc = files.retire(ctx, slot, outs, *png, cs[slot]))) return rc;
+        if (png && (rc = files.retire(ctx, slot, *png, cs[slot]))) return rc;
         if ((rc = deliver(slot))) return rc;
     }
     return BS_OK;
@@ -445,14 +615,16 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         if (k >= 3) {
             HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));  // frame k-3 (same image, same staging) has left the device
             if (done_ms) done_ms->push_back(now_ms());
-            if (png && (rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
+            if (png && (rc = files.retire(ctx, b, *png, posted_on[b]))) return rc;
         }
         const size_t n = (size_t)cfgs[i].width * cfgs[i].height * 3;
-        unsigned char *target = stage[b];
+        unsigned char *target = stage[b], *file_out = nullptr;
         if (!png) {
             bool straddles = false;
             if (double *alias = device_alias_of_pinned(ctx, outs[i], n, &straddles)) target = reinterpret_cast<unsigned char *>(alias);
             if (straddles) return fail(BS_EINVAL, kStraddleMsg);
+        } else if (!(file_out = PngSlots::target_of(*png, outs, i))) {
+            return kCancelled;
         }
         rc = enqueue_render(ctx, &cfgs[i], img[b], n, ts, 0, -1, true, true, /*quiet=*/true);
         if (rc) return rc;
@@ -467,7 +639,7 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
                                last ? ctx->n_cu : plan_cus, ps);
         if (rc) return rc;
         if (png) {
-            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], outs[i], ps);
+            rc = files.enqueue(ctx, b, i, stage[b], cfgs[i], file_out, ps);
             if (rc) return rc;
         } else if (target == stage[b]) {   // (run_share only partitions shares whose outputs are all page-locked)
             return fail(BS_EINTERNAL, "the partitioned pipeline was given a pageable output buffer");
@@ -479,7 +651,7 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
     HIP_TRY(hipStreamSynchronize(pt.post));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int b = 0; png && b < 3; b++)
-        if ((rc = files.retire(ctx, b, outs, *png, posted_on[b]))) return rc;
+        if ((rc = files.retire(ctx, b, *png, posted_on[b]))) return rc;
     return BS_OK;
 }
 // One context's share of bs_render_rgb8_batch / bs_render_png_batch: frames c, c + step, ... -- shared chip, partitioned, or the trial.
@@ -493,7 +665,12 @@ static int run_share(bs_ctx *x, const bs_config *cfgs, int n_frames, const doubl
     // Only with page-locked outputs, which the last kernel of a frame writes itself: a copy into PAGEABLE memory blocks the
     // host thread until the frame's post stage has finished -- 3.8 ms on 8 CUs instead of 0.2 ms on the whole chip -- and the
     // next trace kernel is not enqueued meanwhile (measured 9.1 against 4.8 ms per frame: scripts/post_partition_pageable_ab.py)
-    for (int i = c; (post_cus || trial) && i < n_frames; i += step) {
+    const bool to_ring = png && png->ring;   // (a ring's buffers are the library's own page-locked memory: one look at the first is enough)
+    if ((post_cus || trial) && to_ring && (hipSetDevice(x->device) != hipSuccess || !device_alias_of_pinned(x, png->ring->bufs[0], png->ring->cap))) {
+        post_cus = 0;
+        trial = false;
+    }
+    for (int i = c; (post_cus || trial) && !to_ring && i < n_frames; i += step) {
         if (!outs[i] || cfgs[i].width <= 0 || cfgs[i].height <= 0 || hipSetDevice(x->device) != hipSuccess ||
             !device_alias_of_pinned(x, outs[i], png ? (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height) : (size_t)cfgs[i].width * cfgs[i].height * 3)) {
             post_cus = 0;
@@ -573,7 +750,7 @@ static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cf
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
-    per_context(n_ctx, [&](int c) {
+    per_context(ctxs, n_ctx, [&](int c) {
         rcs[c] = run_share(ctxs[c], cfgs, n_frames, bloom_strengths, bloom_dividers, outs, png, c, n_ctx);
         if (rcs[c]) errs[c] = bs::error_message();
     });
@@ -592,20 +769,9 @@ int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
                         unsigned char *const *outs, const size_t *caps, size_t *out_bytes)
 try {
     if (n_frames > 0 && (!caps || !out_bytes)) return fail(BS_EINVAL, "null argument");
-    const PngSink sink{caps, out_bytes};
+    const PngSink sink{caps, out_bytes, nullptr};
     return render_post_batch(ctxs, n_ctx, cfgs, n_frames, bloom_strengths, bloom_dividers, outs, &sink);
 } catch (...) { return bs::abi_exception("bs_render_png_batch"); }
-
-// One file: create / truncate, write, close.  Empty string on success, else what failed.
-static std::string write_whole_file(const char *path, const unsigned char *data, size_t n)
-{
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return std::string(path) + ": " + std::strerror(errno);
-    const size_t wrote = n ? std::fwrite(data, 1, n, f) : 0;
-    const int close_rc = std::fclose(f);
-    if (wrote != n || close_rc != 0) return std::string(path) + ": " + std::strerror(errno ? errno : EIO);
-    return std::string();
-}
 
 int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths, const int *bloom_dividers,
                         const char *const *paths, int pipe)
@@ -618,61 +784,88 @@ try {
         if (int rc = check_png_frame(cfgs[i].width, cfgs[i].height)) return rc;
         cap = std::max(cap, (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height));
     }
+    for (int c = 0; c < n_ctx; c++) ctxs[c]->files_stats = bs_files_stats_t{};
     if (n_frames == 0) return BS_OK;
-    // `chunk` frames per bs_render_png_batch call into one of two sets of page-locked file buffers; a writer thread writes the set of the
-    // call before while the GPUs fill the other.  (The second set exists only if there is a second call.)
-    const int chunk = (pipe > 0 ? pipe : 16) * n_ctx;
-    const int slots = std::min(chunk, n_frames);
-    const int n_sets = n_frames > chunk ? 2 : 1;
-    // buffer k of the call lives in the pool of context k % n_ctx (entry k / n_ctx), kept for the next call and freed with the context
-    std::vector<unsigned char *> bufs((size_t)n_sets * slots, nullptr);
-    for (size_t k = 0; k < bufs.size(); k++) {
-        bs_ctx *owner = ctxs[k % n_ctx];
-        const size_t e = k / n_ctx;
-        if (owner->file_pool.size() <= e) owner->file_pool.resize(e + 1, {nullptr, 0});
-        auto &slot = owner->file_pool[e];
-        if (slot.second < cap) {
-            if (slot.first) bs_host_free(slot.first);
-            slot = {nullptr, 0};
-            slot.first = static_cast<unsigned char *>(bs_host_alloc(owner, cap));
-            if (!slot.first) return BS_ENOMEM;   // (bs_host_alloc has set the message)
-            slot.second = cap;
+    // Context c: frames c, c + n_ctx, ... as ONE rolling pipeline (run_share, exactly what bs_render_png_batch runs) into a ring of `pipe`
+    // page-locked file buffers of its own, drained by a writer thread of its own (FileRing).  No context ever waits for another.
+    const int ring_size = std::max(kMinRing, std::min(pipe > 0 ? pipe : kDefaultRing, (n_frames + n_ctx - 1) / n_ctx));
+    std::atomic<bool> stop{false};
+    std::vector<int> rcs(n_ctx, BS_OK);
+    std::vector<std::string> errs(n_ctx);
+    std::vector<FileRing *> rings(n_ctx, nullptr);   // (for wake-ups across contexts; each ring lives on its context's thread's stack)
+    std::mutex rings_m;
+    auto stop_all = [&] {
+        stop.store(true);
+        std::lock_guard<std::mutex> lk(rings_m);
+        for (FileRing *r : rings)
+            if (r) r->wake();
+    };
+    per_context(ctxs, n_ctx, [&](int c) {
+        bs_ctx *x = ctxs[c];
+        if (c >= n_frames) return;
+        const double t0 = now_ms();
+        FileRing ring;
+        ring.ctx = x;
+        ring.paths = paths;
+        ring.cap = cap;
+        ring.stop = &stop;
+        // the ring's buffers live in the context's pool (kept for the next call, freed with the context): allocated by THIS thread, which
+        // runs on the GPU's NUMA node, through bs_host_alloc on the context's device
+        if (x->file_pool.size() < (size_t)ring_size) x->file_pool.resize((size_t)ring_size, {nullptr, 0});
+        for (int k = 0; k < ring_size && rcs[c] == BS_OK; k++) {
+            auto &slot = x->file_pool[(size_t)k];
+            if (slot.second < cap) {
+                if (slot.first) bs_host_free(slot.first);
+                slot = {nullptr, 0};
+                slot.first = static_cast<unsigned char *>(bs_host_alloc(x, cap));
+                if (!slot.first) { rcs[c] = BS_ENOMEM; errs[c] = bs::error_message(); break; }
+                slot.second = cap;
+            }
+            ring.bufs.push_back(slot.first);
         }
-        bufs[k] = slot.first;
-    }
-    std::vector<size_t> caps(slots, cap), sizes((size_t)n_sets * slots, 0);
-    std::thread writer;
-    std::string write_error;   // owned by the writer thread until it is joined
-    struct JoinWriter {
-        std::thread &t;
-        ~JoinWriter() { if (t.joinable()) t.join(); }
-    } join_writer{writer};
-    int rc = BS_OK;
-    for (int pos = 0, it = 0; pos < n_frames && rc == BS_OK; pos += chunk, it++) {
-        const int count = std::min(chunk, n_frames - pos), set = it & 1;
-        // (the set being refilled was written out by the writer of the call before the last, joined below one iteration ago;
-        //  the writer of the last call -- the other set -- may still be running: that is the overlap)
-        unsigned char *const *outs = bufs.data() + (size_t)set * slots;
-        size_t *sz = sizes.data() + (size_t)set * slots;
-        const PngSink sink{caps.data(), sz};
-        rc = render_post_batch(ctxs, n_ctx, cfgs + pos, count, bloom_strengths ? bloom_strengths + pos : nullptr, bloom_dividers ? bloom_dividers + pos : nullptr, outs, &sink);
-        if (rc) break;
-        if (writer.joinable()) {              // the call before this one: its files (the other set) must be out before a new writer starts
-            writer.join();
-            if (!write_error.empty()) return fail(BS_EIO, write_error);
+        if (rcs[c] != BS_OK) { stop_all(); return; }
+        ring.start();
+        {
+            std::lock_guard<std::mutex> lk(rings_m);
+            rings[c] = &ring;
         }
-        auto write_set = [&write_error, outs, sz, paths, pos, count]() {
-            for (int j = 0; j < count && write_error.empty(); j++) write_error = write_whole_file(paths[pos + j], outs[j], sz[j]);
-        };
-        try {
-            writer = std::thread(write_set);
-        } catch (const std::system_error &) {   // no thread to be had: write this set here, without the overlap
-            write_set();
+        const PngSink sink{nullptr, nullptr, &ring};
+        int rc = run_share(x, cfgs, n_frames, bloom_strengths, bloom_dividers, nullptr, &sink, c, n_ctx);
+        if (rc && rc != kCancelled) {
+            errs[c] = bs::error_message();
+            stop_all();
         }
-    }
-    if (writer.joinable()) writer.join();
-    if (rc) return rc;   // (the failing call has set the message)
-    if (!write_error.empty()) return fail(BS_EIO, write_error);
+        {
+            std::lock_guard<std::mutex> lk(rings_m);
+            rings[c] = nullptr;
+        }
+        ring.close();   // the writer finishes what it was handed and is joined (also on every error path: ~FileRing does the same)
+        if (!ring.error.empty()) {   // its own file failed: that is this context's error, whatever the pipeline returned because of it
+            rc = BS_EIO;
+            errs[c] = ring.error;
+            stop_all();
+        }
+        rcs[c] = rc;
+        bs_files_stats_t &st = x->files_stats;
+        st.files = ring.files;
+        st.bytes = ring.bytes;
+        st.wall_ms = (ring.t_last > 0 ? ring.t_last : now_ms()) - t0;
+        st.writer_busy_ms = ring.busy_ms;
+        st.buffer_wait_ms = ring.wait_ms;
+        st.ring = ring_size;
+        st.writer_threads = ring.threaded ? 1 : 0;
+        st.numa_node_gpu = x->numa_node;
+        int node = bs::numa_node_of_page(ring.bufs[0]);
+        for (unsigned char *b : ring.bufs)
+            if (bs::numa_node_of_page(b) != node) node = -2;   // (mixed)
+        st.numa_node_buffers = node;
+        st.threads_bound = ring.threaded ? (ring.writer_bound ? 1 : 0) : 0;
+    });
+    // the first context (in index order) with an error of its own decides; a context that was merely stopped has none
+    for (int c = 0; c < n_ctx; c++)
+        if (rcs[c] && rcs[c] != kCancelled) return fail(rcs[c], errs[c]);
+    for (int c = 0; c < n_ctx; c++)
+        if (rcs[c] == kCancelled) return fail(BS_EINTERNAL, "bs_render_png_files: stopped without an error on record");
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_render_png_files"); }
 
@@ -688,7 +881,7 @@ try {
     const int base = cfg->height / n, extra = cfg->height % n;
     std::vector<int> rcs(n, BS_OK);
     std::vector<std::string> errs(n);
-    per_context(n, [&](int c) {
+    per_context(ctxs, n, [&](int c) {
         const int row0 = c * base + std::min(c, extra), row1 = row0 + base + (c < extra ? 1 : 0);
         rcs[c] = bs_render_rows(ctxs[c], cfg, row0, row1, out_rgb + (size_t)row0 * cfg->width * 3, (size_t)(row1 - row0) * cfg->width * 3);
         if (rcs[c]) errs[c] = bs::error_message();

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <string>
 #include <utility>
@@ -131,13 +132,26 @@ struct bs_ctx {
     hipEvent_t ev_png = nullptr;       // behind the last user of PNG slot kPngSingle: see acquire_png
     hipStream_t png_stream = nullptr;
     bool png_busy = false;
-    // page-locked file buffers bs_render_png_files keeps between calls (page-locking 6 MB costs 1-2 ms): (pointer, capacity)
+    // page-locked file buffers bs_render_png_files keeps between calls (page-locking 6 MB costs 1-2 ms): (pointer, capacity) -- the ring its
+    // writer thread drains
     std::vector<std::pair<unsigned char *, size_t>> file_pool;
+    bs_files_stats_t files_stats{};   // this context's share of the last bs_render_png_files call (bs_files_stats)
+    // Where the GPU sits in the host (host_topology.cpp, probed once in bs_create): the host threads that drive this context -- the
+    // per-context thread of every batch form and the file writer -- run on the CPUs of the GPU's NUMA node.
+    int numa_node = -1;               // /sys/bus/pci/devices/<bdf>/numa_node; -1: unknown
+    cpu_set_t numa_cpus;              // that node's CPUs, restricted to what the process may use
+    bool numa_bind = false;           // binding would change something (env BLACKSTAR_NUMA_BIND=0: never)
     // Staging for caller memory that is NOT page-locked (context.cpp: copy_in / copy_out): two page-locked pieces, used alternately
     static constexpr size_t kStageBytes = size_t(8) << 20;
     unsigned char *h_stage[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};   // ev_stage[b] has been recorded behind a DMA that reads stage b and nobody has waited for it yet
+    // Work the *_device entry points enqueue on a CALLER's stream reads and writes memory this context owns (the star grid, counters, the
+    // sRGB8 table, blur / PNG scratch): behind every such call -- on every exit path -- an event is recorded on that stream (ForeignWork), and
+    // bs_destroy waits for them before anything is freed.  One entry per caller stream seen lately.
+    struct Foreign { hipStream_t s = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+    Foreign foreign[4];
+    int foreign_next = 0;
     struct VerifiedRange { const void *host = nullptr; size_t bytes = 0; };
     VerifiedRange verified[8];  // host buffers device_alias_of_pinned has walked page by page (registered memory without a queryable range)
     int verified_next = 0;
@@ -166,6 +180,17 @@ struct StreamDrain {
     StreamDrain(const StreamDrain &) = delete;
     StreamDrain &operator=(const StreamDrain &) = delete;
     ~StreamDrain();
+};
+
+// Declared first thing in every *_device entry point: when the call returns -- with or without an error, whatever it had enqueued by then --
+// an event of the context is recorded on the caller's stream behind it (nothing for the context's own streams: StreamDrain covers those).
+struct ForeignWork {
+    bs_ctx *ctx;
+    hipStream_t s;
+    ForeignWork(bs_ctx *c, void *hip_stream) : ctx(c), s(static_cast<hipStream_t>(hip_stream)) {}
+    ForeignWork(const ForeignWork &) = delete;
+    ForeignWork &operator=(const ForeignWork &) = delete;
+    ~ForeignWork();
 };
 
 // The device alias of a caller's page-locked HOST buffer (zero copy), or nullptr for pageable memory; *straddles: the buffer starts in
@@ -197,6 +222,23 @@ int copy_out(bs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, hipStrea
 int ensure_scratch(bs_ctx *ctx, size_t bytes);
 int post_cus_setting(int v);  // BLACKSTAR_POST_CUS as a number: 0 = never partition, otherwise a multiple of 4 in [8, 32]
 int effective_mode(const bs_ctx *ctx, const bs_config *cfg);
+
+// ---- host_topology.cpp ------------------------------------------------------------------------------------------------------------
+void probe_host_topology(bs_ctx *ctx);        // fills numa_node / numa_cpus / numa_bind (never fails: no information = no binding)
+int numa_node_of_page(const void *p);         // the NUMA node the page at p lives on, -1 unknown
+// The calling thread runs on the CPUs of the context's NUMA node while this object lives; its previous affinity comes back afterwards
+// (a caller's own thread is only borrowed).  bound(): the affinity was really changed.
+class NumaBind {
+public:
+    explicit NumaBind(const bs_ctx *ctx);
+    ~NumaBind();
+    NumaBind(const NumaBind &) = delete;
+    NumaBind &operator=(const NumaBind &) = delete;
+    bool bound() const { return bound_; }
+private:
+    cpu_set_t saved_;
+    bool bound_ = false;
+};
 
 // ---- render.cpp -----------------------------------------------------------------------------------------------------------------
 // row0/row1: the band of OUTPUT rows to render ([0, height) = the frame).

@@ -63,6 +63,39 @@ static void quiesce(bs_ctx *ctx)
         if (e) (void)hipEventSynchronize(e);
     for (hipEvent_t e : ctx->ev_posted)
         if (e) (void)hipEventSynchronize(e);
+    for (const bs_ctx::Foreign &f : ctx->foreign)
+        if (f.used && f.ev) (void)hipEventSynchronize(f.ev);
+}
+
+ForeignWork::~ForeignWork()
+{
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+    for (hipStream_t own : {ctx->stream, ctx->stream2, ctx->copy_stream})
+        if (own && own == s) return;
+    for (const bs_ctx::Partition &pt : ctx->parts)
+        for (hipStream_t own : {pt.trace[0], pt.trace[1], pt.post})
+            if (own && own == s) return;
+    bs_ctx::Foreign *f = nullptr;
+    for (bs_ctx::Foreign &g : ctx->foreign)
+        if (g.used && g.s == s) f = &g;
+    if (!f) {   // a stream not seen lately: the oldest entry makes room -- after what it stands for has finished (nothing may get lost)
+        f = &ctx->foreign[ctx->foreign_next];
+        ctx->foreign_next = (ctx->foreign_next + 1) % (int)(sizeof ctx->foreign / sizeof ctx->foreign[0]);
+        if (f->used && f->ev) (void)hipEventSynchronize(f->ev);
+        f->used = false;
+    }
+    if (!f->ev && hipEventCreateWithFlags(&f->ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);   // no event to be had: wait here rather than leave work bs_destroy cannot see
+        return;
+    }
+    if (hipEventRecord(f->ev, s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        return;
+    }
+    f->s = s;
+    f->used = true;
 }
 
 StreamDrain::~StreamDrain()
@@ -334,6 +367,7 @@ try {
     if (!ctx) { fail(BS_ENOMEM, "out of host memory"); return nullptr; }
     ctx->device = device;
     ctx->n_stars = n_stars;
+    bs::probe_host_topology(ctx);
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
     if (const char *m = std::getenv("BLACKSTAR_STAGGER_MIN_TILES")) ctx->stagger_min_tiles = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
@@ -415,9 +449,10 @@ try {
     if (!ctx) return;
     if (ctx->device >= 0 && hipSetDevice(ctx->device) == hipSuccess) {
         // Everything THIS context enqueued has finished before its memory goes -- and nothing else is waited for: the context's own streams,
-        // and, for work the caller had enqueued on streams of their own (*_device entry points), the event the context recorded behind it
-        // (every launch slot's ev_done, the blur / PNG scratch's ev_post / ev_png).  No hipDeviceSynchronize: other users of the device
-        // (a host application's own streams, other contexts) are not stalled by a bs_destroy.
+        // and, for work the caller had enqueued on streams of their own (*_device entry points), the event the context recorded behind
+        // every such call, error returns included (ForeignWork; also every launch slot's ev_done, the blur / PNG scratch's ev_post / ev_png).
+        // No hipDeviceSynchronize of our own: what the runtime's hipFree does to other streams is the runtime's business and nothing here
+        // relies on it.
         bs::quiesce(ctx);
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
@@ -457,6 +492,8 @@ try {
         for (hipEvent_t e : ctx->ev_posted)
             if (e) (void)hipEventDestroy(e);
         if (ctx->ev_post) (void)hipEventDestroy(ctx->ev_post);
+        for (bs_ctx::Foreign &f : ctx->foreign)
+            if (f.ev) (void)hipEventDestroy(f.ev);
         if (ctx->d_srgb_table) (void)hipFree(ctx->d_srgb_table);
         for (int b = 0; b < 2; b++) {
             if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
@@ -517,5 +554,19 @@ void bs_host_free(void *p)
 try {
     if (p) (void)hipHostFree(p);
 } catch (...) { (void)bs::abi_exception("bs_host_free"); }
+
+int bs_numa_node(const bs_ctx *ctx) { return ctx ? ctx->numa_node : -1; }
+
+int bs_host_page_node(const void *p)
+try {
+    return p ? bs::numa_node_of_page(p) : -1;
+} catch (...) { (void)bs::abi_exception("bs_host_page_node"); return -1; }
+
+int bs_files_stats(const bs_ctx *ctx, bs_files_stats_t *out)
+try {
+    if (!ctx || !out) return fail(BS_EINVAL, "null argument");
+    *out = ctx->files_stats;
+    return BS_OK;
+} catch (...) { return bs::abi_exception("bs_files_stats"); }
 
 }  // extern "C"

@@ -49,6 +49,7 @@ try {
     if (divider <= 0 || width / divider == 0)  // the reference crashes here: foldl1' over an empty window (ImageFilters.hs:59)
         return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
     HIP_TRY(hipSetDevice(ctx->device));
+    ForeignWork seen_by_destroy(ctx, hip_stream);
     size_t n = (size_t)width * height * 3;
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
@@ -102,6 +103,7 @@ int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_valu
 try {
     if (!ctx || (n_values && (!d_in || !d_out_u8))) return fail(BS_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    ForeignWork seen_by_destroy(ctx, hip_stream);   // (the kernel reads the context's sRGB8 table)
     if (bs::launch_srgb8((const double *)d_in, (unsigned char *)d_out_u8, n_values, ctx->d_srgb_table, hip_stream)) return fail(BS_EDEVICE, "srgb8 launch failed");
     return BS_OK;
 } catch (...) { return bs::abi_exception("bs_srgb8_device"); }
@@ -247,6 +249,7 @@ try {
     if (int rc = check_png_frame(width, height)) return rc;
     if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
     HIP_TRY(hipSetDevice(ctx->device));
+    ForeignWork seen_by_destroy(ctx, hip_stream);
     int rc = ensure_png(ctx, bs_ctx::kPngSingle, width, height, false);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);

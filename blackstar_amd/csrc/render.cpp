@@ -119,11 +119,13 @@ extern "C" {
 
 int bs_render_device(bs_ctx *ctx, const bs_config *cfg, void *d_out_rgb, size_t out_doubles, void *hip_stream)
 try {
+    ForeignWork seen_by_destroy(ctx, hip_stream);
     return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream));
 } catch (...) { return bs::abi_exception("bs_render_device"); }
 int bs_render_rows_device(bs_ctx *ctx, const bs_config *cfg, int row0, int row1, void *d_out_rgb, size_t out_doubles, void *hip_stream)
 try {
     if (row1 < 0) return fail(BS_EINVAL, "row band must satisfy 0 <= row0 < row1 <= height");
+    ForeignWork seen_by_destroy(ctx, hip_stream);
     return enqueue_render(ctx, cfg, static_cast<double *>(d_out_rgb), out_doubles, static_cast<hipStream_t>(hip_stream), row0, row1);
 } catch (...) { return bs::abi_exception("bs_render_rows_device"); }
 

@@ -75,6 +75,10 @@ class StarTree:
         _lib.check(_lib.lib().bs_stats(self.handle, C.byref(st)), "bs_stats")
         return {k: getattr(st, k) for k, _ in _lib.BsStats._fields_}
 
+    def numa_node(self) -> int:
+        """`bs_numa_node`: the NUMA node of the host this tree's GPU hangs off (-1: the host does not say)."""
+        return int(_lib.lib().bs_numa_node(self.handle))
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _lib.lib().bs_destroy(self._h)

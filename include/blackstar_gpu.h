@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): the test hooks (bs_debug_*, bs_trace_rays, struct bs_ray_record) left this header and this library: they are declared in
+/* 5 (round 6): additions only; every struct and every version-4 signature is unchanged.  bs_render_png_files runs one rolling pipeline,
+ * one ring of file buffers and one writer thread PER CONTEXT, and `pipe` is now that ring's size.  New: bs_files_stats / bs_files_stats_t,
+ * bs_numa_node, bs_host_page_node.  The host threads that drive a context run on the CPUs of its GPU's NUMA node.  bs_destroy's contract
+ * is written down.
+ * 4 (round 4): the test hooks (bs_debug_*, bs_trace_rays, struct bs_ray_record) left this header and this library: they are declared in
  * blackstar_gpu_debug.h and live in libblackstar_gpu_debug.so; bs_debug_post_cus is gone (the CU partition is measured, not modelled);
  * bs_set_max_steps refuses values above BS_MAX_STEPS_LIMIT; bs_validate_config accepts what the reference renders (negative disk
  * radii, non-finite disk / star parameters).  Every struct and every other signature is unchanged.
@@ -39,7 +43,7 @@ extern "C" {
  * 2 (round 3): bs_stats_t grew `effective_mode`; bs_effective_mode added; bs_render* validate their bs_config (BS_EINVAL for
  * non-finite fields, stepSize <= 0, negative radii, lookAt within 1e-6 of position).  1: rounds 1-2.  A binding should compare
  * bs_abi_version() with the BS_ABI_VERSION it was written against before anything else. */
-#define BS_ABI_VERSION 4
+#define BS_ABI_VERSION 5
 
 enum {
     BS_OK = 0,
@@ -121,6 +125,10 @@ typedef struct bs_ctx bs_ctx;
  * n_stars == 0 is the "no starmap" case: inRadius yields [] and escaped rays are black (src/StarMap.hs:104,115).
  * device: HIP device ordinal (>= 0).  Returns NULL on error. */
 bs_ctx *bs_create(int device, const bs_star *stars, size_t n_stars);
+/* Waits for everything THIS context has enqueued -- on its own streams and, through an event the library records behind every *_device
+ * call (error returns included), on the caller's streams -- then frees its memory.  It does not synchronise the device: work of other
+ * contexts or of the host application is not waited for.  Buffers from bs_host_alloc are the caller's and survive it.  No call on the
+ * context may be in progress on another thread. */
 void bs_destroy(bs_ctx *ctx);
 /* Number of HIP devices this process can see (one bs_ctx per device for bs_render_batch / bs_render_split), or a negative
  * BS_E* code.  No reference counterpart (the reference has one backend: the host's cores, blackstar.cabal:47). */
@@ -254,12 +262,43 @@ int bs_render_png_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, i
                         const int *bloom_dividers, unsigned char *const *outs, const size_t *caps, size_t *out_bytes);
 
 /* Replaces: the reference's batch loop to the very end (app/Main.hs:68-77 mapping doRender, :105-123, over the scenes, including writeImg's
- * write): frame i is rendered, bloomed, encoded on ctxs[i % n_ctx] and WRITTEN to paths[i] (created or truncated, like --force).  Frames go
- * through bs_render_png_batch `pipe` per context and call (<= 0: 16) into two sets of page-locked buffers of the library's own; a
- * writer thread writes the files of one call while the GPUs work on the next.  Blocking.  BS_EIO if a file cannot be written (the frames of
- * later calls are not rendered); files decode to bs_render_rgb8's pixels.  C3: 4.5 ms per frame including the write to a RAM disk. */
+ * write, src/Raytracer.hs:29-32): frame i is rendered, bloomed, encoded on ctxs[i % n_ctx] and WRITTEN to paths[i] (created or truncated, like
+ * --force).  Per context: ONE rolling pipeline over its whole share of the frames (the same one bs_render_png_batch runs, CU partition and
+ * all), a ring of `pipe` page-locked file buffers of the library's own (<= 0: 16; at least 4) and ONE writer thread that creates / writes /
+ * closes the files as the frames leave the device.  A context never waits for another context's frames or files; its pipeline waits for its
+ * own writer only when every buffer of the ring is still to be written (bs_files_stats_t.buffer_wait_ms).  The context's host thread, its
+ * writer and -- through bs_host_alloc -- its buffers sit on the NUMA node of its GPU.  Blocking.  BS_EIO if a file cannot be created or
+ * written (bs_last_error names it): every context stops taking new frames, what is in flight is drained, every writer is joined, the
+ * contexts stay usable; files already written stay.  Files decode to bs_render_rgb8's pixels.  C3: within 1 % of bs_render_png_batch. */
 int bs_render_png_files(bs_ctx *const *ctxs, int n_ctx, const bs_config *cfgs, int n_frames, const double *bloom_strengths,
                         const int *bloom_dividers, const char *const *paths, int pipe);
+
+/* What the host side of ONE context's share of the last bs_render_png_files call did (no reference counterpart: writeImg's write is
+ * sequential there, src/Raytracer.hs:29-32).  writer_busy_ms / wall_ms is the fraction of the call the context's writer spent in
+ * fopen / fwrite / fclose: far below 1 = the GPU sets the pace; buffer_wait_ms > 0 = the writer did. */
+typedef struct bs_files_stats_t {
+    uint64_t files;             /* files this context's writer wrote */
+    uint64_t bytes;             /* ... and their bytes */
+    double wall_ms;             /* this context's share: first buffer prepared ... last file closed */
+    double writer_busy_ms;      /* of that, the writer inside fopen / fwrite / fclose */
+    double buffer_wait_ms;      /* the render pipeline waiting for a free file buffer */
+    int32_t ring;               /* file buffers of the context in that call */
+    int32_t writer_threads;     /* 1; 0: no thread could be started and the pipeline's own thread wrote the files */
+    int32_t numa_node_gpu;      /* bs_numa_node(ctx) */
+    int32_t numa_node_buffers;  /* the node the ring's pages live on (bs_host_page_node); -1 unknown, -2 not all on one node */
+    int32_t threads_bound;      /* 1: the writer ran with its affinity set to the CPUs of numa_node_gpu (so did the pipeline's thread) */
+    int32_t _pad;
+} bs_files_stats_t;
+int bs_files_stats(const bs_ctx *ctx, bs_files_stats_t *out);
+
+/* Where the context's GPU sits in the host: its NUMA node as /sys/bus/pci/devices/<bdf>/numa_node gives it, -1 when the host does not
+ * say.  The threads the library starts for a context (one per context in every *_batch / split / files call, the file writers) and the
+ * calling thread while it drives a context inside those calls run on that node's CPUs (BLACKSTAR_NUMA_BIND=0: left alone); the caller's
+ * thread gets its own affinity back before the call returns. */
+int bs_numa_node(const bs_ctx *ctx);
+/* The NUMA node the page of host memory at p lives on right now (move_pages(2) as a query), -1 unknown.  bs_host_alloc memory lands on
+ * bs_numa_node(ctx) on the hosts measured (profiles/r06_host_topology.txt); bench.py reports it for every delivered form. */
+int bs_host_page_node(const void *p);
 
 /* Replaces: starLookup starmap intensity saturation vel (src/StarMap.hs:93-115), batched: dirs holds n
  * un-normalised direction vectors (x,y,z interleaved, host); out_rgb gets n RGB triples, out_hits (may be
@@ -268,7 +307,7 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
 
 /* Environment read ONCE, at bs_create (A/B switches for measurements; a host application sets none of them): BLACKSTAR_MODE=strict|fast
  * (initial bs_set_mode), BLACKSTAR_POST_CUS (see bs_render_rgb8_batch), BLACKSTAR_ZERO_COPY=0, BLACKSTAR_FAST_GUARD=0, BLACKSTAR_HOST_BANDS,
- * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS. */
+ * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS, BLACKSTAR_NUMA_BIND=0. */
 int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST */
 int bs_get_mode(const bs_ctx *ctx);
 /* The arithmetic a render of `cfg` on this context would be traced with: bs_get_mode(), except that a FAST context traces frames

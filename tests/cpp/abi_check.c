@@ -19,7 +19,11 @@ int main(void)
     if (sizeof(bs_stats_t) != 88 || offsetof(bs_stats_t, kernel_ms) != 64 || offsetof(bs_stats_t, effective_mode) != 80 ||
         offsetof(bs_stats_t, zero_copy) != 84)
         return 19;
-    if (BS_ABI_VERSION != 4) return 20;
+    if (sizeof(bs_files_stats_t) != 64 || offsetof(bs_files_stats_t, wall_ms) != 16 || offsetof(bs_files_stats_t, ring) != 40 ||
+        offsetof(bs_files_stats_t, threads_bound) != 56)
+        return 24;
+    if (bs_numa_node(NULL) != -1 || bs_host_page_node(NULL) != -1 || bs_files_stats(NULL, NULL) != BS_EINVAL) return 25;
+    if (BS_ABI_VERSION != 5) return 20;
     if (bs_abi_version() != BS_ABI_VERSION) return 13;
     if (bs_hsi_to_rgb(0.5, 0.1, 1.05, rgb) != BS_OK || rgb[0] < 0.944 || rgb[0] > 0.946) return 14;
     if (bs_hsi_to_rgb(1.0, 0.1, 1.05, rgb) != BS_EINVAL) return 15;

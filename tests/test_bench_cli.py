@@ -59,10 +59,17 @@ def test_result_line_carries_the_contract_keys():
     assert "REAL catalogue file ppm.cat" in res["config"]["workload"] and "reported separately" in res["config"]["workload"] and res["data"] != "synthetic"
 
 
-def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buffers_per_context():
+def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buffers_per_context(monkeypatch):
     """with_d2h: frame i goes to context i % N through ONE bs_render_batch / bs_render_rgb8_batch call; two frames are in flight per
-    context, so a ring of 4 page-locked buffers per context is enough; the warm-up touches every ring buffer once."""
+    context, so a ring of 4 page-locked buffers per context is enough; the warm-up touches every ring buffer once.  Every form says where
+    its host side lives (`host`: NUMA node of GPU and buffers, GB/s needed per GPU; png_files: what each context's writer did and what
+    1 and 8 writer threads get out of the target directory) and what that allows at 8 GPUs (`prediction_8_gpus`)."""
     calls = []
+    monkeypatch.setenv("BLACKSTAR_BENCH_HOST_ENCODER", "1")
+
+    class FakeTree:
+        def numa_node(self):
+            return 0
 
     class FakeBs:
         @staticmethod
@@ -93,6 +100,11 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
                     f.write(b"x" * 77)
 
         @staticmethod
+        def files_stats(tree):
+            return {"files": 10, "bytes": 770, "wall_ms": 8.0, "writer_busy_ms": 2.0, "buffer_wait_ms": 0.0, "ring": 10, "writer_threads": 1,
+                    "numa_node_gpu": 0, "numa_node_buffers": 0, "threads_bound": 1, "writer_busy_frac": 0.25}
+
+        @staticmethod
         def alloc_png(tree, h, w):
             return np.zeros(h * w * 3 + 100, np.uint8)
 
@@ -101,7 +113,7 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
             calls.append(("png", len(cfgs), len(trees), [id(o) for o in outs], outs[0].dtype))
             return [memoryview(o)[:40 + i % 2] for i, o in enumerate(outs)]   # files of 40 and 41 bytes
 
-    trees = ["t0", "t1", "t2"]
+    trees = [FakeTree(), FakeTree(), FakeTree()]
     frames = [f"cfg{i}" for i in range(30)]
     fences = []
     res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch", "png-batch", "png-files"], lambda: fences.append(1), lambda x: x)
@@ -128,6 +140,22 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     assert b["frames"] == 30 and b["entry_point"] == "bs_render_batch" and b["bytes_to_host_per_frame"] == 16 * 8 * 24
     assert abs(b["Mpixel_s"] - 30 * 16 * 8 / b["seconds"] / 1e6) < 1e-9 and abs(b["ms_per_frame_per_gpu"] - b["seconds"] / 10 * 1e3) < 1e-9
     assert res["rgb8_batch"]["bytes_to_host_per_frame"] == 16 * 8 * 3
+    for key in ("batch", "rgb8_batch", "png_batch"):
+        h, pr = res[key]["host"], res[key]["prediction_8_gpus"]
+        assert h["numa_node_gpu"] == [0, 0, 0] and len(h["numa_node_buffers"]) == 3 and h["bytes_per_frame"] == res[key]["bytes_to_host_per_frame"]
+        assert abs(h["GBs_needed_per_gpu"] - h["bytes_per_frame"] * 10 / res[key]["seconds"] / 1e9) < 1e-12
+        assert pr["gpu_bound"] == 8.0 and pr["predicted_speedup"] == 8.0 and pr["host_GBs_per_gpu_measured"] is None   # (no PCIe probe without a GPU: nothing measured, nothing claimed)
+    f = res["png_files"]
+    assert f["host"]["writers"] == 3 and f["host"]["writer_busy_frac"] == 0.25 and f["host"]["files_per_writer"] == [10, 10, 10]
+    assert f["host"]["buffers_on_gpu_node"] and f["host"]["threads_bound_to_gpu_node"] == [True] * 3
+    assert f["host"]["one_thread_write_GBs"] > 0 and f["host"]["eight_threads_write_GBs"] > 0
+    pr = f["prediction_8_gpus"]
+    assert 0 < pr["predicted_speedup"] <= 8.0 and pr["host_GBs_per_gpu_measured"] == f["host"]["one_thread_write_GBs"]
+    # the rule itself: 8x one GPU unless the host's per-GPU path or its shared part falls short
+    p = bench.predict_frames_8_gpus(200.0, 2.5e6, 5.0, 40.0, "x")      # 0.5 GB/s needed per GPU: one writer does 10x, eight together 80 GPUs' worth
+    assert p["predicted_speedup"] == 8.0 and abs(p["host_headroom_per_gpu"] - 10.0) < 1e-9
+    assert bench.predict_frames_8_gpus(200.0, 2.5e6, 5.0, 2.0, "x")["predicted_speedup"] == 4.0      # the shared part carries 4 GPUs' worth
+    assert bench.predict_frames_8_gpus(200.0, 2.5e6, 0.25, None, "x")["predicted_speedup"] == 4.0    # each GPU's own path does half of what it needs
 
 
 def test_png_files_leg_skips_on_every_rank_when_there_is_no_room(monkeypatch):

@@ -1941,11 +1941,15 @@ def test_disk_intensity_law_ranks_like_the_reference_repositorys_example_image(m
     assert abs(o["picture_peak_radius"] - o["law_peak_radius"]) < 0.3
 
 
-def test_destroy_waits_for_work_enqueued_on_a_callers_stream_and_create_does_not_stall_the_device(catalogue_bytes):
-    """bs_destroy no longer synchronises the device (a host application's other streams must not stall on it): it waits for the context's
-    own streams and for the events it recorded behind work on the CALLER's streams.  A render and a bloom enqueued on two foreign streams,
-    then the context destroyed at once: both results are complete, and the star data was not freed under the kernel (repeated, with a
-    second context created and destroyed meanwhile -- bs_create synchronises its own stream only)."""
+def test_destroy_waits_for_work_enqueued_on_a_callers_stream(catalogue_bytes):
+    """bs_destroy does not synchronise the device: it waits for the context's own streams and for the event the library records behind EVERY
+    *_device call on a caller's stream (csrc: ForeignWork) -- render, bloom, sRGB8 (which reads the context's threshold table and had no
+    event until round 6) and the PNG encoder (context-owned scratch), here on four foreign streams, then the context destroyed at once:
+    all four results are complete (repeated, with a second context created and destroyed meanwhile).  Whether a bs_create / bs_destroy of an
+    IDLE context lets another stream's long kernel run on is measured and printed, not asserted: the library itself waits for nothing
+    foreign, but what hipFree does to the device is the runtime's business."""
+    import time
+
     import torch
     stars = bs.read_map(catalogue_bytes)
     cfg = scenes.with_res(scenes.DEFAULT_AA, 960, 540)     # ~2 M rays: about a millisecond of kernel
@@ -1953,17 +1957,26 @@ def test_destroy_waits_for_work_enqueued_on_a_callers_stream_and_create_does_not
     ref_tree.set_mode(_lib.BS_MODE_FAST)
     ref = bs.render(cfg, ref_tree)
     ref_bloom = bs.bloom(0.3, 25, ref, ref_tree)
+    ref_u8 = bs.srgb8(ref, ref_tree)
+    ref_png = bytes(bs.encode_png(ref_u8, ref_tree))
+    L = _lib.lib()
     try:
         for rep in range(6):
             t = bs.StarTree(stars)
             t.set_mode(_lib.BS_MODE_FAST)
-            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            s1, s2, s3, s4 = (torch.cuda.Stream() for _ in range(4))
             img = torch.full((540, 960, 3), -1.0, dtype=torch.float64, device="cuda:0")
             blo = torch.full((540, 960, 3), -1.0, dtype=torch.float64, device="cuda:0")
-            src = to_device(ref)
+            u8 = torch.full((540, 960, 3), 7, dtype=torch.uint8, device="cuda:0")
+            png = torch.zeros(bs.png_bound(540, 960), dtype=torch.uint8, device="cuda:0")
+            png_bytes = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+            src, src_u8 = to_device(ref), to_device(ref_u8)
             torch.cuda.synchronize()
             bs.render_device(cfg, t, img.data_ptr(), img.numel(), s1.cuda_stream)
-            _lib.check(_lib.lib().bs_bloom_device(t.handle, src.data_ptr(), blo.data_ptr(), 960, 540, 0.3, 25, C.c_void_p(s2.cuda_stream)), "bs_bloom_device")
+            _lib.check(L.bs_bloom_device(t.handle, src.data_ptr(), blo.data_ptr(), 960, 540, 0.3, 25, C.c_void_p(s2.cuda_stream)), "bs_bloom_device")
+            _lib.check(L.bs_srgb8_device(t.handle, src.data_ptr(), u8.data_ptr(), src.numel(), C.c_void_p(s3.cuda_stream)), "bs_srgb8_device")
+            _lib.check(L.bs_encode_png_device(t.handle, src_u8.data_ptr(), 960, 540, png.data_ptr(), png.numel(), png_bytes.data_ptr(), C.c_void_p(s4.cuda_stream)),
+                       "bs_encode_png_device")
             if rep % 2:
                 other = bs.StarTree(stars)      # a bs_create while foreign work is in flight ...
                 other.close()                   # ... and a bs_destroy of an idle context
@@ -1971,5 +1984,24 @@ def test_destroy_waits_for_work_enqueued_on_a_callers_stream_and_create_does_not
             torch.cuda.synchronize()
             assert np.array_equal(to_host(img), ref), f"rep {rep}: the render on the caller's stream did not survive bs_destroy"
             assert np.array_equal(to_host(blo), ref_bloom), f"rep {rep}: the bloom on the caller's stream did not survive bs_destroy"
+            assert np.array_equal(to_host(u8), ref_u8), f"rep {rep}: the sRGB8 map on the caller's stream did not survive bs_destroy"
+            assert bytes(to_host(png)[:int(png_bytes.item())]) == ref_png, f"rep {rep}: the PNG file on the caller's stream did not survive bs_destroy"
+        # measured, not asserted: a long render (4K lensing-disk, ~19 ms) on a foreign stream of ANOTHER context, then an idle context made and destroyed
+        big = scenes.with_res(scenes.LENSING_DISK, 3840, 2160)
+        out = torch.empty((2160, 3840, 3), dtype=torch.float64, device="cuda:0")
+        s = torch.cuda.Stream()
+        bs.render_device(big, ref_tree, out.data_ptr(), out.numel(), s.cuda_stream)
+        torch.cuda.synchronize()                                         # (warm: images allocated, clocks up)
+        bs.render_device(big, ref_tree, out.data_ptr(), out.numel(), s.cuda_stream)
+        t0 = time.perf_counter()
+        idle = bs.StarTree(stars[:1000])
+        t1 = time.perf_counter()
+        busy_after_create = not s.query()
+        idle.close()
+        t2 = time.perf_counter()
+        busy_after_destroy = not s.query()
+        print(f"foreign 4K render in flight: bs_create {1e3 * (t1 - t0):.2f} ms (stream still busy: {busy_after_create}), "
+              f"bs_destroy {1e3 * (t2 - t1):.2f} ms (stream still busy: {busy_after_destroy})")
+        torch.cuda.synchronize()
     finally:
         ref_tree.close()

@@ -401,9 +401,10 @@ def test_render_scene_directory_is_the_references_batch_mode(tree, tmp_path):
 
 @pytest.mark.gpu
 def test_render_png_files_writes_what_render_png_returns(tree, tmp_path):
-    """bs_render_png_files (the batch loop incl. the write, in the library): 11 frames, 2 per internal call (six calls: both buffer sets
-    reused, the writer thread overlapping the next call), mixed sizes and bloom; every file is bs_render_png's bytes.  A path that cannot
-    be written gives BS_EIO naming it, leaves the context usable, and the files of earlier calls are complete."""
+    """bs_render_png_files (the batch loop incl. the write, in the library): 11 frames through a ring of 4 file buffers (the smallest: every
+    buffer is reused, the pipeline has to wait for its writer), mixed sizes and bloom; every file is bs_render_png's bytes.  A path that
+    cannot be written gives BS_EIO naming it, leaves the context usable, and the files before it are complete.  bs_files_stats tells what
+    the context's writer did."""
     import blackstar_amd as bs
     cfgs = []
     for k in range(11):
@@ -415,21 +416,76 @@ def test_render_png_files_writes_what_render_png_returns(tree, tmp_path):
     paths = [str(tmp_path / f"f{k}.png") for k in range(11)]
     bs.render_png_files(cfgs, [tree], paths, pipe=2)
     assert [open(p, "rb").read() for p in paths] == want
+    st = bs.files_stats(tree)
+    assert st["files"] == 11 and st["bytes"] == sum(map(len, want)) and st["ring"] == 4 and st["writer_threads"] == 1
+    assert 0 < st["writer_busy_ms"] <= st["wall_ms"] and 0 < st["writer_busy_frac"] <= 1 and st["buffer_wait_ms"] >= 0
+    assert st["numa_node_gpu"] == tree.numa_node()
+    if st["numa_node_gpu"] >= 0:    # the host says where the GPU hangs: the library's page-locked buffers are on that node
+        assert st["numa_node_buffers"] == st["numa_node_gpu"], st
     t2 = bs.StarTree(tree.stars)
     try:
         two = [str(tmp_path / f"g{k}.png") for k in range(11)]
         bs.render_png_files(cfgs, [tree, t2], two, pipe=1)
         assert [open(p, "rb").read() for p in two] == want
+        assert (bs.files_stats(tree)["files"], bs.files_stats(t2)["files"]) == (6, 5)
     finally:
         t2.close()
     bad = [str(tmp_path / f"h{k}.png") for k in range(11)]
     bad[5] = str(tmp_path / "no_such_directory" / "h5.png")
     with pytest.raises(bs._lib.BlackstarError, match="no_such_directory"):
         bs.render_png_files(cfgs, [tree], bad, pipe=2)
-    assert [open(p, "rb").read() for p in bad[:4]] == want[:4]          # the calls before the failing one are on disk, whole
+    assert [open(p, "rb").read() for p in bad[:5]] == want[:5]          # one writer, in frame order: everything before the failing file is on disk, whole
+    assert bs.files_stats(tree)["files"] == 5
     bs.render_png_files(cfgs[:3], [tree], paths[:3])
     assert [open(p, "rb").read() for p in paths[:3]] == want[:3]
     bs.render_png_files([], [tree], [])
+    assert bs.files_stats(tree)["files"] == 0
+
+
+@pytest.mark.gpu
+def test_one_of_several_writers_fails_mid_batch(tree, tmp_path):
+    """Four contexts (all on this box's one device: four pipelines, four rings, four writer threads), 64 frames, and ONE file -- frame 22,
+    context 2's sixth -- cannot be created.  The call returns BS_EIO naming that path; every context has stopped taking frames (far fewer
+    than 64 files exist), nothing is written after the call has returned, every file that exists is complete and correct, and all four
+    contexts render again at once -- the same batch with good paths gives 64 correct files, 16 from each writer."""
+    import time
+
+    import blackstar_amd as bs
+    others = [bs.StarTree(tree.stars) for _ in range(3)]
+    trees = [tree] + others
+    try:
+        for t in others:
+            t.set_mode(tree.get_mode())
+        cfgs = []
+        for k in range(64):
+            c = scene(*(("default-aa", 160, 90, 0.3) if k % 2 == 0 else ("default", 128, 72, 0.0)))
+            c.camera.position = (c.camera.position[0], c.camera.position[1] + 0.01 * k, c.camera.position[2])
+            cfgs.append(c)
+        want = [bytes(bs.render_png(c, tree)) for c in cfgs]
+        paths = [str(tmp_path / f"a{k}.png") for k in range(64)]
+        paths[22] = str(tmp_path / "missing" / "a22.png")
+        with pytest.raises(bs._lib.BlackstarError, match="missing/a22.png") as e:
+            bs.render_png_files(cfgs, trees, paths, pipe=4)
+        assert "rc=-6" in str(e.value)                                    # BS_EIO
+        listing = sorted(os.listdir(tmp_path))
+        sizes = {f: os.path.getsize(tmp_path / f) for f in listing}
+        assert "a22.png" not in listing and len(listing) < 64
+        stats = [bs.files_stats(t) for t in trees]
+        assert sum(s["files"] for s in stats) == len(listing) and stats[2]["files"] == 5     # frames 2, 6, 10, 14, 18 -- then 22 failed
+        assert all(s["writer_threads"] == 1 and s["ring"] == 4 for s in stats)
+        time.sleep(0.3)
+        assert sorted(os.listdir(tmp_path)) == listing and {f: os.path.getsize(tmp_path / f) for f in listing} == sizes, "a writer outlived the call"
+        for f in listing:
+            assert open(tmp_path / f, "rb").read() == want[int(f[1:-4])], f
+        for k, t in enumerate(trees):                                     # nothing in flight, every context usable straight away
+            assert bytes(bs.render_png(cfgs[k], t)) == want[k]
+        good = [str(tmp_path / f"b{k}.png") for k in range(64)]
+        bs.render_png_files(cfgs, trees, good, pipe=4)
+        assert [open(p, "rb").read() for p in good] == want
+        assert [bs.files_stats(t)["files"] for t in trees] == [16, 16, 16, 16]
+    finally:
+        for t in others:
+            t.close()
 
 
 @pytest.mark.gpu

@@ -45,7 +45,7 @@ foreign import ccall safe   "bs_render_png_files" c_bs_render_png_files
   :: Ptr (Ptr BsCtx) -> CInt -> Ptr () -> CInt -> Ptr CDouble -> Ptr CInt -> Ptr CString -> CInt -> IO CInt
 foreign import ccall safe   "bs_render_batch" c_bs_render_batch
   :: Ptr (Ptr BsCtx) -> CInt -> Ptr () -> CInt -> Ptr (Ptr CDouble) -> IO CInt
-foreign import ccall unsafe "bs_abi_version" c_bs_abi_version :: IO CInt        -- must be 4 (BS_ABI_VERSION this shim was written against)
+foreign import ccall unsafe "bs_abi_version" c_bs_abi_version :: IO CInt        -- must be 5 (BS_ABI_VERSION this shim was written against)
 
 -- struct bs_star  { double x,y,z,hue,sat; int32 mag; int32 _pad; }   = 48 bytes
 pokeStar :: Ptr () -> Int -> (V3 Double, (Int, Double, Double)) -> IO ()
@@ -61,7 +61,7 @@ withStars tree act = do
   let stars = K.assocs tree
       n     = length stars
   v <- c_bs_abi_version
-  when (v /= 4) $ ioError (userError ("libblackstar_gpu has ABI version " ++ show v ++ ", this shim expects 4"))
+  when (v /= 5) $ ioError (userError ("libblackstar_gpu has ABI version " ++ show v ++ ", this shim expects 5"))
   allocaBytes (48 * max 1 n) $ \buf -> do
     forM_ (zip [0 ..] stars) $ \(i, s) -> pokeStar buf i s
     act buf n
