@@ -46,6 +46,7 @@ import subprocess
 import sys
 import time
 
+T_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -55,6 +56,9 @@ from bench_legs import CATALOGUES, COUNTERS, WORKLOADS  # noqa: E402,F401  (name
 
 PARITY_TOLERANCE = "|gpu - cpu| <= 1e-4 * |cpu| + 1e-7 per channel per output pixel (SURVEY.md 8d 'Parity check'; north_star: 1e-4 relative)"
 PARITY_COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
+# output sizes at which the oracle renders BASELINE configs[3] (lensing-disk at 3840x2160) and three frames of configs[4] (the animation at
+# 1920x1080) for the parity list: about a second of the host's cores each; both 4x supersampled like the configs themselves
+PARITY_C4_RES, PARITY_C5_RES, PARITY_C5_FRAMES = (640, 360), (480, 270), (0, 300, 599)
 
 
 def parity_block(np, what, ref, ref_st, got, got_st, mode):
@@ -83,7 +87,7 @@ def parity_block(np, what, ref, ref_st, got, got_st, mode):
     return blk
 
 
-def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None):
+def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None, baseline_config="configs[2]"):
     """Time the C oracle (restatement of the reference CPU path; GHC is unavailable) on a bounded sample -- and, since the oracle's
     frames are computed anyway, compare them with the frames the HIP library renders of the same configs (gpu_render(cfg, stars, mode)
     -> (image, stats), the product called through its C ABI): the `parity` list.  No extra oracle time."""
@@ -122,19 +126,33 @@ def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None):
                      f"C restatement of the reference CPU path (oracle/blackstar_oracle.c, -O2, pthreads over rows)"}
     if gpu_render is not None:
         whole = (w, h) == (cfg["width"], cfg["height"])
-        jobs = [("the timed workload" + ("" if whole else f" at the CPU sample's resolution {w}x{h}") + " (BASELINE configs[2] camera, scene and catalogue)"
-                 if star_bytes else "the timed workload" + ("" if whole else f" at {w}x{h}"), sample, bool(star_bytes), img, st, ("fast",)),
-                ("scenes/default.yaml 1920x1080, no supersampling, no star map (BASELINE configs[1]), the whole frame", dict(scenes.DEFAULT), False, img2, st2,
+        # (what, baseline_config, config, with the catalogue?, the oracle's frame and statistics -- None: render it now --, arithmetic modes)
+        jobs = [("the timed workload" + ("" if whole else f" at the CPU sample's resolution {w}x{h}") + " (camera, scene and catalogue of the timed workload)"
+                 if star_bytes else "the timed workload" + ("" if whole else f" at {w}x{h}"), baseline_config, sample, bool(star_bytes), img, st, ("fast",)),
+                ("scenes/default.yaml 1920x1080, no supersampling, no star map, the whole frame", "configs[1]", dict(scenes.DEFAULT), False, img2, st2,
                  ("fast", "strict")),
-                ("scenes/default.yaml 640x480, no supersampling, no star map (BASELINE configs[0]), the whole frame", cfg1, False, img1, st1, ("fast",))]
+                ("scenes/default.yaml 640x480, no supersampling, no star map, the whole frame", "configs[0]", cfg1, False, img1, st1, ("fast",))]
+        if star_bytes:   # (the remaining BASELINE configs need the catalogue: SURVEY.md 8d "Parity check ... for each config")
+            # configs[3]: lensing-disk.yaml, 4x supersampled, down-scaled from 3840x2160 to what the oracle renders in about a second
+            w4, h4 = PARITY_C4_RES
+            jobs.append((f"scenes/lensing-disk.yaml at {w4}x{h4} (BASELINE's 3840x2160 down-scaled for the oracle), 4x supersample, same catalogue", "configs[3]",
+                         scenes.with_res(scenes.LENSING_DISK, w4, h4), True, None, None, ("fast",)))
+            # configs[4]: frames 0, 300 and 599 of the 600-frame animation, 4x supersampled, at 480x270
+            w5, h5 = PARITY_C5_RES
+            for i in PARITY_C5_FRAMES:
+                jobs.append((f"animations/default-ani.yaml, nFrames=600: frame {i} at {w5}x{h5} (1920x1080 down-scaled for the oracle), 4x supersample, same catalogue",
+                             "configs[4]", scenes.with_res(scenes.ani_frame(i, 600), w5, h5), True, None, None, ("fast",)))
         res["parity"] = []
-        for what, c, stars_, ref, ref_st, modes in jobs:
+        for what, which, c, stars_, ref, ref_st, modes in jobs:
             for mode in modes:
                 try:
+                    if ref is None:
+                        ref, ref_st = c_oracle.render(c, ix, threads=threads)
                     got, got_st = gpu_render(c, stars_, mode)
-                    res["parity"].append(parity_block(np, what, ref, ref_st, got, got_st, mode))
+                    res["parity"].append(dict(parity_block(np, what, ref, ref_st, got, got_st, mode), baseline_config=which))
                 except Exception as e:  # a leg that cannot run is reported as failing parity, not dropped
-                    res["parity"].append({"config": what, "mode": mode, "error": f"{type(e).__name__}: {e}", "outside_1e-4": -1})
+                    res["parity"].append({"config": what, "baseline_config": which, "mode": mode, "error": f"{type(e).__name__}: {e}", "outside_1e-4": -1})
+        res["parity_configs"] = sorted({p_["baseline_config"] for p_ in res["parity"]})
         res["parity_tolerance"] = PARITY_TOLERANCE
         res["parity_ok"] = all(p.get("outside_1e-4") == 0 and p.get("steps_equal") and p.get("fates_equal") for p in res["parity"])
     return res
@@ -209,6 +227,8 @@ def run_ranks(args):
     import blackstar_amd as bs
     from blackstar_amd import _lib, synthetic
 
+    sw = Stopwatch()
+    sw.seconds["imports"] = round(time.perf_counter() - T_START, 3)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -220,6 +240,7 @@ def run_ranks(args):
     # share devices, the gather goes through host memory); the real run is one rank per GPU over RCCL.
     backend = os.environ.get("BLACKSTAR_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
+    devices_or_die(world, ndev, os.environ.get("BLACKSTAR_BENCH_ALLOW_OVERSUBSCRIBE") == "1")
     if backend != "nccl":
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
@@ -253,6 +274,7 @@ def run_ranks(args):
                 "distinct_devices": len({int(g[1]) for g in got}),
                 "version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None}
 
+    t_setup = time.perf_counter()
     cfg_obj, cfg, frames_cfg, frames_obj = load_workload(args, bs)
     if args.form == "split":  # the split form has its own frame (configs[3]); the warm-up launches use it too
         cfg_obj = workload_config(bs, "lensing-4k")
@@ -319,6 +341,8 @@ def run_ranks(args):
 
     resident = args.form in ("all", "resident")
     dt_local = kernel_ms = None
+    sw.seconds["catalogue_and_context"] = round(time.perf_counter() - t_setup, 3)
+    t_timed = time.perf_counter()
     if resident:
         # Everything the host has to do around the timed region is done BEFORE the warm-up steps: the chip drops its clocks within a
         # millisecond of idling and takes ~8 launches (35 ms) to bring them back (kernel_ms_each: 5.5, 5.1, 4.9, 4.7, 4.6, 4.5 ... 4.3 ms
@@ -360,10 +384,12 @@ def run_ranks(args):
         st = tree.stats()
         t_gather = None
 
+    sw.seconds["warmup_and_timed_region"] = round(time.perf_counter() - t_timed, 3)
     # BASELINE configs[1] and configs[3] beside the headline, while the clocks are still up (N = 1, the default workload)
     per_config = None
     if world == 1 and resident and args.workload == "default-aa" and not args.no_boundary:
-        per_config = optional_leg("per_config", True, lambda: per_config_block(bs, torch, np, _lib, tree, args, local_rank))
+        with sw.leg("per_config"):
+            per_config = optional_leg("per_config", True, lambda: per_config_block(bs, torch, np, _lib, tree, args, local_rank))
 
     # Untimed validation: every rank renders the SAME frame once more (the animation: its frame 0); the frames must be bit-identical
     validation = None
@@ -385,15 +411,17 @@ def run_ranks(args):
             got = gather_objs(mine)
             what = "the workload's frame" if frames_cfg is None else "frame 0 of the animation"
             return validation_block(got, what + ", rendered once more on every rank after the timed region (untimed)", digests[1] if rank == 0 and len(digests) > 1 else None)
-        validation = optional_leg("validation", world == 1, validate)
+        with sw.leg("validation"):
+            validation = optional_leg("validation", world == 1, validate)
 
     d2h = None
     want = {"all": ["batch", "rgb8-batch", "png-batch", "png-files"] + (["split"] if with_stars else []), "resident": []}.get(args.form, [args.form])
     if want:
-        d2h = optional_leg("with_d2h", world == 1 and resident,
-                           lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x)),
-                                             same_frames=frames_obj is None, all_ranks=all_ranks if dist_on else None,
-                                             split=lambda: split_leg(bs, np, [tree], rank, world, fence, lambda x: max(all_ranks(x)), gather_objs)))
+        with sw.leg("with_d2h"):
+            d2h = optional_leg("with_d2h", world == 1 and resident,
+                               lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x)),
+                                                 same_frames=frames_obj is None, all_ranks=all_ranks if dist_on else None,
+                                                 split=lambda: split_leg(bs, np, [tree], rank, world, fence, lambda x: max(all_ranks(x)), gather_objs)))
 
     def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
@@ -422,7 +450,8 @@ def run_ranks(args):
 
     sustained = None
     if args.sustained_frames >= 50 and resident:
-        sustained = optional_leg("sustained", world == 1, sustained_block)
+        with sw.leg("sustained"):
+            sustained = optional_leg("sustained", world == 1, sustained_block)
 
     if rank == 0:
         frames = args.steps * world
@@ -452,9 +481,12 @@ def run_ranks(args):
         if args.form == "split":
             split_headline(args, res, d2h["split"], world)
         res["per_rank_ms_per_step"] = per_rank_ms
+        label_roofline_scope(res, world, per_rank_ms)
+        if legs_failed(d2h):
+            res["legs_failed"] = legs_failed(d2h)
         if validation is not None:
             res["validation"] = validation
-            res["valid"] = bool(validation.get("valid", False)) and forms_valid(d2h)
+            res["valid"] = bool(validation.get("valid", False)) and forms_valid(d2h) and not legs_failed(d2h)
         if per_config is not None:
             res["per_config"] = per_config
         if resident and n_streams == 1:
@@ -469,7 +501,8 @@ def run_ranks(args):
         if sustained:
             res["sustained"] = sustained
         if world == 1 and not args.no_boundary and frames_cfg is None and resident:
-            both = optional_leg("boundary", True, lambda: boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream))
+            with sw.leg("boundary_and_strict"):
+                both = optional_leg("boundary", True, lambda: boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream))
             res["boundary"], res["strict"] = both if isinstance(both, tuple) else (both, both)
         if world == 1 and args.cpu_seconds > 0:
             def gpu_render(c, with_stars_, mode):   # the product, through bs_render (C ABI), in the named arithmetic; the oracle only checks it
@@ -484,18 +517,23 @@ def run_ranks(args):
                         t.set_mode(before)
                     else:
                         t.close()
-            res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds, gpu_render, np))
+            with sw.leg("cpu_baseline_and_parity"):
+                res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds, gpu_render, np, WORKLOADS[args.workload]["baseline"]))
             if isinstance(res["cpu_baseline"], dict) and "parity_ok" in res["cpu_baseline"] and "valid" in res:
                 res["valid"] = bool(res["valid"]) and bool(res["cpu_baseline"]["parity_ok"])   # a fast frame that differs from the reference's is not a result
         if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and args.workload == "default-aa":
             # LAST: the profiler's child processes run after every timed leg of this process (a PMC session may leave the device in
             # another clock state for a while), and only the counter values are taken from them
-            try:
-                args.traffic_live = pmc_traffic_live(args.mode, args.catalogue)
-            except Exception as e:  # nothing about the profiler may cost the line that has already been measured
-                args.traffic_live = (None, f"{type(e).__name__}: {e}")
+            with sw.leg("pmc_passes"):
+                try:
+                    args.traffic_live = pmc_traffic_live(args.mode, args.catalogue)
+                except Exception as e:  # nothing about the profiler may cost the line that has already been measured
+                    args.traffic_live = (None, f"{type(e).__name__}: {e}")
             fresh = roofline_block(args, st, kernel_ms, W, H)
-            res["roofline"].update({k: fresh[k] for k in ("traffic", "traffic_kind", "traffic_source")})
+            res["roofline"].update({k: fresh[k] for k in ("traffic", "traffic_kind", "traffic_source", "frac_cycles", "busy_cycles_per_launch",
+                                                          "flop_per_cycle_peak", "frac_cycles_detail", "sclk_MHz_implied") if k in fresh})
+        sw.seconds["total_so_far"] = round(time.perf_counter() - T_START, 3)
+        res["leg_seconds"] = sw.seconds   # where this process's wall time went (the timed region itself is ms_per_step x steps)
         print(json.dumps(res), flush=True)
     tree.close()
     if dist_on:
@@ -516,6 +554,7 @@ def run_single_process(args):
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     world = args.gpus
     ndev = torch.cuda.device_count()
+    devices_or_die(world, ndev, os.environ.get("BLACKSTAR_BENCH_ALLOW_OVERSUBSCRIBE") == "1")
     devs = [i % ndev for i in range(world)]
     cfg_obj, cfg, frames_cfg, frames_obj = load_workload(args, bs)
     if args.form == "split":  # the split form has its own frame (configs[3]); the warm-up launches use it too
@@ -663,9 +702,12 @@ def run_single_process(args):
     if args.form == "split":
         split_headline(args, res, d2h["split"], world)
     res["per_rank_ms_per_step"] = per_rank_ms
+    label_roofline_scope(res, world, per_rank_ms)
+    if legs_failed(d2h):
+        res["legs_failed"] = legs_failed(d2h)
     if validation is not None:
         res["validation"] = validation
-        res["valid"] = bool(validation.get("valid", False)) and forms_valid(d2h)
+        res["valid"] = bool(validation.get("valid", False)) and forms_valid(d2h) and not legs_failed(d2h)
     if kms:
         res["per_rank_kernel_ms"] = [float(np.mean(x)) for x in kms]
     if t_gather is not None:

@@ -8,7 +8,7 @@ import subprocess
 import sys
 import time
 
-__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "d2h_forms", "png_files_leg", "write_rate_probe", "host_block", "predict_frames_8_gpus", "Stopwatch", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "split_headline", "result_line"]
+__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "cycles_view", "d2h_forms", "png_files_leg", "write_rate_probe", "host_block", "predict_frames_8_gpus", "Stopwatch", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "TIMED_CALLS", "pcie_zero_copy_probe", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "label_roofline_scope", "devices_or_die", "legs_failed", "split_headline", "result_line"]
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -140,11 +140,16 @@ def pmc_traffic(mode):
     return None, None
 
 
+N_XCD, N_CU, SIMD_PER_CU, LANES_PER_SIMD_F64 = 8, 256, 4, 16   # MI355X: 8 XCDs x 32 CUs, 4 SIMDs per CU, 16 f64 lanes per SIMD and cycle
+
+
 def pmc_traffic_live(mode, catalogue, timeout_s=60):
     """HBM bytes per launch of the trace kernel MEASURED NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- separate
-    runs, as MI355X_MICROARCH.md's HBM section prescribes) over scripts/prof_frame.py, which renders the same frame three times
-    through the C ABI in a child process.  Counters cannot be read from inside an un-profiled process, hence the children; timing is
-    never taken from them.  Returns (bytes, detail) or (None, why not)."""
+    runs, as MI355X_MICROARCH.md's HBM section prescribes: the two do not fit the TCC's slots together) over scripts/prof_frame.py, which
+    renders the same frame three times through the C ABI in a child process.  The WRITE_SIZE pass also carries GRBM_GUI_ACTIVE (the GRBM
+    block has slots of its own): the launch's busy cycles, summed over the 8 XCDs -- the clock-independent view of the same launch
+    (roofline.frac_cycles).  Counters cannot be read from inside an un-profiled process, hence the children; timing is never taken from
+    them.  Returns (bytes, detail) or (None, why not)."""
     import csv
     import glob
     import shutil
@@ -155,27 +160,57 @@ def pmc_traffic_live(mode, catalogue, timeout_s=60):
     got = {}
     work = tempfile.mkdtemp(prefix="bs_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--",
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE", "GRBM_GUI_ACTIVE")):
+            out = os.path.join(work, counters[0])
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "t", "--",
                    sys.executable, os.path.join(ROOT, "scripts", "prof_frame.py"), "--mode", mode, "--stars", catalogue, "--frames", "3"]
             try:
                 r = subprocess.run(cmd, cwd=work, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             except (OSError, subprocess.TimeoutExpired) as e:
-                return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
-            vals = []
+                return None, f"rocprofv3 --pmc {counters[0]}: {type(e).__name__}"
+            vals = {c: [] for c in counters}
             for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(fn) as f:
-                    vals += [float(row["Counter_Value"]) for row in csv.DictReader(f)
-                             if row.get("Counter_Name") == counter and "trace_frame" in row.get("Kernel_Name", "")]
-            if r.returncode != 0 or not vals:
-                return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(vals)} samples"
-            got[counter] = sum(vals) / len(vals)
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") in vals and "trace_frame" in row.get("Kernel_Name", ""):
+                            vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals[counters[0]]:
+                return None, f"rocprofv3 --pmc {counters[0]}: rc {r.returncode}, {len(vals[counters[0]])} samples"
+            for c, v in vals.items():
+                if v:
+                    got[c] = sum(v) / len(v)
+            if "GRBM_GUI_ACTIVE" in counters:
+                ns = []
+                for fn in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                    with open(fn) as f:
+                        ns += [int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) for row in csv.DictReader(f) if "trace_frame" in row.get("Kernel_Name", "")]
+                if ns:
+                    got["kernel_ns_in_pass"] = sum(ns) / len(ns)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     # KiB units; FETCH_SIZE doubled: the guide's gfx950 correction (an upper bound for this kernel's 32-byte star-grid reads)
-    return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, {"FETCH_SIZE_KiB": got["FETCH_SIZE"], "WRITE_SIZE_KiB": got["WRITE_SIZE"],
-                                                                   "launches_per_pass": 3}
+    detail = {"FETCH_SIZE_KiB": got["FETCH_SIZE"], "WRITE_SIZE_KiB": got["WRITE_SIZE"], "launches_per_pass": 3}
+    if "GRBM_GUI_ACTIVE" in got:
+        detail["GRBM_GUI_ACTIVE"] = got["GRBM_GUI_ACTIVE"]
+        if got.get("kernel_ns_in_pass"):
+            detail["kernel_ms_in_profiled_pass"] = got["kernel_ns_in_pass"] / 1e6
+            detail["sclk_MHz_in_profiled_pass"] = got["GRBM_GUI_ACTIVE"] / N_XCD / got["kernel_ns_in_pass"] * 1e3
+    return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, detail
+
+
+def cycles_view(flop_per_launch, gui_active, kernel_ms=None):
+    """The launch against the FP64 vector roof in CYCLES instead of seconds: flop / (busy cycles x 256 CUs x 4 SIMDs x 16 lanes x 2 flop
+    per FMA).  GRBM_GUI_ACTIVE is summed over the 8 XCDs, which all stay busy for the whole launch, so a launch's cycles = the counter / 8.
+    The same kernel on a box whose power cap holds 2.27 GHz and on one that holds 2.36 gives the same frac_cycles; `frac` (seconds) differs
+    by the clock ratio.  kernel_ms (the un-profiled launch time of this run) turns the cycles into the clock the chip averaged: the peak
+    78.6 TFLOP/s is this roof at 2.4 GHz."""
+    cycles = gui_active / N_XCD
+    per_cycle = N_CU * SIMD_PER_CU * LANES_PER_SIMD_F64 * 2
+    out = {"frac_cycles": flop_per_launch / (cycles * per_cycle), "busy_cycles_per_launch": cycles, "flop_per_cycle_peak": per_cycle,
+           "frac_cycles_detail": "145 flop x executed RK4 steps / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CU x 4 SIMD x 16 lanes x 2): clock-independent"}
+    if kernel_ms:
+        out["sclk_MHz_implied"] = cycles / (kernel_ms * 1e-3) / 1e6   # cycles of the profiled launch over the un-profiled duration
+    return out
 
 
 class Stopwatch:
@@ -361,23 +396,19 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                 call([frame_objs[i % len(frame_objs)] for i in range(n_warm)], [rings[i % n_t][(i // n_t) % 4] for i in range(n_warm)])
             except Exception as e:
                 err = f"{type(e).__name__}: {e}"
-        if os.environ.get("BLACKSTAR_BENCH_D2H_REPS") and err is None and all_ranks is None:  # diagnostic (one process): the same call several times, each timed (stderr)
-            for rep in range(int(os.environ["BLACKSTAR_BENCH_D2H_REPS"])):
-                fence()
-                t0 = time.perf_counter()
-                call(frame_objs, outs)
-                fence()
-                print(f"[d2h {form} rep {rep}] {(time.perf_counter() - t0) / (len(frame_objs) / n_t) * 1e3:.3f} ms per frame per GPU", file=sys.stderr)
-        fence()
-        t0 = time.perf_counter()
-        if err is None:
-            try:
-                got = call(frame_objs, outs)
-            except Exception as e:
-                err = f"{type(e).__name__}: {e}"
-        fence()
-        dt = max_over_ranks(float("inf") if err is not None else time.perf_counter() - t0)
-        if err is not None or dt == float("inf"):   # (every rank learns it through the max; the comparison below stays a collective for all)
+        each = []
+        for _ in range(TIMED_CALLS):   # the same blocking call TIMED_CALLS times, the faster one reported (20 frames are 90 ms: one host hiccup is 1 %)
+            fence()
+            t0 = time.perf_counter()
+            if err is None:
+                try:
+                    got = call(frame_objs, outs)
+                except Exception as e:
+                    err = f"{type(e).__name__}: {e}"
+            fence()
+            each.append(max_over_ranks(float("inf") if err is not None else time.perf_counter() - t0))
+        dt = min(each)
+        if err is not None or max(each) == float("inf"):   # (every rank learns it through the max; the comparison below stays a collective for all)
             identical_everywhere([])
             print(f"bench.py: delivered form {form!r} failed{'' if err is None else ': ' + err}", file=sys.stderr, flush=True)
             res[F["key"]] = {"error": err or "another rank failed", "entry_point": F["entry"]}
@@ -387,6 +418,7 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
         per_gpu = len(frame_objs) / n_t
         res[F["key"]] = {
             "Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
+            "seconds_each_call": [round(t, 6) for t in each],
             "bytes_to_host_per_frame": F["nbytes"](got), "entry_point": F["entry"], "note": F["note"],
             # (ring buffers: the distinct ones hold the last frame written into each; PNG: every file of the call)
             "frames_identical": identical_everywhere([bytes(g) for g in got] if form == "png-batch" else list({id(o): o for o in outs}.values()))}
@@ -442,7 +474,7 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
     if max_over_ranks(0.0 if base else 1.0) > 0:
         return {"skipped": f"no directory with {need >> 20} MiB free on some rank (/dev/shm, {tempfile.gettempdir()})"}
     d = tempfile.mkdtemp(prefix="blackstar_bench_", dir=base)
-    err, dt_local, size, files, fstats, probe = None, float("inf"), 0, None, None, None
+    err, size, files, fstats, probe = None, 0, None, None, None
     try:
         paths = [os.path.join(d, f"f{i:05d}.png") for i in range(len(frame_objs))]
         # untimed warm-up over at least WARM_PER_CONTEXT frames per context (like d2h_forms): the partition trial (a warm-up segment plus
@@ -454,13 +486,20 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
                 bs.render_png_files(frame_objs, trees, paths)
         except Exception as e:  # a failing rank still goes through the same fences and collectives as the others
             err = f"{type(e).__name__}: {e}"
-        fence()
-        t0 = time.perf_counter()
+        each_local = []
+        for rep in range(TIMED_CALLS):
+            fence()
+            t0 = time.perf_counter()
+            if err is None:
+                try:
+                    bs.render_png_files(frame_objs, trees, paths)
+                    each_local.append(time.perf_counter() - t0)
+                    if each_local[-1] <= min(each_local):
+                        fstats = [bs.files_stats(t) for t in trees] if hasattr(bs, "files_stats") else None
+                except Exception as e:
+                    err = f"{type(e).__name__}: {e}"
         if err is None:
             try:
-                bs.render_png_files(frame_objs, trees, paths)
-                dt_local = time.perf_counter() - t0
-                fstats = [bs.files_stats(t) for t in trees] if hasattr(bs, "files_stats") else None
                 size = sum(os.path.getsize(p) for p in paths)
                 if identical_everywhere is not None:  # read back before the directory goes (untimed; a few distinct files would do, all is simplest)
                     files = []
@@ -477,13 +516,16 @@ def png_files_leg(bs, trees, frame_objs, W, H, world, fence, max_over_ranks, ide
                 probe = {"error": f"{type(e).__name__}: {e}"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    dt = max_over_ranks(dt_local)
+    # per call the slowest rank, then the faster call (every rank takes part in every collective, also one that failed: its times are infinite)
+    each = [max_over_ranks(t) for t in (each_local if err is None and len(each_local) == TIMED_CALLS else [float("inf")] * TIMED_CALLS)]
+    dt = min(each)
     same = identical_everywhere(files or []) if identical_everywhere is not None else None   # (a collective when there are ranks: every rank calls it)
     if err is not None or dt == float("inf"):
         return {"error": err or "another rank failed"}
     frames = len(frame_objs) * world
     per_gpu = len(frame_objs) / len(trees)
     out = {"Mpixel_s": frames * W * H / dt / 1e6, "ms_per_frame_per_gpu": dt / per_gpu * 1e3, "frames": frames, "seconds": dt,
+           "seconds_each_call": [round(t, 6) for t in each],
            "frames_per_s": frames / dt, "bytes_written_per_frame": size // max(len(paths), 1), "entry_point": "bs_render_png_files",
            "directory": "RAM disk (/dev/shm)" if base == "/dev/shm" else base, "frames_identical": same, "warm_up_calls": warm_calls,
            "note": "scene to FILE: render -> bloom -> sRGB8 -> PNG encoder on the device; per context one rolling pipeline, a ring of page-locked file "
@@ -563,6 +605,7 @@ def digest_as_float(hexdigest):
     return float(int(hexdigest[:12], 16))
 
 
+TIMED_CALLS = 2         # timed calls per delivered form (the faster one is the form's figure; both are listed)
 WARM_PER_CONTEXT = 48   # frames per context of the delivered forms' untimed warm-up call (the partition trial needs 32, 40 on small frames)
 COUNTERS = ("rays", "steps", "capped", "horizon", "escaped", "disk_hits", "star_hits")
 
@@ -796,6 +839,8 @@ def roofline_block(args, st, kernel_ms, W, H, peak_measured=None):
          "traffic_source": traffic_src,
          "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                  "peak_GBs": PEAK_HBM_GBS, "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    if live and live[0] is not None and isinstance(live[1], dict) and live[1].get("GRBM_GUI_ACTIVE"):
+        r.update(cycles_view(flops, live[1]["GRBM_GUI_ACTIVE"], kernel_ms))
     if peak_measured:
         lv = LOOP_VALU[args.mode]
         # issue slots the stepping loop needs: every wavefront iteration issues full_rate + 4 * quarter_rate slots of 64 lanes
@@ -894,11 +939,52 @@ def boundary_numbers(bs, _lib, tree, cfg_obj, cfg, args, torch, out, stream):
     return res, strict
 
 
+def label_roofline_scope(res, world, per_rank_ms):
+    """Whose launches `roofline` describes.  N = 1: the one GPU's.  N > 1: RANK 0's (its HIP events, its bs_stats) -- a per-GPU figure, not
+    an aggregate -- with every rank's own fraction beside it, derived from that rank's step time (per_rank_ms_per_step; the frames have
+    the same flop count on every rank for a single-frame workload): min / mean / max show a straggler that rank 0's figure would hide."""
+    r = res.get("roofline")
+    if not isinstance(r, dict):
+        return
+    if world == 1:
+        r["scope"] = "the one GPU of this run"
+        return
+    r["scope"] = "per GPU, rank 0 (device 0): kernel time, counters and flop count are rank 0's; value / ms_per_step are the whole job's"
+    fl = r.get("flop_per_launch")
+    ms = [m for m in (per_rank_ms or []) if m and m > 0 and m != float("inf")]
+    if fl and ms and res.get("config", {}).get("launches_in_flight_per_gpu", 1) == 1:
+        fr = [fl / (m * 1e-3) / 1e12 / r["peak"] for m in ms]
+        r["frac_per_rank_from_step_time"] = {"min": min(fr), "mean": sum(fr) / len(fr), "max": max(fr), "ranks": len(fr),
+                                             "note": "flop_per_launch / that rank's ms per step / peak: includes the few-microsecond gap between launches, so slightly below frac"}
+
+
+def devices_or_die(world, ndev, allow_smoke):
+    """--gpus N on a box that shows SOME but not ALL of the devices (2 <= visible < N) is a broken lease, not a smoke run: refuse loudly
+    instead of putting several ranks on one device and printing a line that looks like a result.  One visible device is the documented
+    smoke mode (`oversubscribed: true`); BLACKSTAR_BENCH_ALLOW_OVERSUBSCRIBE=1 allows the in-between case for experiments."""
+    if world <= ndev or ndev == 1 or allow_smoke:
+        return
+    raise SystemExit(f"bench.py --gpus {world}: only {ndev} HIP devices are visible.  A device is missing (check the lease / HIP_VISIBLE_DEVICES / "
+                     f"ROCR_VISIBLE_DEVICES); refusing to oversubscribe {ndev} devices with {world} ranks.  (One visible device = the smoke mode; "
+                     f"BLACKSTAR_BENCH_ALLOW_OVERSUBSCRIBE=1 overrides.)")
+
+
 def forms_valid(d2h):
     """False if any delivered form of this line found frames that should be identical and are not."""
     if not isinstance(d2h, dict):
         return True
     return all(v.get("frames_identical") is not False and v.get("identical_to_one_device") is not False for v in d2h.values() if isinstance(v, dict))
+
+
+def legs_failed(d2h):
+    """The delivered forms / split leg of this line that ended in an error on some rank (a product entry point failed on a device): the
+    measurement of the other legs stands, but a reader of `valid` alone must not miss it -- bench.py puts the list in the line and makes
+    the line invalid."""
+    if not isinstance(d2h, dict):
+        return []
+    if "error" in d2h and not any(isinstance(v, dict) for v in d2h.values()):
+        return ["with_d2h"]
+    return sorted(k for k, v in d2h.items() if isinstance(v, dict) and "error" in v)
 
 
 def split_headline(args, res, blk, world):

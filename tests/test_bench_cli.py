@@ -117,18 +117,21 @@ def test_d2h_forms_drive_the_products_batch_entry_points_with_a_ring_of_four_buf
     frames = [f"cfg{i}" for i in range(30)]
     fences = []
     res = bench.d2h_forms(FakeBs, np, trees, frames, 16, 8, 1, ["batch", "rgb8-batch", "png-batch", "png-files"], lambda: fences.append(1), lambda x: x)
-    assert set(res) == {"batch", "rgb8_batch", "png_batch", "png_files"} and len(fences) == 8
+    assert set(res) == {"batch", "rgb8_batch", "png_batch", "png_files"}
+    assert bench.TIMED_CALLS == 2 and len(fences) == 3 * 4 + 3     # a fence either side of each timed call; png-files: one before each call, one after the last
     W = bench.WARM_PER_CONTEXT * 3   # the warm-up call is long enough for every context to measure the frame shape (the partition trial)
     assert W >= 32 * 3
-    assert [c[:3] for c in calls] == [("batch", W, 3), ("batch", 30, 3), ("rgb8", W, 3), ("rgb8", 30, 3), ("png", W, 3), ("png", 30, 3),
-                                      ] + [("files", 30, 3)] * 6  # warm-up call(s), timed call; png-files warms up 5 x 30 >= W frames too
+    assert [c[:3] for c in calls] == [("batch", W, 3), ("batch", 30, 3), ("batch", 30, 3), ("rgb8", W, 3), ("rgb8", 30, 3), ("rgb8", 30, 3),
+                                      ("png", W, 3), ("png", 30, 3), ("png", 30, 3),
+                                      ] + [("files", 30, 3)] * 7  # warm-up call(s), two timed calls (the faster is the figure); png-files warms up 5 x 30 >= W frames too
+    assert all(len(res[k]["seconds_each_call"]) == 2 and abs(res[k]["seconds"] - min(res[k]["seconds_each_call"])) < 1e-6 for k in res)
     assert res["png_files"]["warm_up_calls"] == 5
     assert res["png_files"]["bytes_written_per_frame"] == 77 and res["png_files"]["frames"] == 30 and res["png_files"]["entry_point"] == "bs_render_png_files"
-    del calls[6:]
+    del calls[9:]
     assert res["png_batch"]["entry_point"] == "bs_render_png_batch" and res["png_batch"]["bytes_to_host_per_frame"] == 40   # the mean file size
     host = res["png_batch"]["host_encoder_baseline"]      # the same frame through zlib on one host core, beside the device encoder's number
     assert set(host) == {"zlib_level1", "zlib_level6"} and all(v["bytes"] > 0 and v["ms_per_frame_one_core"] >= 0 for v in host.values())
-    assert calls[1][4] == np.float64 and calls[3][4] == np.uint8
+    assert calls[1][4] == np.float64 and calls[4][4] == np.uint8
     ids = calls[1][3]
     assert len(set(ids)) == 12                                   # 4 buffers x 3 contexts
     for i in range(30):
@@ -183,7 +186,7 @@ def test_png_files_leg_skips_on_every_rank_when_there_is_no_room(monkeypatch):
 
     collectives.clear()
     r = bench.png_files_leg(Failing, ["t"], ["c"] * 4, 16, 8, 2, lambda: fences.append(1), lambda x: (collectives.append(x), x)[1])
-    assert "disk full" in r["error"] and len(fences) == 2 and collectives == [0.0, float("inf")]   # same fences and collectives as a healthy rank
+    assert "disk full" in r["error"] and len(fences) == 3 and collectives == [0.0, float("inf"), float("inf")]   # same fences and collectives as a healthy rank (two timed calls)
 
 
 def test_device_sampler_reads_only_the_devices_it_was_given(tmp_path):
@@ -400,13 +403,16 @@ def test_parity_block_counts_what_is_outside_the_bar():
     json.dumps(off)
 
 
-def test_cpu_baseline_carries_parity_for_the_timed_frame_and_configs_0_and_1(monkeypatch):
+def test_cpu_baseline_carries_parity_for_all_five_baseline_configs(monkeypatch):
     """cpu_baseline keeps the oracle's frames (it used to throw them away) and compares them with what the product renders of the same
-    configs: FAST on the timed workload's sample, FAST + STRICT on configs[1], FAST on configs[0].  One value outside the bar, or a step
-    count that differs, makes parity_ok False (and bench.py then prints "valid": false)."""
+    configs: FAST on the timed workload's sample (configs[2]), FAST + STRICT on configs[1], FAST on configs[0], and -- round 6 -- FAST on
+    configs[3] (lensing-disk, down-scaled, supersampled) and on frames 0 / 300 / 599 of configs[4] (the animation).  One value outside the
+    bar, or a step count that differs, makes parity_ok False (and bench.py then prints "valid": false)."""
     from oracle import c_oracle, scenes
     from blackstar_amd import synthetic
     monkeypatch.setattr(scenes, "DEFAULT", scenes.with_res(scenes.DEFAULT, 160, 90))    # (the whole 1080p frames take the oracle seconds each)
+    monkeypatch.setattr(bench, "PARITY_C4_RES", (64, 36))
+    monkeypatch.setattr(bench, "PARITY_C5_RES", (48, 27))
     star_bytes = synthetic.catalogue_bytes("synthetic")
     ix = c_oracle.Index(c_oracle.read_ppm(star_bytes))
     calls = []
@@ -418,10 +424,14 @@ def test_cpu_baseline_carries_parity_for_the_timed_frame_and_configs_0_and_1(mon
     cfg = dict(scenes.DEFAULT_AA)
     blk = bench.cpu_baseline(cfg, star_bytes, 0.05, product, np)
     assert blk["kind"] == "port" and blk["cores"] >= 1 and blk["value"] > 0
-    assert [(p["mode"]) for p in blk["parity"]] == ["fast", "fast", "strict", "fast"] and blk["parity_ok"]
+    assert [(p["mode"]) for p in blk["parity"]] == ["fast", "fast", "strict", "fast", "fast", "fast", "fast", "fast"] and blk["parity_ok"]
     assert all(p["outside_1e-4"] == 0 and p["bit_identical"] and p["steps_equal"] and p["fates_equal"] for p in blk["parity"])
-    assert "BASELINE configs[2]" in blk["parity"][0]["config"] and "configs[1]" in blk["parity"][1]["config"] and "configs[0]" in blk["parity"][3]["config"]
+    assert [p["baseline_config"] for p in blk["parity"]] == ["configs[2]", "configs[1]", "configs[1]", "configs[0]", "configs[3]", "configs[4]", "configs[4]", "configs[4]"]
+    assert blk["parity_configs"] == ["configs[0]", "configs[1]", "configs[2]", "configs[3]", "configs[4]"]
+    assert "lensing-disk" in blk["parity"][4]["config"] and "frame 300" in blk["parity"][6]["config"] and "frame 599" in blk["parity"][7]["config"]
     assert calls[0][2] is True and calls[1][2] is False and calls[3][:2] == (640, 480) and "1e-4" in blk["parity_tolerance"]
+    assert calls[4] == (64, 36, True, "fast") and calls[7] == (48, 27, True, "fast")
+    assert blk["parity"][4]["counters_oracle_gpu"]["rays"] == [4 * 64 * 36] * 2            # supersampled like the config itself
 
     def wrong(c, with_stars, mode):
         img, st = product(c, with_stars, mode)

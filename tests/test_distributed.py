@@ -218,7 +218,8 @@ def _bench_validation_worker(rank, world, port, poison_rank, q, crash=False):
     val = bench.validation_block(gather_objs((digest, {k: (1000 + (1 if bad else 0) if k == "steps" else 5) for k in bench.COUNTERS})), "frame")
     dist.barrier()
     if crash:
-        q.put((rank, split.get("error"), forms["batch"].get("error"), bench.forms_valid({"split": split, "batch": forms["batch"]})))
+        q.put((rank, split.get("error"), forms["batch"].get("error"), bench.forms_valid({"split": split, "batch": forms["batch"]}),
+               bench.legs_failed({"split": split, "batch": forms["batch"]})))
     else:
         q.put((rank, split["identical_to_one_device"], split["bands"], split["parts"], forms["batch"]["frames_identical"], val["valid"],
                val["frames_identical_across_devices"], val["steps_per_device"]))
@@ -257,7 +258,8 @@ def test_two_process_bench_validation_tells_a_wrong_frame_on_one_rank(poison_ran
 def test_two_process_bench_legs_survive_a_rank_whose_render_fails():
     """The N > 1 line must not be lost -- or hang -- because an OPTIONAL leg fails on one rank: rank 1's bs_render_rows / bs_render_batch
     raise; both ranks still pass every fence and collective, both report {"error": ...} for the split leg and the delivered form (rank 1 its
-    own message, rank 0 "another rank failed"), and an errored optional leg does not by itself make the headline invalid."""
+    own message, rank 0 "another rank failed").  forms_valid only speaks about frames that were compared; the failed legs are NAMED
+    (legs_failed -> `legs_failed` in the line, which bench.py prints with "valid": false: a product entry point failed on a device)."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -277,3 +279,4 @@ def test_two_process_bench_legs_survive_a_rank_whose_render_fails():
     assert "BS_EDEVICE" in res[1][0] and "BS_ENOMEM" in res[1][1]
     assert res[0][0] == "another rank failed" and res[0][1] == "another rank failed"
     assert res[0][2] is True and res[1][2] is True
+    assert res[0][3] == ["batch", "split"] and res[1][3] == ["batch", "split"]
