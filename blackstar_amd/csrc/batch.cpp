@@ -442,13 +442,17 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
         }
         HIP_TRY(hipEventRecord(ctx->ev_frame[b], cs[b]));
     }
-    HIP_TRY(hipStreamSynchronize(cs[0]));
-    HIP_TRY(hipStreamSynchronize(cs[1]));
-    for (int b = 0; b < 2; b++) {   // (in frame order: the older of the two slots first)
+    // The last two frames, in frame order (the older slot first), each retired as soon as IT has left the device: a file goes to the
+    // writer while the frame behind it is still on the GPU, so only the very last file's write is not hidden behind rendering.
+    for (int b = 0; b < 2; b++) {
         const int slot = (k + b) & 1;
+        if (k - 2 + b < 0) continue;   // (a share of one frame has no older slot)
+        HIP_TRY(hipEventSynchronize(ctx->ev_frame[slot]));
         if (png && (rc = files.retire(ctx, slot, *png, cs[slot]))) return rc;
         if ((rc = deliver(slot))) return rc;
     }
+    HIP_TRY(hipStreamSynchronize(cs[0]));
+    HIP_TRY(hipStreamSynchronize(cs[1]));
     return BS_OK;
 }
 
@@ -646,12 +650,17 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
         }
         HIP_TRY(hipEventRecord(ctx->ev_posted[b], ps));
     }
+    // The last three frames in frame order, each retired as soon as IT has left the device (see the shared-chip pipeline above).
+    for (int j = 0; png && j < 3; j++) {
+        if (k - 3 + j < 0) continue;
+        const int b = (k + j) % 3;   // slot of frame k - 3 + j
+        HIP_TRY(hipEventSynchronize(ctx->ev_posted[b]));
+        if ((rc = files.retire(ctx, b, *png, posted_on[b]))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(pt.trace[0]));
     HIP_TRY(hipStreamSynchronize(pt.trace[1]));
     HIP_TRY(hipStreamSynchronize(pt.post));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int b = 0; png && b < 3; b++)
-        if ((rc = files.retire(ctx, b, *png, posted_on[b]))) return rc;
     return BS_OK;
 }
 // One context's share of bs_render_rgb8_batch / bs_render_png_batch: frames c, c + step, ... -- shared chip, partitioned, or the trial.
