@@ -45,8 +45,9 @@ for i in range(N):
         out["nonfinite_pattern_mismatch_scenes"] += 1
     cm = any(int(sa[k]) != int(ost[k]) for k in COUNTERS)
     out["strict_counter_mismatch_scenes"] += int(cm)
+    nonfinite_mismatch = int((np.isfinite(a) != fin).sum()) + int((np.isfinite(b) != fin).sum())   # a NaN / inf on one side only is OUTSIDE, whatever the comparison says
     da = np.abs(a - ref)[fin]
-    bad_a = int((da > 1e-14 + 1e-12 * np.abs(ref[fin])).sum())
+    bad_a = int((~(da <= 1e-14 + 1e-12 * np.abs(ref[fin]))).sum())   # (~(<=): a NaN from the GPU where the oracle is finite counts)
     out["strict_outside"] += bad_a
     out["strict_worst_abs"] = max(out["strict_worst_abs"], float(da.max()) if da.size else 0.0)
     out["strict_bit_identical_scenes"] += int(np.array_equal(a, ref, equal_nan=True))
@@ -55,7 +56,7 @@ for i in range(N):
     out["fast_step_mismatch_scenes"] += int(int(sb["steps"]) != int(ost["steps"]))
     out["fast_scenes_traced_in_strict"] += int(sb["effective_mode"] == _lib.BS_MODE_STRICT)
     db = np.abs(b - ref)
-    bad_b = int((db[fin] > 1e-7 + 1e-4 * np.abs(ref[fin])).sum())
+    bad_b = int((~(db[fin] <= 1e-7 + 1e-4 * np.abs(ref[fin]))).sum())
     out["fast_outside"] += bad_b
     out["fast_worst_abs"] = max(out["fast_worst_abs"], float(db[fin].max()) if fin.any() else 0.0)
     m = fin & (np.abs(ref) > 1e-3)
@@ -66,8 +67,8 @@ for i in range(N):
             y, x, c = (int(v) for v in np.unravel_index(int(np.argmax(rel)), rel.shape))
             out["fast_worst_rel"] = w
             out["fast_worst_rel_scene"] = dict(index=i, cfg=cfg, pixel=[y, x, c], oracle=float(ref[y, x, c]), fast=float(b[y, x, c]))
-    if (cm or bad_a or fm or bad_b) and len(out["bad"]) < 5:
-        out["bad"].append(dict(index=i, cfg=cfg, strict_counters_differ=cm, strict_outside=bad_a, fast_fates_differ=fm, fast_outside=bad_b,
+    if (cm or bad_a or fm or bad_b or nonfinite_mismatch) and len(out["bad"]) < 5:
+        out["bad"].append(dict(index=i, cfg=cfg, strict_counters_differ=cm, strict_outside=bad_a, fast_fates_differ=fm, fast_outside=bad_b, nonfinite_mismatch=nonfinite_mismatch,
                                oracle={k: int(ost[k]) for k in COUNTERS}, strict={k: int(sa[k]) for k in COUNTERS}))
 out["oracle_seconds"] = t_oracle
 out["oracle_threads"] = int(ost["threads"]) if N else 0

@@ -26,6 +26,8 @@ EXPORTS = {
     "Foreign.C.String": set("CString peekCString withCString newCString".split()),
     "Data.ByteString": set("packCStringLen writeFile readFile ByteString take drop null".split()),
     "Control.Exception": set("bracket bracket_ finally".split()),
+    "Control.Concurrent": set("runInBoundThread forkIO forkOS".split()),
+    "Control.Concurrent.MVar": set("MVar newMVar withMVar takeMVar putMVar".split()),
     "Control.Monad": set("when unless forM forM_ filterM replicateM_ void".split()),
     "Data.IORef": set("IORef newIORef readIORef writeIORef modifyIORef".split()),
     "System.IO.Unsafe": set("unsafePerformIO".split()),

@@ -7,6 +7,8 @@ import Foreign.C.Types
 import Foreign.C.String (CString, peekCString, withCString)
 import qualified Data.ByteString as B
 import Control.Exception (bracket)
+import Control.Concurrent (runInBoundThread)
+import Control.Concurrent.MVar (MVar, newMVar, withMVar)
 import Control.Monad (when, forM, forM_)
 import Data.IORef
 import System.IO.Unsafe (unsafePerformIO)
@@ -26,7 +28,9 @@ import StarMap (StarTree)
 data BsCtx
 -- the context plus its page-locked image buffers, which every frame reuses (allocating page-locked memory costs milliseconds;
 -- filling it does not fault): [(buffer, capacity in doubles)] -- one for renderGpu, two for renderBatch (two frames in flight per GPU)
-data GpuTree = GpuTree { gpuCtx :: Ptr BsCtx, gpuBufs :: IORef [(ForeignPtr CDouble, Int)] }
+-- gpuLock: a bs_ctx is driven by one thread at a time (include/blackstar_gpu.h); every single-context entry point below takes it, so two
+-- thunks of renderPure sparked in parallel queue up instead of racing on the context and its one reusable buffer.
+data GpuTree = GpuTree { gpuCtx :: Ptr BsCtx, gpuBufs :: IORef [(ForeignPtr CDouble, Int)], gpuLock :: MVar () }
 
 -- include/blackstar_gpu.h
 foreign import ccall safe   "bs_create"     c_bs_create  :: CInt -> Ptr () -> CSize -> IO (Ptr BsCtx)
@@ -69,13 +73,26 @@ withStars tree act = do
 lastError :: String -> IO a
 lastError what = c_bs_error >>= peekCString >>= \e -> ioError (userError (what ++ ": " ++ e))
 
+-- bs_last_error() is thread-local in the library, and under -threaded a `safe` foreign call may run on another OS thread than the next
+-- call of the same Haskell thread: a call that can fail and the fetch of its message are made from ONE bound thread.
+checked :: String -> IO CInt -> IO ()
+checked what call = runInBoundThread $ do
+  rc <- call
+  when (rc /= 0) $ lastError what
+
+checkedPtr :: String -> IO (Ptr a) -> IO (Ptr a)
+checkedPtr what call = runInBoundThread $ do
+  p <- call
+  when (p == nullPtr) $ lastError what
+  return p
+
 -- One context on one device; destroyed when the action returns or throws.
 withCtx :: Ptr () -> Int -> Int -> (GpuTree -> IO a) -> IO a
 withCtx buf n device act =
-  bracket (c_bs_create (fromIntegral device) buf (fromIntegral n)) (\ctx -> when (ctx /= nullPtr) (c_bs_destroy ctx)) $ \ctx -> do
-    when (ctx == nullPtr) $ lastError ("bs_create on device " ++ show device)
+  bracket (checkedPtr ("bs_create on device " ++ show device) (c_bs_create (fromIntegral device) buf (fromIntegral n))) c_bs_destroy $ \ctx -> do
     ref <- newIORef []
-    act (GpuTree ctx ref)
+    lock <- newMVar ()
+    act (GpuTree ctx ref lock)
 
 -- Upload the star set once (replaces handing `tree` to doStart, app/Main.hs:46-49).
 withGpuTree :: Int -> StarTree -> (GpuTree -> IO a) -> IO a
@@ -94,13 +111,12 @@ withGpuTrees devices tree act = do
 -- k page-locked image buffers of at least n doubles each, grown on demand and then reused by every frame (bs_host_free runs when
 -- the GC drops a buffer; the memory is hipHostMallocPortable: every device of the node may write it, and it may outlive the context).
 imageBuffers :: GpuTree -> Int -> Int -> IO [ForeignPtr CDouble]
-imageBuffers (GpuTree ctx ref) k n = do
+imageBuffers (GpuTree ctx ref _) k n = do
   have <- readIORef ref
   let (fit, _tooSmall) = partition ((>= n) . snd) have            -- (buffers that are too small are dropped: the GC frees them)
       keep = take k fit
   fresh <- forM [1 .. k - length keep] $ \_ -> do
-    p <- c_bs_host_alloc ctx (fromIntegral (8 * n))
-    when (p == nullPtr) $ lastError "bs_host_alloc"
+    p <- checkedPtr "bs_host_alloc" (c_bs_host_alloc ctx (fromIntegral (8 * n)))
     fp <- newForeignPtr p_bs_host_free p
     return (fp, n)
   writeIORef ref (keep ++ fresh ++ drop k fit)
@@ -122,15 +138,14 @@ pokeConfig p cfg = do
 
 -- Drop-in for `render cfg tree` (src/Raytracer.hs:53): same Config, same result type.
 renderGpu :: GpuTree -> Config -> IO (Image U RGB Double)
-renderGpu gpu@(GpuTree ctx _) cfg = do
+renderGpu gpu@(GpuTree ctx _ lock) cfg = withMVar lock $ \_ -> do
   let (w, h) = resolution (scene cfg)
       n = w * h * 3
   -- the caller owns the image: one page-locked buffer (bs_host_alloc), reused frame after frame.
   -- (mallocForeignPtrArray n also works, but a fresh pageable buffer per frame costs 8.7 instead of 4.5 ms per 1080p frame:
   --  bench.py's "boundary" block, bs_render_pageable vs bs_render_pinned.)
   [fp] <- imageBuffers gpu 1 n
-  rc <- allocaBytes 168 $ \pc -> pokeConfig pc cfg >> withForeignPtr fp (\po -> c_bs_render ctx pc po (fromIntegral n))
-  when (rc /= 0) $ lastError "bs_render"
+  checked "bs_render" $ allocaBytes 168 $ \pc -> pokeConfig pc cfg >> withForeignPtr fp (\po -> c_bs_render ctx pc po (fromIntegral n))
   -- interleaved RGB f64, row-major, y down == the Storable layout of `Pixel RGB Double`: view the buffer as a storable vector
   -- (no copy) and let massiv convert it to its unboxed planar form -- a COPY, so the buffer is free for the next frame.
   -- (fromVector is what the reference's own boxBlur returns its result with; newer massiv also has
@@ -138,7 +153,8 @@ renderGpu gpu@(GpuTree ctx _) cfg = do
   unboxedCopy fp w h
 
 -- `render cfg tree` as the PURE value app/Main.hs:109 hands to timeAction (src/Util.hs:37-45 forces it with deepseq and times that):
--- img <- timeAction "Rendering" $ renderPure gpu cfg.  One frame at a time per context, like the reference's own call.
+-- img <- timeAction "Rendering" $ renderPure gpu cfg.  The thunk MUST be forced inside the withGpuTree bracket that made `gpu` (timeAction
+-- does, at once): forced later it would call bs_render on a destroyed context.  Frames of one context are serialised by gpuLock.
 renderPure :: GpuTree -> Config -> Image U RGB Double
 renderPure gpu cfg = unsafePerformIO (renderGpu gpu cfg)
 {-# NOINLINE renderPure #-}
@@ -154,23 +170,22 @@ unboxedCopy fp w h = do
 -- Replaces the tail of doRender (app/Main.hs:109-123): img <- render cfg tree; final <- bloom ... img; writeImg outPath final.
 -- The file's bytes are made on the GPU; they decode to what writeImg's `A.map (toWord8 . fmap sRGB)` feeds its encoder.
 renderToFile :: GpuTree -> Config -> FilePath -> IO ()
-renderToFile (GpuTree ctx _) cfg outPath = do
+renderToFile (GpuTree ctx _ lock) cfg outPath = withMVar lock $ \_ -> do
   let scn = scene cfg
       (w, h) = resolution scn
   cap <- alloca $ \p -> do
-    rc <- c_bs_png_bound (fromIntegral w) (fromIntegral h) p
-    when (rc /= 0) $ lastError "bs_png_bound"
+    checked "bs_png_bound" $ c_bs_png_bound (fromIntegral w) (fromIntegral h) p
     peek p
   allocaBytes (fromIntegral cap) $ \buf -> alloca $ \pn -> do      -- (a reused bs_host_alloc buffer is written by the GPU itself)
-    rc <- allocaBytes 168 $ \pc -> pokeConfig pc cfg >>
+    checked "bs_render_png" $ allocaBytes 168 $ \pc -> pokeConfig pc cfg >>
             c_bs_render_png ctx pc (realToFrac (bloomStrength scn)) (fromIntegral (bloomDivider scn)) buf cap pn
-    when (rc /= 0) $ lastError "bs_render_png"
     n <- peek pn
     B.packCStringLen (castPtr buf, fromIntegral n) >>= B.writeFile outPath
 
 -- Replaces the directory loop of doStart (app/Main.hs:68-77: forM_ ... handleScene, i.e. doRender per scene file) in ONE foreign call:
 -- scene i is rendered, bloomed (strength 0 = no bloom, like app/Main.hs:113) and PNG-encoded on gpus !! (i mod N) and written to its
--- path while later scenes render -- two frames in flight per GPU, no collective, only the file's bytes cross PCIe.  Files are created
+-- path while later scenes render -- per GPU a rolling pipeline of frames in flight, its own file buffers and its own writer thread on the
+-- GPU's NUMA node; no collective, no GPU waits for another, only the file's bytes cross PCIe.  Files are created
 -- or truncated (what --force does; ask promptOverwriteFile BEFORE the call for the others, see the doStart edit below).
 renderScenesToFiles :: [GpuTree] -> [(Config, FilePath)] -> IO ()
 renderScenesToFiles gpus jobs = do
@@ -185,8 +200,8 @@ renderScenesToFiles gpus jobs = do
     withMany withCString (map snd jobs) $ \cpaths ->
     withArray cpaths $ \ppaths -> do
       forM_ (zip [0 ..] jobs) $ \(i, (cfg, _)) -> pokeConfig (pcfgs `plusPtr` (168 * i)) cfg
-      rc <- c_bs_render_png_files pctxs (fromIntegral (length gpus)) pcfgs (fromIntegral n) pstrengths pdividers ppaths 0
-      when (rc /= 0) $ lastError "bs_render_png_files"
+      checked "bs_render_png_files" $
+        c_bs_render_png_files pctxs (fromIntegral (length gpus)) pcfgs (fromIntegral n) pstrengths pdividers ppaths 0
 
 -- For a caller that keeps Haskell's bloom / writeImg: the frames of `cfgs` through bs_render_batch, frame i on gpus !! (i mod N), handed
 -- to `consume i img` in order.  Rounds of 2N frames go into 2N page-locked buffers (two per context, reused by every round; the kernels
@@ -208,9 +223,8 @@ renderBatch gpus cfgs consume = do
           bufs = take m slots
       allocaBytes (168 * m) $ \pcfgs -> do
         forM_ (zip [0 ..] chunk) $ \(j, cfg) -> pokeConfig (pcfgs `plusPtr` (168 * j)) cfg
-        rc <- withMany withForeignPtr bufs $ \ptrs -> withArray ptrs $ \pouts ->
+        checked "bs_render_batch" $ withMany withForeignPtr bufs $ \ptrs -> withArray ptrs $ \pouts ->
                 c_bs_render_batch pctxs (fromIntegral nGpu) pcfgs (fromIntegral m) pouts
-        when (rc /= 0) $ lastError "bs_render_batch"
       forM_ (zip3 [first ..] chunk bufs) $ \(i, cfg, fp) -> do
         let (w, h) = resolution (scene cfg)
         unboxedCopy fp w h >>= consume i
