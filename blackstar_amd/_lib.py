@@ -16,6 +16,7 @@ SO_PATH = os.environ.get("BLACKSTAR_LIB") or os.path.join(_HERE, "libblackstar_g
 BS_MODE_STRICT, BS_MODE_FAST = 0, 1
 BS_ABI_VERSION = 5  # include/blackstar_gpu.h
 BS_MAX_STEPS_LIMIT = 1 << 30
+BS_FAST_MAX_EXPECTED_STEPS = 2000  # include/blackstar_gpu.h
 # The test hooks (include/blackstar_gpu_debug.h) live in a library of their own, next to the product it was built with; only tests,
 # scripts/ and bench.py's issue-rate probe load it (debug_lib()).
 DEBUG_SO_PATH = SO_PATH[:-3] + "_debug.so" if SO_PATH.endswith(".so") else SO_PATH + "_debug"

@@ -24,6 +24,7 @@ struct bs_ctx {
     int disk_slots = 4;
     bool zero_copy = true;       // page-locked caller buffers are written by the kernel itself (env BLACKSTAR_ZERO_COPY=0: always stage + copy)
     bool fast_guard = true;      // FAST mode re-traces photon-sphere-grazing rays in STRICT (env BLACKSTAR_FAST_GUARD=0 turns it off for A/B)
+    double fast_max_steps = BS_FAST_MAX_EXPECTED_STEPS;   // FAST frames whose expected steps per ray exceed this are traced in STRICT (env BLACKSTAR_FAST_MAX_STEPS; 0 = no limit)
     int n_cu = 256;
     int blocks_per_cu = 4;       // resident workgroups per CU (VGPR/LDS-limited); env BLACKSTAR_BLOCKS_PER_CU for A/B builds
     int stagger_cycles = 16000;  // first-tile phase offset per SIMD slot (env BLACKSTAR_STAGGER overrides; 0 = off)
@@ -222,6 +223,7 @@ int copy_out(bs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, hipStrea
 int ensure_scratch(bs_ctx *ctx, size_t bytes);
 int post_cus_setting(int v);  // BLACKSTAR_POST_CUS as a number: 0 = never partition, otherwise a multiple of 4 in [8, 32]
 int effective_mode(const bs_ctx *ctx, const bs_config *cfg);
+double expected_steps(const bs_config *cfg);   // N0 = (|camera| + sqrt safeDistance) / stepSize
 
 // ---- host_topology.cpp ------------------------------------------------------------------------------------------------------------
 void probe_host_topology(bs_ctx *ctx);        // fills numa_node / numa_cpus / numa_bind (never fails: no information = no binding)

@@ -326,13 +326,33 @@ int ensure_scratch(bs_ctx *ctx, size_t bytes)
     return BS_OK;
 }
 // The arithmetic a frame is traced with.  FAST's error model (rounding differences of ~1 ulp per right-hand side, amplified by
-// the discrete map) needs the RK4 step to resolve the field: with stepSize above 0.5 Schwarzschild radii a single step past the
-// hole amplifies a perturbation by >10x and FAST and STRICT trajectories part ways (scripts/fuzz_worst.py: terminal directions
-// 4e-3 apart at stepSize 1.0, all of the fuzz's largest colour deviations), so such frames are traced with STRICT arithmetic even
-// in FAST mode -- the reference's default is 0.3 and every scene file it ships uses that.  (BLACKSTAR_FAST_GUARD=0: off, for A/B.)
+// the discrete map) needs two things of the frame, and a FAST context traces frames that lack either in STRICT -- at STRICT's cost, 2.4x
+// per step -- so that every frame stays inside the 1e-4 parity bar with a measured margin (BLACKSTAR_FAST_GUARD=0: both rules off, A/B):
+//  (1) a step that resolves the field: with stepSize above 0.5 Schwarzschild radii a single step past the hole amplifies a perturbation
+//      by >10x and FAST and STRICT trajectories part ways (terminal directions 4e-3 apart at stepSize 1.0, all of the round-2 fuzz's
+//      largest colour deviations).  The reference's default is 0.3 and every scene file it ships uses that.
+//  (2) a path of bounded length (round 6): the difference between FAST's and STRICT's terminal direction grows with the number of steps,
+//      about 1e-9 relative colour difference per expected step on a clustered sky (the star PSF exp(-d^2 / 2w^2) turns a direction
+//      difference e into up to 6000 e): over 3 560 random long-path scenes against the ORACLE (scripts/fuzz_longpath.py,
+//      profiles/r06_fuzz_oracle_longpath.json) the worst value is 1.8e-6 below N0 = 2 000 expected steps per ray, 1.2e-5 below 10 000,
+//      3.6e-5 below 30 000 and 2.2e-4 -- OUTSIDE the bar, 3 values -- between 30 000 and 100 000.  N0 = (|camera| + sqrt safeDistance) /
+//      stepSize, the longest straight path through the traced volume; above fast_max_steps (BS_FAST_MAX_EXPECTED_STEPS = 2 000: 57x
+//      inside the bar at worst) the frame is traced in STRICT.  The scenes the reference ships have N0 = 233 .. 523.
+double expected_steps(const bs_config *cfg)
+{
+    const double px = cfg->cam_pos[0], py = cfg->cam_pos[1], pz = cfg->cam_pos[2];
+    const double r2 = (px * px + py * py) + pz * pz;
+    const double twice = 2.0 * r2;
+    const double safe = (2500.0 <= twice) ? twice : 2500.0;   // src/Raytracer.hs:59-60
+    return (std::sqrt(r2) + std::sqrt(safe)) / cfg->step_size;
+}
+
 int effective_mode(const bs_ctx *ctx, const bs_config *cfg)
 {
-    if (ctx->mode == BS_MODE_FAST && ctx->fast_guard && !(cfg->step_size <= 0.5)) return BS_MODE_STRICT;
+    if (ctx->mode == BS_MODE_FAST && ctx->fast_guard) {
+        if (!(cfg->step_size <= 0.5)) return BS_MODE_STRICT;
+        if (ctx->fast_max_steps > 0 && !(expected_steps(cfg) <= ctx->fast_max_steps)) return BS_MODE_STRICT;
+    }
     return ctx->mode;
 }
 }  // namespace bs
@@ -371,6 +391,7 @@ try {
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
     if (const char *m = std::getenv("BLACKSTAR_STAGGER_MIN_TILES")) ctx->stagger_min_tiles = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
+    if (const char *m = std::getenv("BLACKSTAR_FAST_MAX_STEPS")) ctx->fast_max_steps = std::max(0.0, std::atof(m));   // (0: no long-path rule; for measurements)
     if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_HOST_BANDS")) ctx->host_bands = std::max(1, std::min((int)bs_ctx::kMaxHostBands, std::atoi(m)));
     if (const char *m = std::getenv("BLACKSTAR_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, std::min(8, std::atoi(m)));

@@ -70,14 +70,19 @@ enum {
  *         by 4x at worst, not bit-exact.  The clustered figure is the star lookup's doing, not the integrator's: a star's weight
  *         exp(-d^2 / (2 * 0.0005^2)) (src/StarMap.hs:99-110) turns a terminal-direction difference e into up to 6000 e of relative difference,
  *         and its scene -- stepSize 0.05 from 318 radii away, 14 000 steps per ray, e = 4e-9, a pixel summing a dense cluster band -- is
- *         replayed by name against the oracle in tests/test_gpu_parity.py (FUZZ_WORST).  Two guards keep it there (without them the fuzz's worst
- *         case was 2.3e-5: rays grazing the photon sphere amplify any rounding difference): a ray that orbits the
- *         hole (more steps than the longest straight path plus one photon-sphere circumference; a few per million)
- *         is re-traced with STRICT arithmetic inside the same kernel, and a frame whose stepSize exceeds 0.5 (the
- *         RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether -- at STRICT's cost,
- *         2.4x FAST's per step (C3 frame: 10.4 vs 4.4 ms at stepSize 0.3).  bs_effective_mode(ctx, cfg) tells which arithmetic
- *         a frame will get and bs_stats_t.effective_mode which one the last render got.  The reference's default stepSize
- *         is 0.3 and every scene file it ships uses that. */
+ *         replayed by name against the oracle in tests/test_gpu_parity.py (FUZZ_WORST).  That difference grows with the LENGTH of the path: over
+ *         3 560 random long-path scenes against the CPU oracle (profiles/r06_fuzz_oracle_longpath.json; clustered sky) the worst value is
+ *         1.8e-6 below 2 000 expected steps per ray, 1.2e-5 below 10 000, 3.6e-5 below 30 000 and 2.2e-4 -- outside the bar -- between 30 000
+ *         and 100 000 (the reference's own scenes: 233 .. 523).  Three guards keep every FAST frame inside the bar with a measured margin:
+ *         a ray that orbits the hole (more steps than the longest straight path plus one photon-sphere circumference; a few per million;
+ *         rays grazing the photon sphere amplify any rounding difference) is re-traced with STRICT arithmetic inside the same kernel; a
+ *         frame whose stepSize exceeds 0.5 (the RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether;
+ *         and so is (round 6) a frame whose expected steps per ray N0 = (|camera.position| + sqrt safeDistance) / stepSize exceed
+ *         BS_FAST_MAX_EXPECTED_STEPS -- both at STRICT's cost, 2.4x FAST's per step (C3 frame: 10.4 vs 4.4 ms at stepSize 0.3).  With them the
+ *         worst FAST value measured anywhere is 1.8e-6 relative (57x inside the bar).  bs_effective_mode(ctx, cfg) tells which arithmetic a
+ *         frame will get and bs_stats_t.effective_mode which one the last render got.  The reference's default stepSize is 0.3 and every
+ *         scene file it ships uses that. */
+#define BS_FAST_MAX_EXPECTED_STEPS 2000
 enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
 
 /* Replaces the `Config` argument of render (src/ConfigFile.hs:16-38), AS PARSED: radii un-squared,
@@ -309,11 +314,11 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
 
 /* Environment read ONCE, at bs_create (A/B switches for measurements; a host application sets none of them): BLACKSTAR_MODE=strict|fast
  * (initial bs_set_mode), BLACKSTAR_POST_CUS (see bs_render_rgb8_batch), BLACKSTAR_ZERO_COPY=0, BLACKSTAR_FAST_GUARD=0, BLACKSTAR_HOST_BANDS,
- * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS, BLACKSTAR_NUMA_BIND=0. */
+ * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS, BLACKSTAR_NUMA_BIND=0, BLACKSTAR_FAST_MAX_STEPS. */
 int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST */
 int bs_get_mode(const bs_ctx *ctx);
 /* The arithmetic a render of `cfg` on this context would be traced with: bs_get_mode(), except that a FAST context traces frames
- * with stepSize > 0.5 in STRICT (see BS_MODE_FAST above).  Returns BS_MODE_* or BS_EINVAL.  For batch frames (whose statistics
+ * with stepSize > 0.5, or with more than BS_FAST_MAX_EXPECTED_STEPS expected steps per ray, in STRICT (see BS_MODE_FAST above).  Returns BS_MODE_* or BS_EINVAL.  For batch frames (whose statistics
  * are not kept) this is the only way to know; perf numbers and A/B comparisons should record it. */
 int bs_effective_mode(const bs_ctx *ctx, const bs_config *cfg);
 /* Safety cap on colorize' iterations per ray; the reference has none (src/Raytracer.hs:80-86).  Default 100000.  1 <= max_steps <=

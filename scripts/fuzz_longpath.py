@@ -3,8 +3,9 @@
 for their expected steps per ray N0 = (|cam| + sqrt(safeDistance)) / stepSize, log-uniform in [N0_MIN, N0_MAX] (the reference's own scenes:
 230; the round-5 fuzz reached 14 000), on the CLUSTERED sky (a star's weight exp(-d^2 / 2w^2) turns a terminal-direction difference e into
 up to 6000 e of relative colour difference -- the amplifier that made the round-5 worst case).  Each scene is rendered by the CPU ORACLE,
-by the HIP library in STRICT and in FAST with the guard rule switched OFF (BLACKSTAR_FAST_GUARD=0 for the long-path rule only is not
-separable, so the rule's threshold is passed in: scenes above it are traced in STRICT by the library and counted as such).
+by the HIP library in STRICT and in FAST.  Run with BLACKSTAR_FAST_MAX_STEPS=0 (no long-path rule: FAST's own arithmetic at every length --
+how the rule's threshold was chosen) or without it (the library as shipped: frames above BS_FAST_MAX_EXPECTED_STEPS are traced in STRICT
+and counted as such).
 Reports, per decade-third of N0: scenes, FAST's worst relative / absolute deviation from the oracle, values outside the parity bar
 |gpu - cpu| <= 1e-4 |cpu| + 1e-7, step / fate equality; STRICT against the oracle (must be exact in counters, 1e-12 in values).
 Usage: fuzz_longpath.py [N_SCENES [SEED [N0_MAX [WIDTH HEIGHT]]]]"""
@@ -91,7 +92,7 @@ for i in range(N):
         B["worst_scene"] = dict(index=i, n0=n0, mean_steps_per_ray=ost["steps"] / ost["rays"], cfg=cfg)
     records.append([round(n0, 1), round(ost["steps"] / ost["rays"], 1), rel, float(db[fin].max()) if fin.any() else 0.0, out_b,
                     int(sb["effective_mode"] == _lib.BS_MODE_STRICT)])
-print(json.dumps(dict(scenes=N, seed=SEED, sky="clustered", stars=len(tree), frame=[W, H], cap=CAP, n0_range=[N0_MIN, N0_MAX], oracle_seconds=t_oracle,
+print(json.dumps(dict(scenes=N, seed=SEED, sky="clustered", BLACKSTAR_FAST_MAX_STEPS=os.environ.get("BLACKSTAR_FAST_MAX_STEPS", "unset (the library's rule applies)"), stars=len(tree), frame=[W, H], cap=CAP, n0_range=[N0_MIN, N0_MAX], oracle_seconds=t_oracle,
                       n0_definition="(|cam| + sqrt(max(2500, 2 |cam|^2))) / stepSize: the longest straight path through the traced volume, in steps",
                       bins=[b for b in bins if b["scenes"]],
                       per_scene_columns=["n0", "mean_steps_per_ray", "fast_worst_rel", "fast_worst_abs", "fast_outside", "traced_in_strict"],
