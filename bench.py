@@ -31,7 +31,7 @@ line carries, measured after the timed region (--form all, the default):
   validation / valid   after the timed region every device renders the same frame once more: the frames must be BIT-IDENTICAL across
                        devices (sha256) and the step counters equal; every delivered form compares its frames too (frames_identical).
                        A mismatch makes the line "valid": false -- a speed-up is only a result if the other GPUs rendered the scene
-  sustained            500 more frames on one stream with per-50-frame times and sampled sclk / power (clock droop under the
+  sustained            300 more frames on one stream with per-50-frame times and sampled sclk / power (clock droop under the
                        package power cap is visible here, not in 20 launches)
 --catalogue clustered | PATH swaps the uniform synthetic sky for the non-uniform one or a real PPM catalogue file (reported as such).
 Which key answers BASELINE's ">= 6x at 8 GPUs": for frames (configs[4], and the headline) value(N=8) / value(N=1) of the driver's own runs
@@ -193,7 +193,7 @@ def parse_args():
     ap.add_argument("--no-validate", action="store_true",
                     help="skip the untimed validation after the timed region (every device renders the same frame once more; the frames must be "
                          "bit-identical and the step counters equal)")
-    ap.add_argument("--sustained-frames", type=int, default=500, help="frames of the `sustained` leg after the timed region (0 disables)")
+    ap.add_argument("--sustained-frames", type=int, default=300, help="frames of the `sustained` leg after the timed region (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 disables)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bs_render / bs_render_rgb8 / STRICT / ubench legs at N=1")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes/launch measured elsewhere (overrides --traffic)")

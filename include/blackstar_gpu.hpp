@@ -100,8 +100,17 @@ public:
         ctx_ = bs_create(device, stars.data(), stars.size());
         if (!ctx_) throw std::runtime_error(std::string("bs_create: ") + bs_last_error());
     }
-    // The arithmetic a render of cfg would be traced with (FAST contexts trace stepSize > 0.5 in STRICT): bs_effective_mode
+    // The arithmetic a render of cfg would be traced with (FAST contexts trace stepSize > 0.5 and paths of more than
+    // BS_FAST_MAX_EXPECTED_STEPS expected steps per ray in STRICT): bs_effective_mode
     int effectiveMode(const bs_config &c) const { return bs_effective_mode(ctx_, &c); }
+    // What this tree's writer did in the last renderToFiles call (bs_files_stats), and the NUMA node of its GPU (bs_numa_node; -1 unknown)
+    bs_files_stats_t filesStats() const
+    {
+        bs_files_stats_t st;
+        if (bs_files_stats(ctx_, &st)) throw std::runtime_error(std::string("bs_files_stats: ") + bs_last_error());
+        return st;
+    }
+    int numaNode() const { return bs_numa_node(ctx_); }
     StarTree(const StarTree &) = delete;
     StarTree &operator=(const StarTree &) = delete;
     ~StarTree() { bs_destroy(ctx_); }
@@ -208,7 +217,8 @@ inline std::vector<unsigned char> renderPng(const Config &cfg, const StarTree &t
 }
 
 // doStart's loop over doRender (app/Main.hs:68-77, :105-123) including writeImg's write: scene i is rendered on trees[i % trees.size()]
-// and its PNG file written to paths[i] by the library (frames in flight, a writer thread) -- one call for a directory of scenes
+// and its PNG file written to paths[i] by the library (per tree: a rolling pipeline of frames in flight, its own ring of page-locked file
+// buffers and its own writer thread, on the GPU's NUMA node) -- one call for a directory of scenes
 inline void renderToFiles(const std::vector<Config> &cfgs, const std::vector<const StarTree *> &trees, const std::vector<std::string> &paths)
 {
     if (cfgs.size() != paths.size()) throw std::runtime_error("renderToFiles: one path per scene");

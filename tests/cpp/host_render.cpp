@@ -47,6 +47,10 @@ int main(int argc, char **argv)
             std::vector<std::string> paths;
             for (int k = 0; k < 3; k++) paths.push_back(std::string(argv[2]) + "." + std::to_string(k) + ".png");
             renderToFiles({cfg, cfg, cfg}, {&tree}, paths);
+            {   // the context's own writer wrote them (bs_files_stats): three files, their bytes, from a ring of at least four buffers
+                const bs_files_stats_t st = tree.filesStats();
+                if (st.files != 3 || st.bytes != 3 * file.size() || st.writer_threads != 1 || st.ring < 4 || st.numa_node_gpu != tree.numaNode()) return 11;
+            }
             for (const std::string &p : paths) {
                 FILE *r = std::fopen(p.c_str(), "rb");
                 if (!r) return 9;

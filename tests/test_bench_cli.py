@@ -27,7 +27,7 @@ def test_help_and_defaults():
     finally:
         sys.argv = old
     assert (a.gpus, a.steps, a.warmup, a.form, a.catalogue, a.mode, a.workload) == (1, 20, 10, "all", "synthetic", "fast", "default-aa")
-    assert a.sustained_frames == 500 and a.cpu_seconds > 0
+    assert a.sustained_frames == 300 and a.cpu_seconds > 0
 
 
 def test_no_gpu_means_no_result_not_a_fallback():
