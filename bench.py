@@ -244,6 +244,8 @@ def run_ranks(args):
     if backend != "nccl":
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
+    # one process per GPU: this rank's threads on the GPU's NUMA node (BLACKSTAR_NUMA_BIND=0 leaves them alone, like the library's own binding)
+    binding = bind_rank_to_gpu_node(torch, local_rank) if os.environ.get("BLACKSTAR_NUMA_BIND", "1") != "0" else {"bound": False, "why": "BLACKSTAR_NUMA_BIND=0"}
     rccl = None
     # BLACKSTAR_BENCH_FORCE_DIST=1 (set by `--launcher torchrun --gpus 1`): one rank still goes through init_process_group, the all_gathers,
     # the barrier, all_gather_object, --gather's dist.gather and destroy_process_group -- the RCCL branch executed on ONE GPU, so that an
@@ -462,7 +464,8 @@ def run_ranks(args):
         extra = {"backend": ("RCCL (nccl)" if backend == "nccl" else backend) + ("" if world > 1 else " -- forced at world 1: BLACKSTAR_BENCH_FORCE_DIST")
                             if dist_on else "none (single rank)",
                  "devices_visible": ndev, "oversubscribed": world > ndev, "launches_in_flight_per_gpu": n_streams,
-                 "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])]}
+                 "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])],
+                 "rank0_cpu_binding": binding}
         if n_streams > 1:
             extra["launches_in_flight_note"] = ("consecutive frames alternate between two streams and share the GPU, so kernel_ms "
                                                 "(per-launch event time) exceeds ms_per_step")

@@ -8,7 +8,7 @@ import subprocess
 import sys
 import time
 
-__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "pmc_traffic", "pmc_traffic_live", "cycles_view", "d2h_forms", "png_files_leg", "write_rate_probe", "host_block", "predict_frames_8_gpus", "Stopwatch", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "TIMED_CALLS", "pcie_zero_copy_probe", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "label_roofline_scope", "devices_or_die", "legs_failed", "split_headline", "result_line"]
+__all__ = ["ROOT", "FLOP_PER_STEP", "PEAK_FP64_VALU_TFLOPS", "PEAK_HBM_GBS", "LOOP_VALU", "WORKLOAD_C3", "WORKLOAD_C5", "WORKLOADS", "workload_config", "CATALOGUES", "catalogue_note", "DeviceSampler", "pci_bus_of", "bind_rank_to_gpu_node", "pmc_traffic", "pmc_traffic_live", "cycles_view", "d2h_forms", "png_files_leg", "write_rate_probe", "host_block", "predict_frames_8_gpus", "Stopwatch", "sustained_leg", "frame_digest", "digest_as_float", "WARM_PER_CONTEXT", "TIMED_CALLS", "pcie_zero_copy_probe", "COUNTERS", "validation_block", "per_config_block", "predict_bands", "split_leg", "optional_leg", "roofline_block", "measure_peak", "boundary_numbers", "forms_valid", "label_roofline_scope", "devices_or_die", "legs_failed", "split_headline", "result_line"]
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -115,6 +115,31 @@ class DeviceSampler:
                 d["power_W_max"] = max(acc["power_uW"]) / 1e6
             out.append(d)
         return out or None
+
+
+def bind_rank_to_gpu_node(torch, d):
+    """One process per GPU: run this rank's threads on the CPUs of the NUMA node its GPU hangs off (sysfs local_cpulist of the device's PCI
+    function, restricted to what the process may use) -- on a two-socket 8-GPU node half of the ranks would otherwise drive a GPU across
+    the socket link.  The library binds the threads IT starts itself (bs::NumaBind); this covers the rank's own Python thread, which
+    enqueues the resident form's launches.  Returns what was done, for the result line; never raises."""
+    try:
+        pr = torch.cuda.get_device_properties(d)
+        bdf = f"{int(pr.pci_domain_id):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(base + "/numa_node").read().split()[0])
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        use = cpus & allowed
+        if node < 0 or not use or use == allowed:
+            return {"pci": bdf, "numa_node": node, "bound": False, "why": "the host gives no node for the device, or the node is all this process may use"}
+        os.sched_setaffinity(0, use)
+        return {"pci": bdf, "numa_node": node, "bound": True, "cpus": len(use)}
+    except (OSError, ValueError, AttributeError, RuntimeError) as e:
+        return {"bound": False, "why": f"{type(e).__name__}: {e}"}
 
 
 def pci_bus_of(torch, d):
