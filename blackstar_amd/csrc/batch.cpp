@@ -273,7 +273,7 @@ struct FileRing {
     void loop()
     {
         bs::NumaBind on_node(ctx);
-        writer_bound = on_node.bound();
+        writer_bound = on_node.bound() || ctx->numa_confined;
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             cv_work.wait(lk, [&] { return !jobs.empty() || closing; });

@@ -142,6 +142,7 @@ struct bs_ctx {
     int numa_node = -1;               // /sys/bus/pci/devices/<bdf>/numa_node; -1: unknown
     cpu_set_t numa_cpus;              // that node's CPUs, restricted to what the process may use
     bool numa_bind = false;           // binding would change something (env BLACKSTAR_NUMA_BIND=0: never)
+    bool numa_confined = false;       // the whole process is confined to that node's CPUs already: nothing to bind, every thread is on the node
     // Staging for caller memory that is NOT page-locked (context.cpp: copy_in / copy_out): two page-locked pieces, used alternately
     static constexpr size_t kStageBytes = size_t(8) << 20;
     unsigned char *h_stage[2] = {nullptr, nullptr};

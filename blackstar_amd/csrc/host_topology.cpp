@@ -63,6 +63,7 @@ void probe_host_topology(bs_ctx *ctx)
 {
     ctx->numa_node = -1;
     ctx->numa_bind = false;
+    ctx->numa_confined = false;
     CPU_ZERO(&ctx->numa_cpus);
     if (const char *m = std::getenv("BLACKSTAR_NUMA_BIND"))
         if (std::atoi(m) == 0) return;   // A/B switch: leave every thread where the caller's scheduler puts it
@@ -84,7 +85,8 @@ void probe_host_topology(bs_ctx *ctx)
     CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
     CPU_AND(&ctx->numa_cpus, &node_cpus, &allowed);
-    ctx->numa_bind = CPU_COUNT(&ctx->numa_cpus) > 0 && !CPU_EQUAL(&ctx->numa_cpus, &allowed);   // (nothing to do when the node is all we may use)
+    ctx->numa_confined = CPU_COUNT(&ctx->numa_cpus) > 0 && CPU_EQUAL(&ctx->numa_cpus, &allowed);   // the process may only run on the node anyway (e.g. bound by its launcher)
+    ctx->numa_bind = CPU_COUNT(&ctx->numa_cpus) > 0 && !ctx->numa_confined;
 }
 
 // The NUMA node the page at p lives on (move_pages(2) with a null node list only queries), or -1: not resident, not a page the kernel

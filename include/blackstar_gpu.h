@@ -293,7 +293,7 @@ typedef struct bs_files_stats_t {
     int32_t writer_threads;     /* 1; 0: no thread could be started and the pipeline's own thread wrote the files */
     int32_t numa_node_gpu;      /* bs_numa_node(ctx) */
     int32_t numa_node_buffers;  /* the node the ring's pages live on (bs_host_page_node); -1 unknown, -2 not all on one node */
-    int32_t threads_bound;      /* 1: the writer ran with its affinity set to the CPUs of numa_node_gpu (so did the pipeline's thread) */
+    int32_t threads_bound;      /* 1: the writer and the pipeline's thread ran on the CPUs of numa_node_gpu (bound by the library, or the process is confined to them) */
     int32_t _pad;
 } bs_files_stats_t;
 int bs_files_stats(const bs_ctx *ctx, bs_files_stats_t *out);
