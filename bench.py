@@ -158,6 +158,30 @@ def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None, baseline_c
     return res
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout -- but native libraries write there too (RCCL's version banner, gloo's "connected to N peer
+    ranks", profiler notes).  From here on file descriptor 1 is stderr's for everybody in this process; the result line alone goes to the
+    real stdout, kept aside in _RESULT_FD (emit)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(res):
+    line = (json.dumps(res) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+        return
+    while line:
+        line = line[os.write(_RESULT_FD, line):]
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -537,7 +561,7 @@ def run_ranks(args):
                                                           "flop_per_cycle_peak", "frac_cycles_detail", "sclk_MHz_implied") if k in fresh})
         sw.seconds["total_so_far"] = round(time.perf_counter() - T_START, 3)
         res["leg_seconds"] = sw.seconds   # where this process's wall time went (the timed region itself is ms_per_step x steps)
-        print(json.dumps(res), flush=True)
+        emit(res)
     tree.close()
     if dist_on:
         dist.destroy_process_group()
@@ -720,7 +744,7 @@ def run_single_process(args):
         res["with_d2h"] = d2h
     if sustained:
         res["sustained"] = sustained
-    print(json.dumps(res), flush=True)
+    emit(res)
     for t in trees:
         t.close()
 
@@ -745,6 +769,8 @@ def reexec_under_torchrun(args):
 
 def main():
     args = parse_args()
+    if args.launcher != "torchrun" or "WORLD_SIZE" in os.environ:   # (the re-exec form's parent prints nothing itself: its ranks claim theirs)
+        claim_stdout()
     if "WORLD_SIZE" in os.environ:
         run_ranks(args)
     elif args.launcher == "torchrun":
