@@ -700,20 +700,7 @@ def run_single_process(args):
         d2h = optional_leg("with_d2h", resident, lambda: d2h_forms(bs, np, trees, objs, W, H, 1, want, fence, lambda x: x, same_frames=frames_obj is None,
                                                                    split=lambda: split_leg(bs, np, trees, 0, 1, fence, lambda x: x, lambda o: [o])))
 
-    def sustained_block():
-        n_sus = args.sustained_frames // 50 * 50
-        with DeviceSampler([pci_bus_of(torch, d) for d in devs]) as smp:
-            wall, per_dev = sustained_leg(bs, torch, np, trees, [cfg if frames_cfg is None else frames_cfg[k % len(frames_cfg)] for k in range(world)],
-                                          outs, streams, devs, n_sus)
-        worst = max(p["ms_per_frame"] for p in per_dev) if world <= ndev else wall / n_sus * 1e3
-        return dict(per_dev[0], frames=n_sus, Mpixel_s=world * W * H / (wall / n_sus * 1e3) / 1e3, wall_ms_per_round=wall / n_sus * 1e3,
-                    per_rank_ms_per_frame=[p["ms_per_frame"] for p in per_dev], slowest_device_ms_per_frame=worst, device=smp.summary(),
-                    note="back-to-back launches of the same frame, one stream per device, all devices at once; Mpixel_s from the wall clock")
-
-    sustained = None
-    if args.sustained_frames >= 50 and resident:
-        sustained = optional_leg("sustained", True, sustained_block)
-
+    # (the sustained leg with its clock sampler belongs to the one-process-per-GPU form: run_ranks)
     extra = {"backend": "none (one process, one bs_ctx + stream per device; frames never leave their GPU)",
              "devices_visible": ndev, "oversubscribed": world > ndev, "devices": devs, "launches_in_flight_per_gpu": n_streams,
              "catalogue": args.catalogue, "n_stars": int(len(stars)), "effective_mode": ["strict", "fast"][int(st["effective_mode"])]}
@@ -742,8 +729,6 @@ def run_single_process(args):
         res["config"]["gather"] = "peer copy of every device's last frame to device 0 inside the timed region"
     if d2h:
         res["with_d2h"] = d2h
-    if sustained:
-        res["sustained"] = sustained
     emit(res)
     for t in trees:
         t.close()

@@ -459,20 +459,6 @@ def d2h_forms(bs, np, trees, frame_objs, W, H, world, forms, fence, max_over_ran
                     "worth of DDR5 is several hundred GB/s")
             except Exception as e:
                 res[F["key"]]["host"] = {"error": f"{type(e).__name__}: {e}"}
-        if form == "png-batch" and hasattr(bs, "render_rgb8") and os.environ.get("BLACKSTAR_BENCH_HOST_ENCODER") == "1":
-            # (BLACKSTAR_BENCH_HOST_ENCODER=1) what the same file costs the way the reference makes it (JuicyPixels over zlib, one core): this frame's pixels through zlib
-            # on ONE host core, the Sub-filtered scanlines at levels 1 and 6 -- a reported baseline like cpu_baseline, outside every timed region
-            import zlib
-            px = bs.render_rgb8(frame_objs[0], trees[0])
-            sub = px.copy()
-            sub[:, 1:] -= px[:, :-1]
-            raw = b"".join(b"\x01" + sub[y].tobytes() for y in range(px.shape[0]))
-            host = {}
-            for level in (1, 6):
-                t0 = time.perf_counter()
-                z = zlib.compress(raw, level)
-                host[f"zlib_level{level}"] = {"ms_per_frame_one_core": (time.perf_counter() - t0) * 1e3, "bytes": len(z)}
-            res[F["key"]]["host_encoder_baseline"] = host
         del rings, outs, got
     return res
 
