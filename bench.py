@@ -447,7 +447,8 @@ def run_ranks(args):
             d2h = optional_leg("with_d2h", world == 1 and resident,
                                lambda: d2h_forms(bs, np, [tree], my_frames(args.steps), W, H, world, want, fence, lambda x: max(all_ranks(x)),
                                                  same_frames=frames_obj is None, all_ranks=all_ranks if dist_on else None,
-                                                 split=lambda: split_leg(bs, np, [tree], rank, world, fence, lambda x: max(all_ranks(x)), gather_objs)))
+                                                 split=lambda: split_leg(bs, np, [tree], rank, world, fence, lambda x: max(all_ranks(x)), gather_objs),
+                                                 extras=rank == 0))   # (host probes on the rank that prints: eight ranks probing one file system at once would measure each other)
 
     def sustained_block():
         n_sus = args.sustained_frames // 50 * 50
