@@ -414,14 +414,16 @@ def test_render_png_files_writes_what_render_png_returns(tree, tmp_path):
         cfgs.append(c)
     want = [bytes(bs.render_png(c, tree)) for c in cfgs]
     paths = [str(tmp_path / f"f{k}.png") for k in range(11)]
+    mine = os.sched_getaffinity(0)
     bs.render_png_files(cfgs, [tree], paths, pipe=2)
+    assert os.sched_getaffinity(0) == mine                    # the caller's thread was only borrowed: its affinity is back
     assert [open(p, "rb").read() for p in paths] == want
     st = bs.files_stats(tree)
     assert st["files"] == 11 and st["bytes"] == sum(map(len, want)) and st["ring"] == 4 and st["writer_threads"] == 1
     assert 0 < st["writer_busy_ms"] <= st["wall_ms"] and 0 < st["writer_busy_frac"] <= 1 and st["buffer_wait_ms"] >= 0
     assert st["numa_node_gpu"] == tree.numa_node()
-    if st["numa_node_gpu"] >= 0:    # the host says where the GPU hangs: the library's page-locked buffers are on that node
-        assert st["numa_node_buffers"] == st["numa_node_gpu"], st
+    if st["numa_node_gpu"] >= 0:    # the host says where the GPU hangs: the library's page-locked buffers are on that node, its threads on that node's CPUs
+        assert st["numa_node_buffers"] == st["numa_node_gpu"] and st["threads_bound"] == 1, st
     t2 = bs.StarTree(tree.stars)
     try:
         two = [str(tmp_path / f"g{k}.png") for k in range(11)]
