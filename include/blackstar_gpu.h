@@ -65,23 +65,23 @@ enum {
  * FAST:   the same discrete RK4 map evaluated in the ray's orbital plane with FMA-accumulated stage sums and
  *         r^-5 from v_rsq_f64 + a 2nd-order series correction.  Step counts, fates and disk crossings equal
  *         STRICT's on every ray tested; pixel values agree with STRICT to 3.4e-8 absolute / 3.7e-7 relative
- *         on the BASELINE frames; over the committed 100 000-scene fuzz runs (profiles/r05_fuzz_modes_100000.json, 2.7e9 values each) the worst
- *         is 1.1e-6 relative on a uniform sky and 2.3e-5 on a CLUSTERED one (r05_fuzz_modes_clustered_100000.json) -- inside the 1e-4 relative bar
- *         by 4x at worst, not bit-exact.  The clustered figure is the star lookup's doing, not the integrator's: a star's weight
- *         exp(-d^2 / (2 * 0.0005^2)) (src/StarMap.hs:99-110) turns a terminal-direction difference e into up to 6000 e of relative difference,
- *         and its scene -- stepSize 0.05 from 318 radii away, 14 000 steps per ray, e = 4e-9, a pixel summing a dense cluster band -- is
- *         replayed by name against the oracle in tests/test_gpu_parity.py (FUZZ_WORST).  That difference grows with the LENGTH of the path: over
- *         3 560 random long-path scenes against the CPU oracle (profiles/r06_fuzz_oracle_longpath.json; clustered sky) the worst value is
- *         1.8e-6 below 2 000 expected steps per ray, 1.2e-5 below 10 000, 3.6e-5 below 30 000 and 2.2e-4 -- outside the bar -- between 30 000
- *         and 100 000 (the reference's own scenes: 233 .. 523).  Three guards keep every FAST frame inside the bar with a measured margin:
- *         a ray that orbits the hole (more steps than the longest straight path plus one photon-sphere circumference; a few per million;
- *         rays grazing the photon sphere amplify any rounding difference) is re-traced with STRICT arithmetic inside the same kernel; a
- *         frame whose stepSize exceeds 0.5 (the RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether;
- *         and so is (round 6) a frame whose expected steps per ray N0 = (|camera.position| + sqrt safeDistance) / stepSize exceed
- *         BS_FAST_MAX_EXPECTED_STEPS -- both at STRICT's cost, 2.4x FAST's per step (C3 frame: 10.4 vs 4.4 ms at stepSize 0.3).  With them the
- *         worst FAST value measured anywhere is 1.8e-6 relative (57x inside the bar).  bs_effective_mode(ctx, cfg) tells which arithmetic a
- *         frame will get and bs_stats_t.effective_mode which one the last render got.  The reference's default stepSize is 0.3 and every
- *         scene file it ships uses that. */
+ *         on the BASELINE frames -- inside the 1e-4 relative bar of north_star, not bit-exact.  Over the committed fuzz runs on this
+ *         library (profiles/r06_fuzz_modes_100000.json, r06_fuzz_modes_clustered_100000.json: 100 000 random scenes and 2.7e9 values
+ *         each, FAST against STRICT; r06_fuzz_oracle_*.json: 5 500 scenes against the CPU oracle) the worst value is 5.1e-7 relative on a
+ *         uniform sky and 3.8e-6 on a CLUSTERED one: 26x inside the bar at worst.  The clustered figure is the star lookup's doing, not
+ *         the integrator's: a star's weight exp(-d^2 / (2 * 0.0005^2)) (src/StarMap.hs:99-110) turns a terminal-direction difference e into
+ *         up to 6000 e of relative difference.  Three guards keep it there:
+ *         (1) a ray that orbits the hole (more steps than the longest straight path plus one photon-sphere circumference; a few per
+ *             million; rays grazing the photon sphere amplify any rounding difference) is re-traced with STRICT arithmetic inside the kernel;
+ *         (2) a frame whose stepSize exceeds 0.5 (the RK4 step no longer resolves the field next to the hole) is traced in STRICT altogether;
+ *         (3) so is (round 6) a frame whose expected steps per ray N0 = (|camera.position| + sqrt safeDistance) / stepSize exceed
+ *             BS_FAST_MAX_EXPECTED_STEPS: FAST's direction difference grows with the LENGTH of the path.  Measured with this rule off, over
+ *             3 560 long-path scenes against the oracle (profiles/r06_fuzz_oracle_longpath.json; clustered sky): worst value 1.8e-6 below
+ *             2 000 expected steps, 1.2e-5 below 10 000, 3.6e-5 below 30 000 and 2.2e-4 -- OUTSIDE the bar -- between 30 000 and 100 000
+ *             (round 5's worst case, 2.3e-5, was such a scene: stepSize 0.05 from 318 radii away, 14 000 steps; FUZZ_WORST in
+ *             tests/test_gpu_parity.py replays it by name).  The reference's own scene files have N0 = 233 .. 523.
+ *         (2) and (3) cost STRICT's time, 2.4x FAST's per step (C3 frame: 10.7 vs 4.4 ms at stepSize 0.3).  bs_effective_mode(ctx, cfg) tells
+ *         which arithmetic a frame will get and bs_stats_t.effective_mode which one the last render got. */
 #define BS_FAST_MAX_EXPECTED_STEPS 2000
 enum { BS_MODE_STRICT = 0, BS_MODE_FAST = 1 };
 
