@@ -28,26 +28,42 @@ using namespace bs;
 // be started (std::system_error: EAGAIN under a process / thread limit) must not become an exception in an `extern "C"` function, which
 // would end the process: its body runs on the calling thread instead, after the others have been started.
 // Whichever thread runs body(c) does so on the CPUs of context c's NUMA node (bs::NumaBind; the caller's own thread gets its affinity back).
+// No exception leaves a body -- on a worker thread it would end the process, on the calling thread it would unwind past joinable
+// threads --: it is translated like at the ABI (abi_exception: std::bad_alloc -> BS_ENOMEM, else BS_EINTERNAL) and returned, with its
+// message, after every thread has been joined.  BS_OK otherwise (the bodies report their own errors through what they capture).
 template <class Body>
-static void per_context(bs_ctx *const *ctxs, int n, Body inner)
+static int per_context(bs_ctx *const *ctxs, int n, Body inner)
 {
+    std::vector<int> thrown((size_t)n, BS_OK);
+    std::vector<std::string> what((size_t)n);
     auto body = [&](int c) {
-        bs::NumaBind on_node(ctxs[c]);
-        inner(c);
-    };
-    if (n == 1) { body(0); return; }
-    std::vector<std::thread> th;
-    std::vector<int> inline_later;
-    th.reserve((size_t)n);
-    for (int c = 0; c < n; c++) {
         try {
-            th.emplace_back(body, c);
-        } catch (const std::system_error &) {
-            inline_later.push_back(c);
+            bs::NumaBind on_node(ctxs[c]);
+            inner(c);
+        } catch (...) {
+            thrown[(size_t)c] = bs::abi_exception("a per-context thread");
+            try { what[(size_t)c] = bs::error_message(); } catch (...) {}
         }
+    };
+    if (n == 1) {
+        body(0);
+    } else {
+        std::vector<std::thread> th;
+        std::vector<int> inline_later;
+        th.reserve((size_t)n);
+        for (int c = 0; c < n; c++) {
+            try {
+                th.emplace_back(body, c);
+            } catch (const std::system_error &) {
+                inline_later.push_back(c);
+            }
+        }
+        for (int c : inline_later) body(c);
+        for (auto &t : th) t.join();
     }
-    for (int c : inline_later) body(c);
-    for (auto &t : th) t.join();
+    for (int c = 0; c < n; c++)
+        if (thrown[(size_t)c]) return fail(thrown[(size_t)c], what[(size_t)c]);
+    return BS_OK;
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -150,10 +166,11 @@ try {
     // collective: frames are independent (app/Main.hs:72-77 renders them one after another).
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
-    per_context(ctxs, n_ctx, [&](int c) {
+    const int thrown = per_context(ctxs, n_ctx, [&](int c) {
         rcs[c] = render_frames_pipelined(ctxs[c], cfgs, outs, c, n_frames, n_ctx);
         if (rcs[c]) errs[c] = bs::error_message();
     });
+    if (thrown) return thrown;
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
@@ -759,10 +776,11 @@ static int render_post_batch(bs_ctx *const *ctxs, int n_ctx, const bs_config *cf
     if (int rc = distinct_contexts(ctxs, n_ctx)) return rc;
     std::vector<int> rcs(n_ctx, BS_OK);
     std::vector<std::string> errs(n_ctx);
-    per_context(ctxs, n_ctx, [&](int c) {
+    const int thrown = per_context(ctxs, n_ctx, [&](int c) {
         rcs[c] = run_share(ctxs[c], cfgs, n_frames, bloom_strengths, bloom_dividers, outs, png, c, n_ctx);
         if (rcs[c]) errs[c] = bs::error_message();
     });
+    if (thrown) return thrown;
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
@@ -809,9 +827,16 @@ try {
         for (FileRing *r : rings)
             if (r) r->wake();
     };
-    per_context(ctxs, n_ctx, [&](int c) {
+    // (an exception in one context's body must stop the others too: they would otherwise render their whole share into a call that fails)
+    struct StopOnUnwind {
+        decltype(stop_all) &f;
+        bool armed = true;
+        ~StopOnUnwind() { if (armed) f(); }
+    };
+    const int thrown = per_context(ctxs, n_ctx, [&](int c) {
         bs_ctx *x = ctxs[c];
         if (c >= n_frames) return;
+        StopOnUnwind on_unwind{stop_all};
         const double t0 = now_ms();
         FileRing ring;
         ring.ctx = x;
@@ -834,19 +859,30 @@ try {
         }
         if (rcs[c] != BS_OK) { stop_all(); return; }
         ring.start();
+        struct Registered {   // other contexts' stop_all may wake this ring only while it is alive (declared after it: destroyed before it)
+            std::vector<FileRing *> &all;
+            std::mutex &m;
+            int c;
+            Registered(std::vector<FileRing *> &a, std::mutex &mm, int cc, FileRing *r) : all(a), m(mm), c(cc)
+            {
+                std::lock_guard<std::mutex> lk(m);
+                all[(size_t)c] = r;
+            }
+            ~Registered()
+            {
+                std::lock_guard<std::mutex> lk(m);
+                all[(size_t)c] = nullptr;
+            }
+        };
+        int rc;
         {
-            std::lock_guard<std::mutex> lk(rings_m);
-            rings[c] = &ring;
-        }
-        const PngSink sink{nullptr, nullptr, &ring};
-        int rc = run_share(x, cfgs, n_frames, bloom_strengths, bloom_dividers, nullptr, &sink, c, n_ctx);
-        if (rc && rc != kCancelled) {
-            errs[c] = bs::error_message();
-            stop_all();
-        }
-        {
-            std::lock_guard<std::mutex> lk(rings_m);
-            rings[c] = nullptr;
+            Registered reg(rings, rings_m, c, &ring);
+            const PngSink sink{nullptr, nullptr, &ring};
+            rc = run_share(x, cfgs, n_frames, bloom_strengths, bloom_dividers, nullptr, &sink, c, n_ctx);
+            if (rc && rc != kCancelled) {
+                errs[c] = bs::error_message();
+                stop_all();
+            }
         }
         ring.close();   // the writer finishes what it was handed and is joined (also on every error path: ~FileRing does the same)
         if (!ring.error.empty()) {   // its own file failed: that is this context's error, whatever the pipeline returned because of it
@@ -869,7 +905,9 @@ try {
             if (bs::numa_node_of_page(b) != node) node = -2;   // (mixed)
         st.numa_node_buffers = node;
         st.threads_bound = ring.threaded ? (ring.writer_bound ? 1 : 0) : 0;
+        on_unwind.armed = false;
     });
+    if (thrown) return thrown;
     // the first context (in index order) with an error of its own decides; a context that was merely stopped has none
     for (int c = 0; c < n_ctx; c++)
         if (rcs[c] && rcs[c] != kCancelled) return fail(rcs[c], errs[c]);
@@ -890,11 +928,12 @@ try {
     const int base = cfg->height / n, extra = cfg->height % n;
     std::vector<int> rcs(n, BS_OK);
     std::vector<std::string> errs(n);
-    per_context(ctxs, n, [&](int c) {
+    const int thrown = per_context(ctxs, n, [&](int c) {
         const int row0 = c * base + std::min(c, extra), row1 = row0 + base + (c < extra ? 1 : 0);
         rcs[c] = bs_render_rows(ctxs[c], cfg, row0, row1, out_rgb + (size_t)row0 * cfg->width * 3, (size_t)(row1 - row0) * cfg->width * 3);
         if (rcs[c]) errs[c] = bs::error_message();
     });
+    if (thrown) return thrown;
     for (int c = 0; c < n; c++)
         if (rcs[c]) return fail(rcs[c], errs[c]);
     return BS_OK;
