@@ -74,7 +74,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 static int render_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, double *const *outs, int first, int n_frames, int step)
 {
     if (first >= n_frames) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     size_t need = 0;
     for (int i = first; i < n_frames; i += step) {
         if (cfgs[i].width <= 0 || cfgs[i].height <= 0 || !outs[i]) return fail(BS_EINVAL, "bad frame");
@@ -404,7 +404,7 @@ static int render_rgb8_frames_pipelined(bs_ctx *ctx, const bs_config *cfgs, cons
                                         int first, int n_frames, int step, const PngSink *png, std::vector<double> *done_ms = nullptr)
 {
     if (first >= n_frames) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     size_t need = 0;
     int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, first, n_frames, step, &need);
     if (rc) return rc;
@@ -572,7 +572,8 @@ static void plan_share(bs_ctx *ctx, const bs_config *cfgs, const double *strengt
 // false: the runtime would not make them (no CU-mask support on this device / driver) -- the caller falls back to the shared chip.
 static bool ensure_partition(bs_ctx *ctx, int post_cus)
 {
-    if (post_cus < 8 || post_cus > 32 || post_cus % 4 != 0 || hipSetDevice(ctx->device) != hipSuccess) return false;
+    const bs::OnDevice on_device(ctx->device);
+    if (post_cus < 8 || post_cus > 32 || post_cus % 4 != 0 || !on_device.ok()) return false;
     bs_ctx::Partition &pt = ctx->parts[(post_cus - 8) / 4];
     if (pt.post) return true;
     const int words = (ctx->n_cu + 31) / 32;
@@ -604,7 +605,7 @@ static int render_rgb8_frames_partitioned(bs_ctx *ctx, int post_cus, const bs_co
                                           unsigned char *const *outs, int first, int n_frames, int step, const PngSink *png, std::vector<double> *done_ms = nullptr)
 {
     if (first >= n_frames) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     size_t need = 0;
     int rc = check_rgb8_share(cfgs, strengths, dividers, outs, png, first, n_frames, step, &need);
     if (rc) return rc;
@@ -687,17 +688,18 @@ static int run_share(bs_ctx *x, const bs_config *cfgs, int n_frames, const doubl
     int post_cus = 0;
     bool trial = false;
     bs_ctx::PartitionKey key{};
+    const bs::OnDevice on_device(x->device);   // (the pipelines below check it themselves: BS_ON_DEVICE)
     plan_share(x, cfgs, strengths, dividers, c, n_frames, step, png != nullptr, &post_cus, &trial, &key);
     // Only with page-locked outputs, which the last kernel of a frame writes itself: a copy into PAGEABLE memory blocks the
     // host thread until the frame's post stage has finished -- 3.8 ms on 8 CUs instead of 0.2 ms on the whole chip -- and the
     // next trace kernel is not enqueued meanwhile (measured 9.1 against 4.8 ms per frame: scripts/post_partition_pageable_ab.py)
     const bool to_ring = png && png->ring;   // (a ring's buffers are the library's own page-locked memory: one look at the first is enough)
-    if ((post_cus || trial) && to_ring && (hipSetDevice(x->device) != hipSuccess || !device_alias_of_pinned(x, png->ring->bufs[0], png->ring->cap))) {
+    if ((post_cus || trial) && to_ring && (!on_device.ok() || !device_alias_of_pinned(x, png->ring->bufs[0], png->ring->cap))) {
         post_cus = 0;
         trial = false;
     }
     for (int i = c; (post_cus || trial) && !to_ring && i < n_frames; i += step) {
-        if (!outs[i] || cfgs[i].width <= 0 || cfgs[i].height <= 0 || hipSetDevice(x->device) != hipSuccess ||
+        if (!outs[i] || cfgs[i].width <= 0 || cfgs[i].height <= 0 || !on_device.ok() ||
             !device_alias_of_pinned(x, outs[i], png ? (size_t)bs::png_file_bound(cfgs[i].width, cfgs[i].height) : (size_t)cfgs[i].width * cfgs[i].height * 3)) {
             post_cus = 0;
             trial = false;

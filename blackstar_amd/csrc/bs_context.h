@@ -173,6 +173,35 @@ size_t ctx_layout_bytes();                    // sizeof(bs_ctx) as the product l
         if (e_ != hipSuccess) return bs::fail(BS_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// The calling thread's current HIP device is the context's while this object lives and the CALLER's again afterwards: a host application
+// that drives other devices from the same thread (torch, another library, its own kernels) finds its current device as it left it after
+// every call into this library.  (A thread whose current device is the context's already pays one hipGetDevice.)
+struct OnDevice {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipErrorInvalidDevice;
+    explicit OnDevice(int device)
+    {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+        err = prev == device ? hipSuccess : hipSetDevice(device);
+        switched = err == hipSuccess && prev >= 0 && prev != device;
+    }
+    OnDevice(const OnDevice &) = delete;
+    OnDevice &operator=(const OnDevice &) = delete;
+    ~OnDevice()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    bool ok() const { return err == hipSuccess; }
+};
+#define BS_ON_DEVICE(ctx)                     \
+    bs::OnDevice on_device_((ctx)->device);   \
+    if (!on_device_.ok()) return bs::fail(BS_EDEVICE, std::string("hipSetDevice: ") + hipGetErrorString(on_device_.err))
+
 // On every exit path of a blocking entry point nothing of the call may still be in flight: the caller's buffers are DMA
 // targets, and after an error return the caller is free to release them.  (On the success path the streams have been
 // synchronised already and this costs a few microseconds.)

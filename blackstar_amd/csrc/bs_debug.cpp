@@ -37,7 +37,7 @@ try {
     if (int rc = check_png_frame(width, height)) return rc;
     const size_t nb = bs::png_block_count(width, height);
     if (n_clocks < nb * bs::kPngPhases) return fail(BS_EINVAL, "clocks: blocks * 23 entries are required (blocks = ceil(height * (3 width + 1) / 8192))");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     const size_t n = (size_t)width * height * 3;
     if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
     int rc = ensure_png(ctx, bs_ctx::kPngSingle, width, height, true);
@@ -112,7 +112,7 @@ try {
     int rc = fill_params(ctx, cfg, p);
     if (rc) return rc;
     if (n_rays == 0) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     const size_t yx_bytes = (n_rays * 2 * sizeof(int32_t) + 255) & ~size_t(255);
     rc = ensure_scratch(ctx, yx_bytes + n_rays * sizeof(bs_ray_record));
     if (rc) return rc;
@@ -127,7 +127,7 @@ try {
 int bs_debug_ubench(bs_ctx *ctx, int kind, int blocks, int iters, double *out_ms, double *out_ginstr)
 try {
     if (!ctx || !out_ms || blocks <= 0 || iters <= 0) return fail(BS_EINVAL, "bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     double *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 64));
     hipError_t e = hipSuccess;
@@ -149,7 +149,7 @@ int bs_debug_sqrt_div(bs_ctx *ctx, const double *a, const double *b, size_t n, d
 try {
     if (!ctx || (n && (!a || !b || !out_sqrt || !out_div))) return fail(BS_EINVAL, "null argument");
     if (n == 0) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     double *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 4 * n * sizeof(double)));
     int rc = copy_in(ctx, d, a, n * sizeof(double), ctx->stream);

@@ -69,7 +69,9 @@ static void quiesce(bs_ctx *ctx)
 
 ForeignWork::~ForeignWork()
 {
-    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+    if (!ctx) return;
+    const OnDevice on_device(ctx->device);
+    if (!on_device.ok()) return;
     for (hipStream_t own : {ctx->stream, ctx->stream2, ctx->copy_stream})
         if (own && own == s) return;
     for (const bs_ctx::Partition &pt : ctx->parts)
@@ -100,7 +102,9 @@ ForeignWork::~ForeignWork()
 
 StreamDrain::~StreamDrain()
 {
-    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+    if (!ctx) return;
+    const OnDevice on_device(ctx->device);
+    if (!on_device.ok()) return;
     for (hipStream_t s : {ctx->stream, ctx->stream2, ctx->copy_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (const bs_ctx::Partition &pt : ctx->parts)
@@ -422,7 +426,8 @@ try {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
     }
-    bool good = ok(hipSetDevice(device), "hipSetDevice") &&
+    const bs::OnDevice on_device(device);   // (declared after `owner`: the caller's device comes back before a failed context is destroyed, bs_destroy sets its own)
+    bool good = ok(on_device.err, "hipSetDevice") &&
                 ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
                 ok(hipEventCreate(&ctx->ev_u0), "hipEventCreate") && ok(hipEventCreate(&ctx->ev_u1), "hipEventCreate") &&
                 ok(hipMalloc((void **)&ctx->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(bs::StarNode)), "hipMalloc nodes") &&
@@ -469,7 +474,8 @@ try {
 void bs_destroy(bs_ctx *ctx)
 try {
     if (!ctx) return;
-    if (ctx->device >= 0 && hipSetDevice(ctx->device) == hipSuccess) {
+    const bs::OnDevice on_device(ctx->device);
+    if (on_device.ok()) {
         // Everything THIS context enqueued has finished before its memory goes -- and nothing else is waited for: the context's own streams,
         // and, for work the caller had enqueued on streams of their own (*_device entry points), the event the context recorded behind
         // every such call, error returns included (ForeignWork; also every launch slot's ev_done, the blur / PNG scratch's ev_post / ev_png).
@@ -565,7 +571,8 @@ void *bs_host_alloc(bs_ctx *ctx, size_t bytes)
 try {
     if (!ctx || bytes == 0) { fail(BS_EINVAL, "null context or zero size"); return nullptr; }
     void *p = nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+    const bs::OnDevice on_device(ctx->device);
+    if (!on_device.ok() || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
         fail(BS_ENOMEM, "hipHostMalloc failed");
         return nullptr;
     }

@@ -48,7 +48,7 @@ try {
     if (!ctx || !d_in || !d_out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
     if (divider <= 0 || width / divider == 0)  // the reference crashes here: foldl1' over an empty window (ImageFilters.hs:59)
         return fail(BS_EINVAL, "bloom radius (width `div` bloomDivider) must be >= 1");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     ForeignWork seen_by_destroy(ctx, hip_stream);
     size_t n = (size_t)width * height * 3;
     int rc = ensure_post(ctx, n);
@@ -64,7 +64,7 @@ try {
 int bs_bloom(bs_ctx *ctx, const double *in, double *out, int width, int height, double strength, int divider)
 try {
     if (!ctx || !in || !out || width <= 0 || height <= 0) return fail(BS_EINVAL, "bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     size_t n = (size_t)width * height * 3;
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
@@ -83,7 +83,7 @@ try {
     if (!ctx || !in || !out || width2 < 0 || height2 < 0) return fail(BS_EINVAL, "bad argument");
     const size_t n_in = (size_t)width2 * height2 * 3, n_out = (size_t)(width2 / 2) * (height2 / 2) * 3;
     if (n_out == 0) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     int rc = ensure_post(ctx, n_in);
     if (rc) return rc;
     StreamDrain drain(ctx);
@@ -102,7 +102,7 @@ try {
 int bs_srgb8_device(bs_ctx *ctx, const void *d_in, void *d_out_u8, size_t n_values, void *hip_stream)
 try {
     if (!ctx || (n_values && (!d_in || !d_out_u8))) return fail(BS_EINVAL, "bad argument");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     ForeignWork seen_by_destroy(ctx, hip_stream);   // (the kernel reads the context's sRGB8 table)
     if (bs::launch_srgb8((const double *)d_in, (unsigned char *)d_out_u8, n_values, ctx->d_srgb_table, hip_stream)) return fail(BS_EDEVICE, "srgb8 launch failed");
     return BS_OK;
@@ -112,7 +112,7 @@ int bs_srgb8(bs_ctx *ctx, const double *in, unsigned char *out, size_t n_values)
 try {
     if (!ctx || (n_values && (!in || !out))) return fail(BS_EINVAL, "bad argument");
     if (n_values == 0) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     int rc = ensure_post(ctx, n_values);
     if (rc) return rc;
     if (ctx->u8_cap < n_values) {
@@ -163,7 +163,7 @@ try {
     const size_t n = (size_t)cfg->width * cfg->height * 3;
     if (out_bytes < n) return fail(BS_EINVAL, "output buffer too small");
     if (int rc = check_bloom_args(cfg->width, bloom_strength, bloom_divider)) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     int rc = ensure_post(ctx, n);
     if (rc) return rc;
     if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
@@ -248,7 +248,7 @@ try {
     if (!ctx || !d_rgb8 || !d_png || !d_file_bytes) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     ForeignWork seen_by_destroy(ctx, hip_stream);
     int rc = ensure_png(ctx, bs_ctx::kPngSingle, width, height, false);
     if (rc) return rc;
@@ -294,7 +294,7 @@ try {
     if (!ctx || !rgb8 || !out_png || !out_bytes) return fail(BS_EINVAL, "null argument");
     if (int rc = check_png_frame(width, height)) return rc;
     if (cap < bs::png_file_bound(width, height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     const size_t n = (size_t)width * height * 3;
     if (!grow_device(ctx->d_u8, ctx->u8_cap, n)) return fail(BS_ENOMEM, "hipMalloc failed");
     StreamDrain drain(ctx);
@@ -308,7 +308,7 @@ try {
     auto t0 = std::chrono::steady_clock::now();
     if (cap < bs::png_file_bound(cfg->width, cfg->height)) return fail(BS_EINVAL, "output buffer too small: bs_png_bound(width, height) bytes are required");
     if (int rc = check_bloom_args(cfg->width, bloom_strength, bloom_divider)) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     const size_t n = (size_t)cfg->width * cfg->height * 3;
     int rc = ensure_post(ctx, n);
     if (rc) return rc;

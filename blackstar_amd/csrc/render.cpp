@@ -42,7 +42,7 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, TraceParams &p, int row0, int
 int resolve_stats(bs_ctx *ctx)
 {
     if (!ctx->pending) return BS_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     bs_ctx::LaunchSlot &sl = ctx->slots[ctx->stats_slot];
     HIP_TRY(hipEventSynchronize(sl.ev_done));
     float ms = 0;
@@ -76,7 +76,7 @@ int enqueue_render(bs_ctx *ctx, const bs_config *cfg, double *d_out, size_t out_
     if (row1 < 0) row1 = cfg->height;
     if (out_doubles < (size_t)cfg->width * (size_t)(row1 - row0) * 3) return fail(BS_EINVAL, "output buffer too small");
     p.out = d_out;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     if (first) {
         if (ctx->pending && ctx->stats_slot == ctx->next_slot) {  // bs_stats still owes the numbers of this slot's previous owner
             rc = resolve_stats(ctx);
@@ -143,7 +143,7 @@ try {
     auto t0 = std::chrono::steady_clock::now();
     size_t need = (size_t)cfg->width * (size_t)(row1 - row0) * 3;
     if (out_doubles < need) return fail(BS_EINVAL, "output buffer too small");
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     bool straddles = false;
     double *alias = device_alias_of_pinned(ctx, out_rgb, need * sizeof(double), &straddles);
     if (straddles) return fail(BS_EINVAL, kStraddleMsg);
@@ -223,7 +223,7 @@ try {
     p.nodes = ctx->d_nodes;
     p.colors = ctx->d_colors;
     p.cell_start = ctx->d_cell_start;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BS_ON_DEVICE(ctx);
     // persistent scratch (grown on demand, kept for the life of the context): [dirs 3n | rgb 3n] doubles, then n hit counts
     int rc = ensure_scratch(ctx, 6 * n * sizeof(double) + n * sizeof(int32_t));
     if (rc) return rc;

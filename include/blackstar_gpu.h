@@ -17,6 +17,8 @@
  * are independent of each other (each takes its own tile-queue/statistics block from a ring of 8; the ninth
  * waits for the first to finish) and bs_stats reports the one enqueued last.  Every blocking entry point returns
  * only after all work it enqueued has finished -- also on an error return, so caller buffers may be released.
+ * The calling thread's current HIP device is the same after every call as before it (the library switches to the
+ * context's device for the call and back: a host application that drives other devices from that thread is not disturbed).
  * Functions returning int return 0 on success and a negative BS_E* code on failure; bs_last_error() gives a
  * thread-local message.
  */

@@ -1091,13 +1091,17 @@ def test_failing_frame_mid_batch_leaves_nothing_in_flight(tree):
 def test_batch_split_and_stats_on_every_visible_device(catalogue_bytes):
     """One context per VISIBLE device (hipGetDeviceCount, not device 0 x n): frames round-robin over them (bs_render_batch),
     one frame in row bands over them (bs_render_split), per-device statistics -- all bit-identical to device 0 alone.
-    On a one-GPU box this degenerates to one context; the 8-GPU node exercises the per-device threads and uploads."""
+    On a one-GPU box this degenerates to one context; the 8-GPU node exercises the per-device threads and uploads.
+    The calling thread's current HIP device is the caller's business: every call leaves it as it found it (blackstar_gpu.h, bs::OnDevice) --
+    checked after each group of calls below (trivially true with one device)."""
     n = _lib.lib().bs_device_count()
     assert n >= 1
     import torch
     assert n == torch.cuda.device_count()
+    home = torch.cuda.current_device()
     stars = bs.read_map(catalogue_bytes)
     trees = [bs.StarTree(stars, device=d) for d in range(n)]
+    assert torch.cuda.current_device() == home   # bs_create on every device
     try:
         for t in trees:
             t.set_mode(_lib.BS_MODE_FAST)
@@ -1108,6 +1112,7 @@ def test_batch_split_and_stats_on_every_visible_device(catalogue_bytes):
             assert np.array_equal(a, b)
         big = scenes.with_res(scenes.LENSING_DISK, 160, 97)
         assert np.array_equal(bs.render_split(big, trees), bs.render(big, trees[0]))
+        assert torch.cuda.current_device() == home   # bs_render, bs_render_batch, bs_render_split
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         anim = bs.Animation.from_file(os.path.join(root, "animations", "default-ani.yaml"))
         anim.nFrames = 2 * n + 3
@@ -1125,13 +1130,20 @@ def test_batch_split_and_stats_on_every_visible_device(catalogue_bytes):
         for d, t in enumerate(trees):  # every device renders and reports on its own
             img = bs.render(cfgs[0], t)
             assert np.array_equal(img, ref[0]) and t.stats()["rays"] == 4 * 96 * 54
+            assert torch.cuda.current_device() == home   # bs_render / bs_stats of a context on ANOTHER device than the thread's
             o = torch.empty((54, 96, 3), dtype=torch.float64, device=f"cuda:{d}")
             bs.render_device(cfgs[0], t, o.data_ptr(), o.numel(), torch.cuda.current_stream(d).cuda_stream)
+            assert torch.cuda.current_device() == home   # bs_render_device
             torch.cuda.synchronize(d)
             assert np.array_equal(to_host(o), ref[0])
+            p = _lib.lib().bs_host_alloc(t.handle, 4096)
+            assert p and torch.cuda.current_device() == home   # bs_host_alloc
+            _lib.lib().bs_host_free(p)
+            assert bytes(bs.encode_png(ref8[0], t)[:8]) == b"\x89PNG\r\n\x1a\n" and torch.cuda.current_device() == home   # the post stage's entry points
     finally:
         for t in trees:
             t.close()
+        assert torch.cuda.current_device() == home   # bs_destroy
 
 
 def test_star_lookup_reuses_its_scratch(tree, oracle, oracle_index):
