@@ -96,3 +96,37 @@ def generate_frames(animation: Animation) -> List[Config]:
     frames = sorted(animation.keyframes, key=lambda k: k.time)  # sortBy (comparing time) is stable, like sorted()
     points = [float(i) * stepsize for i in range(animation.nFrames)]
     return [Config(scene=copy.deepcopy(animation.scene), camera=_interpolate(frames, p)) for p in points]
+
+
+def _wrap64(v: int) -> int:
+    """Int arithmetic of a 64-bit GHC: two's-complement wrap-around."""
+    return (v + (1 << 63)) % (1 << 64) - (1 << 63)
+
+
+def _n_digits(x: int) -> int:
+    """nDigits of padZero (src/Util.hs:45): (floor . logBase 10 $ fromIntegral x) + 1 in Int.  logBase 10 x = log x / log 10 in Double,
+    so 1000 has "3 digits" (2.9999999999999996) like in GHC; for x = 0 the logarithm is -Infinity and `floor :: Double -> Int` gives
+    what x86-64 GHC's floorDoubleInt gives: cvttsd2si's minBound, minus one because -inf < minBound, wrapped -- RECALLED, like SURVEY
+    Appendix F.7 says; tools/ghc_pin/Dump.hs writes padzero.txt and tests/ghc_pin.py compares it, index 0 included, when it arrives."""
+    import math
+    if x > 0:
+        fl = math.floor(math.log(float(x)) / math.log(10.0))
+    elif x == 0:
+        fl = _wrap64(-(1 << 63) - 1)   # floor (-Infinity) :: Int
+    else:
+        fl = -(1 << 63)                # floor NaN :: Int (cvttsd2si's "indefinite"; NaN < n is False)
+    return _wrap64(fl + 1)
+
+
+def pad_zero(max_val: int, val: int) -> str:
+    """src/Util.hs:43-48 padZero maxVal val: `val` left-padded with zeros to the digit count of maxVal -- as the reference computes it,
+    quirks included: index 0 is NOT padded (nDigits 0 is hugely negative, the difference wraps negative, replicate of a negative count
+    is empty), and a power of ten whose logBase 10 falls just short (1000) counts one digit less."""
+    n_zeros = _wrap64(_n_digits(max_val) - _n_digits(val))
+    return "0" * max(n_zeros, 0) + str(val)
+
+
+def frame_file_name(basename: str, n_frames: int, idx: int, ext: str = ".yaml") -> str:
+    """The file `animate` writes frame idx of an nFrames animation to (app/Animate.hs:55-56): basename ++ "_" ++ padZero (nFr - 1) idx
+    <.> ".yaml" -- which the batch loop (app/Main.hs:68-77) renders to the same name with .png.  With the reference's padding."""
+    return f"{basename}_{pad_zero(n_frames - 1, idx)}{ext}"

@@ -114,11 +114,23 @@ def _png_bound(height, width):
     return png_bound(height, width)
 
 
-def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1, basename: str = "frame", pipe: int = 16) -> "list[str]":
+def _frame_namer(n_frames: int, basename: str, reference_names: bool):
+    """<basename>_<index>.png: zero-padded to the width of the last index, or -- reference_names -- exactly as `animate` + the batch loop name
+    the frame (app/Animate.hs:55-56 with src/Util.hs:43-48 padZero, whose index 0 comes out unpadded: blackstar_amd.animation.pad_zero)."""
+    from .animation import frame_file_name
+    width = len(str(max(n_frames - 1, 1)))
+    if reference_names:
+        return lambda j: frame_file_name(basename, n_frames, j, ".png")
+    return lambda j: f"{basename}_{j:0{width}d}.png"
+
+
+def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1, basename: str = "frame", pipe: int = 16,
+                    reference_names: bool = False) -> "list[str]":
     """app/Animate.hs + blackstar's batch mode (app/Main.hs:68-77) for one animation: frame i on rank i % world, each rendered, bloomed,
     mapped to sRGB8, ENCODED AS A PNG FILE on the device and written by the library (`bs_render_png_files`: frames in flight on the GPU,
     a native writer thread writing `<basename>_<zero-padded index>.png` from page-locked buffers meanwhile).  No collective, no pixels on
-    the host, no Python between frames.  `pipe`: frames per internal call.  Returns the paths this rank wrote."""
+    the host, no Python between frames.  `pipe`: the ring of file buffers per context.  reference_names: the reference's own file names
+    (padZero's quirk for index 0 included) instead of plain zero padding.  Returns the paths this rank wrote."""
     import os
 
     from .animation import generate_frames, validate_keyframes
@@ -126,21 +138,21 @@ def write_animation(animation, tree, out_dir: str, rank: int = 0, world: int = 1
 
     validate_keyframes(animation.keyframes)
     frames = generate_frames(animation)
-    width = len(str(max(len(frames) - 1, 1)))
+    name = _frame_namer(len(frames), basename, reference_names)
     os.makedirs(out_dir, exist_ok=True)
     mine = shard_frames(len(frames), rank, world)
-    paths = [os.path.join(out_dir, f"{basename}_{j:0{width}d}.png") for j in mine]
+    paths = [os.path.join(out_dir, name(j)) for j in mine]
     render_png_files([frames[j] for j in mine], [tree], paths, pipe=pipe)
     return paths
 
 
 def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: Optional[int] = 0, out_dir: Optional[str] = None,
-                     basename: str = "frame", dist=None):
+                     basename: str = "frame", dist=None, reference_names: bool = False):
     """BASELINE configs[4] end to end: the frames of an Animation (src/Animation.hs generateFrames), frame i on rank
     i % world, each through the device pipeline of doRender (render -> bloom -> sRGB8, `bs_render_rgb8_batch`), gathered as
     RGB8 on `gather_to` (6.2 MB per 1080p frame instead of 49.8 MB of f64).  With out_dir, every rank also writes the frames it
     rendered as PNG files (`<basename>_<zero-padded index>.png`, the naming of app/Animate.hs:55-56 with the padding done
-    right -- SURVEY Appendix F.7), encoded on its GPU (`bs_encode_png`); write_animation is the variant that ONLY writes files
+    right -- SURVEY Appendix F.7; reference_names=True: exactly the reference's names), encoded on its GPU (`bs_encode_png`); write_animation is the variant that ONLY writes files
     and never brings pixels to the host.  Returns the ordered list of (h, w, 3) uint8 tensors on the root, None elsewhere."""
     import os
 
@@ -152,7 +164,7 @@ def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: 
 
     validate_keyframes(animation.keyframes)
     frames = generate_frames(animation)
-    width = len(str(max(len(frames) - 1, 1)))
+    name = _frame_namer(len(frames), basename, reference_names)
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
 
@@ -185,7 +197,7 @@ def render_animation(animation, tree, rank: int = 0, world: int = 1, gather_to: 
             nonlocal png_buf
             if png_buf is None or png_buf.size < _png_bound(*rgb8.shape[:2]):
                 png_buf = alloc_png(tree, *rgb8.shape[:2])
-            pending.append(pool.submit(write_file, os.path.join(out_dir, f"{basename}_{i:0{width}d}.png"), bytes(encode_png(rgb8, tree, out=png_buf))))
+            pending.append(pool.submit(write_file, os.path.join(out_dir, name(i)), bytes(encode_png(rgb8, tree, out=png_buf))))
         return torch.from_numpy(rgb8)
 
     try:

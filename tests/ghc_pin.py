@@ -168,6 +168,6 @@ def compare_animation(dump):
             i, name = line.split()
             if int(i) >= 1:
                 assert name == str(int(i)).zfill(width), (i, name)
-            else:
-                print(f"reference names frame 0 {name!r} (render_animation writes {'0'.zfill(width)!r})")
+            # blackstar_amd.animation.pad_zero restates padZero with its quirks (index 0: RECALLED floor (-Infinity) :: Int): every line must agree
+            assert name == bs.pad_zero(len(want) - 1, int(i)), (i, name, bs.pad_zero(len(want) - 1, int(i)))
     return len(want)

@@ -95,6 +95,30 @@ def test_animation_frames_match_independent_restatement():
         bs.validate_keyframes(a.keyframes)
 
 
+def test_frame_file_names_follow_the_references_pad_zero():
+    """Row f3's file naming (app/Animate.hs:55-56 over src/Util.hs:43-48 padZero): digits counted with floor (logBase 10 x) + 1 in Double /
+    Int, which pads like zfill from index 1 on, leaves index 0 unpadded (logBase 10 0 = -Infinity: SURVEY Appendix F.7, recalled Int
+    semantics) and counts one digit short where log x / log 10 falls below the integer (1000).  The default names of write_animation /
+    render_animation are plainly zero-padded; reference_names=True gives these."""
+    import math
+    from blackstar_amd.distributed import _frame_namer
+    assert [bs.pad_zero(599, i) for i in (0, 1, 9, 10, 99, 100, 599)] == ["0", "001", "009", "010", "099", "100", "599"]
+    for mx in (1, 9, 10, 99, 374, 599, 998):
+        for v in range(1, mx + 1, max(1, mx // 40)):
+            assert bs.pad_zero(mx, v) == str(v).zfill(len(str(mx))), (mx, v)
+        assert bs.pad_zero(mx, 0) == "0"
+    assert bs.pad_zero(0, 0) == "0"                                   # a one-frame animation
+    assert math.log(1000.0) / math.log(10.0) < 3                     # the quirk's premise holds in this libm too
+    assert bs.pad_zero(1000, 5) == "005" and bs.pad_zero(9999, 1000) == "01000" and bs.pad_zero(999, 5) == "005"
+    assert bs.frame_file_name("default-ani", 600, 0) == "default-ani_0.yaml" and bs.frame_file_name("default-ani", 600, 42, ".png") == "default-ani_042.png"
+    ours, theirs = _frame_namer(600, "ani", False), _frame_namer(600, "ani", True)
+    assert ours(0) == "ani_000.png" and theirs(0) == "ani_0.png" and all(ours(i) == theirs(i) for i in range(1, 600))
+    # both namings keep the batch loop's lexicographic order (app/Main.hs:68-70 sorts the directory listing) equal to frame order
+    for namer in (ours, theirs):
+        names = [namer(i) for i in range(600)]
+        assert sorted(names) == names
+
+
 def test_synthetic_catalogue_layout_and_reader(catalogue_bytes, oracle):
     data = synthetic.ppm_catalogue_bytes(2000, synthetic.SEED + 1)
     assert data == catalogue_bytes  # vectorised generator == the scalar one that made the fixture
