@@ -130,3 +130,20 @@ def frame_file_name(basename: str, n_frames: int, idx: int, ext: str = ".yaml") 
     """The file `animate` writes frame idx of an nFrames animation to (app/Animate.hs:55-56): basename ++ "_" ++ padZero (nFr - 1) idx
     <.> ".yaml" -- which the batch loop (app/Main.hs:68-77) renders to the same name with .png.  With the reference's padding."""
     return f"{basename}_{pad_zero(n_frames - 1, idx)}{ext}"
+
+
+def write_frame_files(animation: Animation, out_dir: str, basename: str) -> List[str]:
+    """What `animate` leaves behind (app/Animate.hs:47-61 with --force): one scene file per frame, `<basename>_<padZero (nFrames-1) i>.yaml`
+    = Data.Yaml.encode of the frame's Config (src/ConfigFile.hs:45-46, :52-53: V3 as [x, y, z], diskColor with its hue back in degrees) --
+    files the reference's own `blackstar` directory mode (app/Main.hs:68-77) and this library's render_scene_directory both read.
+    Returns the paths in frame order."""
+    import os
+    validate_keyframes(animation.keyframes)
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    for i, cfg in enumerate(generate_frames(animation)):
+        path = os.path.join(out_dir, frame_file_name(basename, animation.nFrames, i))
+        with open(path, "w", encoding="utf-8") as f:
+            f.write(cfg.to_yaml())
+        paths.append(path)
+    return paths

@@ -119,6 +119,27 @@ def test_frame_file_names_follow_the_references_pad_zero():
         assert sorted(names) == names
 
 
+def test_animate_compatible_frame_files_round_trip(tmp_path):
+    """SURVEY 7.7 "animate-compatible frame files": write_frame_files leaves what `animate --force` leaves (app/Animate.hs:47-61) -- one scene
+    file per frame under the reference's names -- and reading them back (the decoder the directory mode uses) gives the frames' configs
+    bit for bit: floats survive the YAML text (repr round trip), the disk hue goes out in degrees and comes back divided by 360."""
+    a = bs.Animation.from_file(os.path.join(ROOT, "animations", "default-ani.yaml"))
+    a.nFrames = 12
+    paths = bs.write_frame_files(a, str(tmp_path / "frames"), "default-ani")
+    assert [os.path.basename(p) for p in paths] == ["default-ani_0.yaml"] + [f"default-ani_{i:02d}.yaml" for i in range(1, 12)]
+    assert sorted(os.listdir(tmp_path / "frames")) == sorted(os.path.basename(p) for p in paths)
+    frames = bs.generate_frames(a)
+    for p, want in zip(paths, frames):
+        got = bs.Config.from_file(p)
+        assert got.camera == want.camera, p
+        assert got.to_bs_config() == want.to_bs_config(), p
+        # hue x 360 / 360 must come back exactly for the value the reference's scenes use (0.16 is not representable; 360 * h is rounded once each way)
+        assert got.scene.diskColor[1:] == want.scene.diskColor[1:] and abs(got.scene.diskColor[0] - want.scene.diskColor[0]) <= 2.8e-17
+    a.keyframes = a.keyframes[:1]
+    with pytest.raises(bs.ConfigError):
+        bs.write_frame_files(a, str(tmp_path / "bad"), "x")
+
+
 def test_synthetic_catalogue_layout_and_reader(catalogue_bytes, oracle):
     data = synthetic.ppm_catalogue_bytes(2000, synthetic.SEED + 1)
     assert data == catalogue_bytes  # vectorised generator == the scalar one that made the fixture
