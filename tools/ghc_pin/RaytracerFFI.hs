@@ -29,7 +29,8 @@ data BsCtx
 -- the context plus its page-locked image buffers, which every frame reuses (allocating page-locked memory costs milliseconds;
 -- filling it does not fault): [(buffer, capacity in doubles)] -- one for renderGpu, two for renderBatch (two frames in flight per GPU)
 -- gpuLock: a bs_ctx is driven by one thread at a time (include/blackstar_gpu.h); every single-context entry point below takes it, so two
--- thunks of renderPure sparked in parallel queue up instead of racing on the context and its one reusable buffer.
+-- thunks of renderPure sparked in parallel queue up instead of racing on the context and its one reusable buffer; the multi-context
+-- calls hold every context they were given (withAllLocks).
 data GpuTree = GpuTree { gpuCtx :: Ptr BsCtx, gpuBufs :: IORef [(ForeignPtr CDouble, Int)], gpuLock :: MVar () }
 
 -- include/blackstar_gpu.h
@@ -107,6 +108,11 @@ withGpuTrees devices tree act = do
     when (c <= 0) $ lastError "bs_device_count"
     return [0 .. fromIntegral c - 1]
   withStars tree $ \buf n -> withMany (withCtx buf n) devs act
+
+-- Every context of a multi-context call is held for the length of the call, taken in list order (two batch calls over the same
+-- contexts queue up; the same list order everywhere rules out a deadlock between them).
+withAllLocks :: [GpuTree] -> IO a -> IO a
+withAllLocks gpus act = foldr (\g inner -> withMVar (gpuLock g) (\_ -> inner)) act gpus
 
 -- k page-locked image buffers of at least n doubles each, grown on demand and then reused by every frame (bs_host_free runs when
 -- the GC drops a buffer; the memory is hipHostMallocPortable: every device of the node may write it, and it may outlive the context).
@@ -192,7 +198,7 @@ renderScenesToFiles gpus jobs = do
   let n    = length jobs
       scns = map (scene . fst) jobs
   when (null gpus) $ ioError (userError "renderScenesToFiles: no GPU contexts")
-  when (n > 0) $
+  when (n > 0) $ withAllLocks gpus $
     withArray (map gpuCtx gpus) $ \pctxs ->
     allocaBytes (168 * n) $ \pcfgs ->
     withArray (map (realToFrac . bloomStrength) scns :: [CDouble]) $ \pstrengths ->
@@ -208,7 +214,7 @@ renderScenesToFiles gpus jobs = do
 -- write them directly), so page-locked memory stays at 2N frames however long the animation is; each frame is copied into massiv's
 -- unboxed form before its buffer is reused.  Every round starts at a multiple of N, so frame i does run on context i mod N.
 renderBatch :: [GpuTree] -> [Config] -> (Int -> Image U RGB Double -> IO ()) -> IO ()
-renderBatch gpus cfgs consume = do
+renderBatch gpus cfgs consume = withAllLocks gpus $ do
   when (null gpus) $ ioError (userError "renderBatch: no GPU contexts")
   let nGpu   = length gpus
       sizeOf' cfg = let (w, h) = resolution (scene cfg) in w * h * 3
