@@ -87,10 +87,30 @@ def parity_block(np, what, ref, ref_st, got, got_st, mode):
     return blk
 
 
-def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None, baseline_config="configs[2]"):
+def cpu_baseline(cfg, star_bytes, budget_s, gpu_render=None, np=None, baseline_config="configs[2]", host_cpus=None):
     """Time the C oracle (restatement of the reference CPU path; GHC is unavailable) on a bounded sample -- and, since the oracle's
     frames are computed anyway, compare them with the frames the HIP library renders of the same configs (gpu_render(cfg, stars, mode)
-    -> (image, stats), the product called through its C ABI): the `parity` list.  No extra oracle time."""
+    -> (image, stats), the product called through its C ABI): the `parity` list.  No extra oracle time.
+    host_cpus: the CPUs this process could use BEFORE it bound itself to its GPU's NUMA node (bind_rank_to_gpu_node): the CPU baseline is
+    "the host's cores", all of them -- the oracle's threads run on that set, and the caller's binding comes back afterwards."""
+    bound_to = None
+    if host_cpus and hasattr(os, "sched_setaffinity"):
+        try:
+            bound_to = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, host_cpus)   # (threads the oracle starts inherit the calling thread's affinity)
+        except OSError:
+            bound_to = None
+    try:
+        return _cpu_baseline(cfg, star_bytes, budget_s, gpu_render, np, baseline_config)
+    finally:
+        if bound_to is not None:
+            try:
+                os.sched_setaffinity(0, bound_to)
+            except OSError:
+                pass
+
+
+def _cpu_baseline(cfg, star_bytes, budget_s, gpu_render, np, baseline_config):
     from oracle import c_oracle, scenes
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # a container CPU quota (cgroup v2 cpu.max = "<quota> <period>") caps the cores that really run
@@ -269,6 +289,7 @@ def run_ranks(args):
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     # one process per GPU: this rank's threads on the GPU's NUMA node (BLACKSTAR_NUMA_BIND=0 leaves them alone, like the library's own binding)
+    host_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None   # (what the CPU baseline may use: cpu_baseline)
     binding = bind_rank_to_gpu_node(torch, local_rank) if os.environ.get("BLACKSTAR_NUMA_BIND", "1") != "0" else {"bound": False, "why": "BLACKSTAR_NUMA_BIND=0"}
     rccl = None
     # BLACKSTAR_BENCH_FORCE_DIST=1 (set by `--launcher torchrun --gpus 1`): one rank still goes through init_process_group, the all_gathers,
@@ -546,7 +567,7 @@ def run_ranks(args):
                     else:
                         t.close()
             with sw.leg("cpu_baseline_and_parity"):
-                res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds, gpu_render, np, WORKLOADS[args.workload]["baseline"]))
+                res["cpu_baseline"] = optional_leg("cpu_baseline", True, lambda: cpu_baseline(cfg, star_bytes, args.cpu_seconds, gpu_render, np, WORKLOADS[args.workload]["baseline"], host_cpus=host_cpus))
             if isinstance(res["cpu_baseline"], dict) and "parity_ok" in res["cpu_baseline"] and "valid" in res:
                 res["valid"] = bool(res["valid"]) and bool(res["cpu_baseline"]["parity_ok"])   # a fast frame that differs from the reference's is not a result
         if world == 1 and resident and args.traffic == "live" and args.traffic_bytes is None and not args.no_boundary and args.workload == "default-aa":

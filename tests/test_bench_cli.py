@@ -443,6 +443,18 @@ def test_cpu_baseline_carries_parity_for_all_five_baseline_configs(monkeypatch):
     blk = bench.cpu_baseline(cfg, star_bytes, 0.05, crashes, np)
     assert not blk["parity_ok"] and all("BS_EDEVICE" in p["error"] for p in blk["parity"])
     assert "parity" not in bench.cpu_baseline(cfg, star_bytes, 0.05)      # no product to check (nothing renders on the CPU instead)
+    # A rank that has bound itself to its GPU's NUMA node (bind_rank_to_gpu_node) still measures the CPU baseline on ALL the cores the
+    # process had before: host_cpus; the binding comes back afterwards.
+    if hasattr(os, "sched_setaffinity") and len(os.sched_getaffinity(0)) >= 2:
+        everything = os.sched_getaffinity(0)
+        one = {min(everything)}
+        os.sched_setaffinity(0, one)
+        try:
+            assert bench.cpu_baseline(cfg, star_bytes, 0.05)["cores"] == 1                      # bound: one core is all it sees
+            wide = bench.cpu_baseline(cfg, star_bytes, 0.05, host_cpus=everything)
+            assert wide["cores"] > 1 and os.sched_getaffinity(0) == one                          # the host's cores, and the binding is back
+        finally:
+            os.sched_setaffinity(0, everything)
 
 
 def test_launcher_torchrun_with_one_gpu_forces_the_distributed_branch(monkeypatch):
