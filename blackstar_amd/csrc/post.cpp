@@ -15,6 +15,9 @@ using namespace bs;
 int bs::ensure_post(bs_ctx *ctx, size_t n)
 {
     if (ctx->post_cap >= n) return BS_OK;
+    // growing = freeing: a blur an earlier *_device call enqueued on a caller's stream may still be using the old pair (nothing here relies
+    // on hipFree waiting for the device)
+    if (ctx->post_busy && ctx->ev_post) HIP_TRY(hipEventSynchronize(ctx->ev_post));
     for (double *&b : ctx->d_post) {
         if (b) (void)hipFree(b);
         b = nullptr;
@@ -210,6 +213,11 @@ try {
 // of the file for a caller whose buffer the GPU cannot write.
 int bs::ensure_png(bs_ctx *ctx, int k, int w, int h, bool device_file)
 {
+    // (slot kPngSingle may still be in use by an encoder an earlier bs_encode_png_device enqueued on a caller's stream: wait before it can be
+    // freed to grow; slots 0..2 belong to the batch pipelines, which drain their streams before they return)
+    if (k == bs_ctx::kPngSingle && ctx->png_busy && ctx->ev_png &&
+        (ctx->png_scratch_cap[k] < bs::png_scratch_bytes(w, h) || (device_file && ctx->png_file_cap[k] < (size_t)bs::png_file_bound(w, h))))
+        HIP_TRY(hipEventSynchronize(ctx->ev_png));
     if (!grow_device(ctx->d_png_scratch[k], ctx->png_scratch_cap[k], bs::png_scratch_bytes(w, h)))
         return fail(BS_ENOMEM, "hipMalloc PNG scratch failed");
     if (device_file && !grow_device(ctx->d_png_file[k], ctx->png_file_cap[k], (size_t)bs::png_file_bound(w, h)))
