@@ -692,6 +692,12 @@ def test_write_animation_files_only(tree, tmp_path):
     for i in (0, 1, 15, 16, 17, 31, 32, 36):
         with open(tmp_path / f"f_{i:02d}.png", "rb") as f:
             assert np.array_equal(decode_png_rgb8(f.read()), bs.render_rgb8(cfgs[i], tree)), i
+    # the reference's own names (app/Animate.hs:55-56, padZero: index 0 unpadded) for the same files, byte for byte
+    named = write_animation(anim, tree, str(tmp_path / "ref"), basename="f", reference_names=True)
+    assert [os.path.basename(p) for p in named] == ["f_0.png"] + [f"f_{i:02d}.png" for i in range(1, 37)]
+    for i, p in enumerate(named):
+        with open(p, "rb") as f, open(tmp_path / f"f_{i:02d}.png", "rb") as g:
+            assert f.read() == g.read(), i
 
 
 def _random_scene(rng):
