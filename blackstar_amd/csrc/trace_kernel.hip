@@ -26,6 +26,15 @@ __device__ unsigned long long g_trace_probe[kProbeWords * kProbeWaves];
 // their latency-bound tail (star lookup, shading, image write, next tile's setup) at the same time, leaving the
 // f64 pipe idle (PMC: VALU busy 91 % with stars vs 96 % without).  Delaying the first tile of the wave in
 // SIMD slot k by k/4 of a tile time keeps the four phases apart for the rest of the frame.
+// How a wavefront's statistics reach the launch slot's counters when it runs out of tiles (BS_EXIT_STATS, an A/B knob):
+//   2 (the product)  the four wavefronts of a workgroup add theirs up in LDS behind one barrier and seven lanes issue ONE set of atomics
+//   0 (rounds 1-5)   every wavefront issues its own: 4096 x 7 device-scope atomics on ONE 64-byte line -- the line the tile queue's head
+//                    lives in -- in the last 0.3 ms of the launch.  Round 6 (scripts/launch_cost_probe.py, profiles/r06_exit_stats_ab.txt):
+//                    the C3 frame 4.25 -> 4.13 ms with 2, and 4.07 -> 4.06 for a build with no statistics at all (1): the whole of it
+//   1                none (probe only: bs_stats reads zeros)
+#ifndef BS_EXIT_STATS
+#define BS_EXIT_STATS 2
+#endif
 template <bool FAST>
 __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const TraceParams P)
 {
@@ -124,6 +133,25 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     }
     const unsigned long long s_steps = wave_sum(stat[0 * kBlock]), s_cap = wave_sum(stat[1 * kBlock]), s_hor = wave_sum(stat[2 * kBlock]),
                              s_esc = wave_sum(stat[3 * kBlock]), s_disk = wave_sum(stat[4 * kBlock]), s_star = wave_sum(stat[5 * kBlock]);
+#if BS_EXIT_STATS == 1
+    if (lane == 0 && s_steps == 0xFFFFFFFFFFFFFFFFull) atomicAdd(&P.counters[0], s_steps + s_cap + s_hor + s_esc + s_disk + s_star + a_iters);
+#elif BS_EXIT_STATS == 2
+    {
+        __shared__ unsigned long long s_exit[7 * (kBlock / 64)];
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) {
+            unsigned long long *e = s_exit + 7 * wv;
+            e[0] = s_steps; e[1] = s_cap; e[2] = s_hor; e[3] = s_esc; e[4] = s_disk; e[5] = s_star; e[6] = a_iters;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) v += s_exit[7 * w + threadIdx.x];
+            if (v) atomicAdd(&P.counters[threadIdx.x], v);
+        }
+    }
+#else
     if (lane == 0) {
         atomicAdd(&P.counters[6], a_iters);
         atomicAdd(&P.counters[0], s_steps);
@@ -133,6 +161,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         if (s_disk) atomicAdd(&P.counters[4], s_disk);
         if (s_star) atomicAdd(&P.counters[5], s_star);
     }
+#endif
 #ifdef BS_TRACE_PROBE
     const unsigned gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (lane == 0 && gw < (unsigned)kProbeWaves) {
