@@ -31,6 +31,9 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, TraceParams &p, int row0, int
         p.blocks_per_slot = cus;
         p.grid_blocks = (int32_t)std::max<long>(1, std::min<long>((tiles + 3) / 4, waves / 4));
         p.stagger_cycles = tiles >= (long)ctx->stagger_min_tiles * waves ? ctx->stagger_cycles : 0;  // only worth it when a wave runs several tiles
+        // wavefront g starts on tile g, no initial pop (trace_kernel.hip; one binary, the knob alone, profiles/r06_static_first_tile_ab.txt: the C3
+        // frame 0.9 % faster, default.yaml at 1080p 2.3 %, 640 x 360 15 %, lensing-disk at 4K level)
+        p.queue_base = tiles < (long)ctx->static_first_below * waves ? 4 * p.grid_blocks : 0;
     }
     p.n_entries = (int32_t)ctx->n_entries;
     p.nodes = ctx->d_nodes;

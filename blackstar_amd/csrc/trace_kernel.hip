@@ -44,6 +44,15 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     const LaneLds lds(s_lane, s_ints);
 
     const int lane = threadIdx.x & 63;
+#if defined(BS_PAD_NOPS) && BS_PAD_NOPS > 0
+    // Shifts every instruction behind it by 4 bytes per s_nop, executed once per wavefront.  Where the kernel's code lands modulo 32 bytes is
+    // worth 1.6-2.3 % of the C3 frame (profiles/r06_code_alignment_ab.txt: offsets 24, 28, 0, 4 good, 8-20 bad; what rounds 2-5 booked as "extra
+    // scalar state in the rare path costs 1-2.5 % although the hot path's ISA is unchanged").  The Makefile's PAD picks the offset;
+    // scripts/alignment_sweep.sh measures all eight.
+#define BS_STR2(x) #x
+#define BS_STR(x) BS_STR2(x)
+    asm volatile(".rept " BS_STR(BS_PAD_NOPS) "\n s_nop 0\n .endr");
+#endif
 #ifdef BS_TRACE_PROBE
     const unsigned long long probe_t0 = wall_clock64();
     unsigned long long probe_t1 = 0, probe_t2 = 0, probe_ts = 0;
@@ -77,15 +86,23 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     // The queue pop for tile t+1 is issued BEFORE tile t is traced (the returned index is not needed until the next
     // trip), so the ~1-2 us round trip of the device-scope atomic never stalls the wavefront.  Over-fetching past
     // the end is harmless: indices >= n_tiles just end the loop.
-    int next_tile = 0;
-    if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
+    // The FIRST tile needs no atomic (P.queue_base != 0, render.cpp): wavefront g of the grid takes tile g and the queue hands out the tiles
+    // from queue_base = the number of wavefronts on.  Rounds 1-5 started every launch with up to 4096 pops on one address before anything
+    // was traced: 25-45 us -- 2 % of the reference's default.yaml at 1080p, 15 % of a 640 x 360 frame, 0.9 % of the C3 frame
+    // (profiles/r06_static_first_tile_ab.txt: one binary, BLACKSTAR_STATIC_FIRST_BELOW alone).
+    const int queue_base = P.queue_base;
+    int next_tile = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
+    if (queue_base == 0) {
+        next_tile = 0;
+        if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
+    }
 #ifdef BS_TRACE_PROBE
     probe_t1 = wall_clock64();
 #endif
     for (;;) {
         const int tile = __builtin_amdgcn_readfirstlane(next_tile);
         if (tile >= n_tiles) break;
-        if (lane == 0) next_tile = (int)atomicAdd(&P.counters[7], 1ull);
+        if (lane == 0) next_tile = queue_base + (int)atomicAdd(&P.counters[7], 1ull);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int xi = tx * 8 + lx, yb = ty * 8 + ly, yi = P.band_t0 + yb;  // yb: traced row within the band (band_t0 is even with supersampling)
         const bool inb = xi < P.wt && yi < P.band_t1;
