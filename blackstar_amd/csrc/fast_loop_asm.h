@@ -1,0 +1,164 @@
+// fast_loop_asm.h -- the FAST stepping loop of trace_ray<true> spelled in gfx950 assembly (one extended-asm statement).
+//
+// The arithmetic is rk4_planar_position + rk4_planar_velocity of trace_device.h, instruction for instruction what hipcc makes of them
+// (66 f64 VALU per step, 4 of them v_rsq_f64); what is written by hand is everything AROUND the arithmetic, which the compiler cannot be
+// talked into (profiles/EXPERIMENTS.md 1.2, 6.6):
+//   * the state is updated IN PLACE, y and r^2 ping-pong between two register pairs across the two copies of the step: no v_mov at all
+//     (the compiled loop carries one v_mov_b64 per step);
+//   * the wavefront's scalar bookkeeping is 7 SALU and two never-taken branches per step (compiled: 13 SALU, three branches that fall
+//     through and one that is taken per step), and the ONLY taken branch is the back edge, once per BS_FL_UNROLL steps;
+//   * the rare events -- some lane's guard fired, some lane crossed the disk plane -- LEAVE the statement: the C++ around it (trace_ray)
+//     snapshots / records and re-enters.  Nothing rare sits between the steps, so where the loop's second step lands is no longer a matter of
+//     what the rare blocks happen to weigh (a 1.5 % lottery per build, profiles/r06_code_alignment_ab.txt).
+//
+// Operands (all 64-bit pairs except it / maxs / ev):
+//   VGPR state   x, y, wx, wy, r2      "+v"   the planar state in the ray's own units; on exit: the state the NEXT step starts from
+//   VGPR scratch yb, r2b, t0..t7       "=&v"  on a crossing exit t0 = y and t1 = r^2 BEFORE the step that crossed
+//   VGPR consts  c25, lo, hi, thr      "v"    2.5; the per-lane guard thresholds; the crossing threshold (0 or -inf)
+//   SGPR consts  c4375, m23, maxs, amask
+//   SGPR state   ok "+s" (guards of the state about to be stepped), it "+s"
+//   SGPR out     go (the lanes that go on), crossed (the crossing ballot), ev (0: a guard fired BEFORE a step, nothing stepped; 1: a step crossed)
+// Clobbers vcc, scc.  exec is not touched: the steps run unmasked (finished lanes free-run, trace_device.h "per-lane LDS scratch").
+//
+// Hazards (gfx940 family, what LLVM's GCNHazardRecognizer would have checked): a v_rsq_f64 result is first read two instructions later
+// (trans -> VALU forwarding needs one); SALU reads of VALU-written SGPRs and s_cbranch_vccnz after a v_cmp are interlocked in hardware.
+#pragma once
+
+#ifndef BS_FL_UNROLL
+#define BS_FL_UNROLL 2  // steps per taken branch: 2 or 4
+#endif
+#ifndef BS_FL_EARLY
+#define BS_FL_EARLY 0  // 1: the scalar bookkeeping of the NEXT step issues in the shadow of stage 4 instead of behind it
+#endif
+
+// go = (it < maxs) ? amask & ok : 0;  SCC = (go != amask)
+#define BS_FL_HEAD                              \
+    "s_and_b64 %[go], %[amask], %[ok]\n\t"      \
+    "s_cmp_lt_i32 %[it], %[maxs]\n\t"           \
+    "s_cselect_b64 %[go], %[go], 0\n\t"         \
+    "s_cmp_lg_u64 %[go], %[amask]\n\t"
+
+// the guards of the new state (v_cmp into ok / go) become the next step's ok; it counts the step; then the next step's head
+#define BS_FL_SCALAR                            \
+    "s_and_b64 %[ok], %[ok], %[go]\n\t"         \
+    "s_add_i32 %[it], %[it], 1\n\t"             \
+    BS_FL_HEAD
+
+// stages 1-3, the new position (x in place, y -> YN, r^2 -> R2N), the three compares, stage 4 up to the sums T = S + R
+#define BS_FL_PART1(Y, R2, YN, R2N)                                  \
+    "v_rsq_f64 " YN ", " R2 "\n\t"                                   \
+    "v_fma_f64 " R2N ", 0.5, %[wx], %[x]\n\t"                        \
+    "v_fma_f64 %[t0], 0.5, %[wy], " Y "\n\t"                         \
+    "v_mul_f64 %[t1], " YN ", " YN "\n\t"                            \
+    "v_fma_f64 %[t2], -" R2 ", %[t1], 1.0\n\t"                       \
+    "v_mul_f64 %[t1], %[t1], %[t1]\n\t"                              \
+    "v_mul_f64 " YN ", " YN ", %[t1]\n\t"                            \
+    "v_mul_f64 %[t1], " R2N ", " R2N "\n\t"                          \
+    "v_fmac_f64 %[t1], %[t0], %[t0]\n\t"                             \
+    "v_rsq_f64 %[t3], %[t1]\n\t"                                     \
+    "v_fma_f64 %[t4], %[c4375], %[t2], %[c25]\n\t"                   \
+    "v_mul_f64 %[t2], %[t2], " YN "\n\t"                             \
+    "v_fmac_f64 " YN ", %[t2], %[t4]\n\t"                            \
+    "v_fma_f64 %[t4], -" YN ", %[x], " R2N "\n\t"                    \
+    "v_fma_f64 %[t5], -" YN ", " Y ", %[t0]\n\t"                     \
+    "v_mul_f64 %[t6], %[t4], %[t4]\n\t"                              \
+    "v_mul_f64 %[t2], %[t3], %[t3]\n\t"                              \
+    "v_fmac_f64 %[t6], %[t5], %[t5]\n\t"                             \
+    "v_fma_f64 %[t1], -%[t1], %[t2], 1.0\n\t"                        \
+    "v_mul_f64 %[t2], %[t2], %[t2]\n\t"                              \
+    "v_rsq_f64 %[t7], %[t6]\n\t"                                     \
+    "v_mul_f64 %[t2], %[t3], %[t2]\n\t"                              \
+    "v_fma_f64 %[t3], %[c4375], %[t1], %[c25]\n\t"                   \
+    "v_mul_f64 %[t1], %[t1], %[t2]\n\t"                              \
+    "v_fmac_f64 %[t2], %[t1], %[t3]\n\t"                             \
+    "v_mul_f64 %[t1], " R2N ", %[t2]\n\t"                            \
+    "v_mul_f64 " R2N ", %[t7], %[t7]\n\t"                            \
+    "v_mul_f64 %[t0], %[t0], %[t2]\n\t"                              \
+    "v_fma_f64 %[t2], -%[t6], " R2N ", 1.0\n\t"                      \
+    "v_mul_f64 " R2N ", " R2N ", " R2N "\n\t"                        \
+    "v_mul_f64 " R2N ", %[t7], " R2N "\n\t"                          \
+    "v_fma_f64 %[t3], %[c4375], %[t2], %[c25]\n\t"                   \
+    "v_mul_f64 %[t2], %[t2], " R2N "\n\t"                            \
+    "v_fmac_f64 " R2N ", %[t2], %[t3]\n\t"                           \
+    "v_add_f64 %[t2], %[wx], %[x]\n\t"                               \
+    "v_add_f64 %[t3], %[wy], " Y "\n\t"                              \
+    "v_fma_f64 %[t6], -2.0, %[t1], %[t2]\n\t"                        \
+    "v_fmac_f64 %[t1], " R2N ", %[t4]\n\t"                           \
+    "v_fma_f64 %[t7], -2.0, %[t0], %[t3]\n\t"                        \
+    "v_fmac_f64 %[t0], " R2N ", %[t5]\n\t"                           \
+    "v_fma_f64 %[t4], " YN ", %[x], %[t1]\n\t"                       \
+    "v_fma_f64 %[x], %[m23], %[t4], %[t2]\n\t"                       \
+    "v_fma_f64 %[t5], " YN ", " Y ", %[t0]\n\t"                      \
+    "v_mul_f64 " R2N ", %[x], %[x]\n\t"                              \
+    "v_fma_f64 " YN ", %[m23], %[t5], %[t3]\n\t"                     \
+    "v_fmac_f64 " R2N ", " YN ", " YN "\n\t"                         \
+    "v_mul_f64 %[t2], " Y ", " YN "\n\t"                             \
+    "v_cmp_nlt_f64 %[ok], " R2N ", %[lo]\n\t"                        \
+    "v_cmp_ngt_f64 %[go], " R2N ", %[hi]\n\t"                        \
+    "v_cmp_le_f64 vcc, %[t2], %[thr]\n\t"                            \
+    "v_mul_f64 %[t2], %[t6], %[t6]\n\t"                              \
+    "v_fmac_f64 %[t2], %[t7], %[t7]\n\t"                             \
+    "v_rsq_f64 %[t3], %[t2]\n\t"                                     \
+    "v_add_f64 %[t1], %[t1], %[t4]\n\t"                              \
+    "v_add_f64 %[t0], %[t0], %[t5]\n\t"
+
+// the rest of stage 4 and the new displacement per step
+#define BS_FL_PART2                                                  \
+    "v_mul_f64 %[t4], %[t3], %[t3]\n\t"                              \
+    "v_fma_f64 %[t2], -%[t2], %[t4], 1.0\n\t"                        \
+    "v_mul_f64 %[t4], %[t4], %[t4]\n\t"                              \
+    "v_mul_f64 %[t3], %[t3], %[t4]\n\t"                              \
+    "v_fma_f64 %[t4], %[c4375], %[t2], %[c25]\n\t"                   \
+    "v_mul_f64 %[t2], %[t2], %[t3]\n\t"                              \
+    "v_fmac_f64 %[t3], %[t2], %[t4]\n\t"                             \
+    "v_fmac_f64 %[t1], %[t3], %[t6]\n\t"                             \
+    "v_fmac_f64 %[t0], %[t3], %[t7]\n\t"                             \
+    "v_fmac_f64 %[wx], %[m23], %[t1]\n\t"                            \
+    "v_fmac_f64 %[wy], %[m23], %[t0]\n\t"
+
+#if BS_FL_EARLY
+#define BS_FL_STEP(Y, R2, YN, R2N) BS_FL_PART1(Y, R2, YN, R2N) BS_FL_SCALAR BS_FL_PART2
+#else
+#define BS_FL_STEP(Y, R2, YN, R2N) BS_FL_PART1(Y, R2, YN, R2N) BS_FL_PART2 BS_FL_SCALAR
+#endif
+
+// step A: (y, r2) -> (yb, r2b); step B: back.  After each: leave if the step crossed, leave (before stepping) if the next step's guards fire.
+#define BS_FL_PAIR                                                   \
+    BS_FL_STEP("%[y]", "%[r2]", "%[yb]", "%[r2b]")                   \
+    "s_cbranch_vccnz .Lbs_cross_a%=\n\t"                             \
+    "s_cbranch_scc1 .Lbs_guard_b%=\n\t"                              \
+    BS_FL_STEP("%[yb]", "%[r2b]", "%[y]", "%[r2]")                   \
+    "s_cbranch_vccnz .Lbs_cross_b%=\n\t"                             \
+    "s_cbranch_scc1 .Lbs_guard_a%=\n\t"
+
+#if BS_FL_UNROLL == 4
+#define BS_FL_BODY BS_FL_PAIR BS_FL_PAIR
+#else
+#define BS_FL_BODY BS_FL_PAIR
+#endif
+
+#define BS_FAST_LOOP_ASM                                             \
+    BS_FL_HEAD                                                       \
+    "s_cbranch_scc1 .Lbs_guard_a%=\n"                                \
+    ".Lbs_loop%=:\n\t"                                               \
+    BS_FL_BODY                                                       \
+    "s_branch .Lbs_loop%=\n"                                         \
+    ".Lbs_cross_a%=:\n\t"                                            \
+    "v_mov_b64 %[t0], %[y]\n\t"                                      \
+    "v_mov_b64 %[t1], %[r2]\n\t"                                     \
+    "v_mov_b64 %[y], %[yb]\n\t"                                      \
+    "v_mov_b64 %[r2], %[r2b]\n\t"                                    \
+    "s_branch .Lbs_cross%=\n"                                        \
+    ".Lbs_cross_b%=:\n\t"                                            \
+    "v_mov_b64 %[t0], %[yb]\n\t"                                     \
+    "v_mov_b64 %[t1], %[r2b]\n"                                      \
+    ".Lbs_cross%=:\n\t"                                              \
+    "s_mov_b64 %[crossed], vcc\n\t"                                  \
+    "s_mov_b32 %[ev], 1\n\t"                                         \
+    "s_branch .Lbs_done%=\n"                                         \
+    ".Lbs_guard_b%=:\n\t"                                            \
+    "v_mov_b64 %[y], %[yb]\n\t"                                      \
+    "v_mov_b64 %[r2], %[r2b]\n"                                      \
+    ".Lbs_guard_a%=:\n\t"                                            \
+    "s_mov_b32 %[ev], 0\n"                                           \
+    ".Lbs_done%=:\n"

@@ -22,10 +22,14 @@
 #include <hip/hip_runtime.h>
 
 #include "bs_internal.h"
+#include "fast_loop_asm.h"
 
 namespace bs {
 namespace {
 
+#ifndef BS_ASM_LOOP
+#define BS_ASM_LOOP 1  // the FAST stepping loop: 1 = fast_loop_asm.h, 0 = the C++ statement of the same steps (A/B knob, and the readable version)
+#endif
 constexpr int kBlock = 256;  // 4 wavefronts per workgroup; each wavefront traces one 8x8 tile of traced pixels at a time
 #ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 4  // __launch_bounds__ minimum waves per SIMD: 4 workgroups per CU is what the LDS budget admits
@@ -654,6 +658,39 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         // y exists and tested with a scalar branch at the end.  A step is one basic block with two (rare) scalar exits --
         // no VALU -> SALU -> branch round trip sits on the wavefront's critical path.
         unsigned long long ok = __builtin_amdgcn_ballot_w64(!(r2 < U.lo)) & __builtin_amdgcn_ballot_w64(!(r2 > U.hi));
+#if BS_ASM_LOOP
+        // The steps themselves are one assembly statement (fast_loop_asm.h: the arithmetic of rk4_planar_position / rk4_planar_velocity
+        // as compiled, the scalar bookkeeping by hand); it runs until something RARE happens and says what: a guard fired before a step
+        // (ev 0: `go` = the lanes that go on; nothing was stepped) or a step crossed the disk plane somewhere (ev 1: yo / r2o = that step's
+        // y and r^2 before it, the state is the one after it).  The rare work is C++, here; then the statement is entered again.
+        if (amask != 0) {  // a wavefront with no ray at all (records kernel tail) must not enter: the loop only ends on a CHANGE of amask
+            const double lo = U.lo, hi = U.hi, c25 = U.c25, c4375 = U.c4375, m23 = U.m23;
+            for (;;) {
+                double yo, r2o, yb, r2b, t2, t3, t4, t5, t6, t7;
+                unsigned long long go, crossed;
+                int ev;
+                asm volatile(BS_FAST_LOOP_ASM
+                             : [x] "+v"(x), [y] "+v"(y), [wx] "+v"(wx), [wy] "+v"(wy), [r2] "+v"(r2), [yb] "=&v"(yb), [r2b] "=&v"(r2b), [t0] "=&v"(yo),
+                               [t1] "=&v"(r2o), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+                               [ok] "+s"(ok), [it] "+s"(it), [go] "=&s"(go), [crossed] "=&s"(crossed), [ev] "=&s"(ev)
+                             : [c25] "v"(c25), [lo] "v"(lo), [hi] "v"(hi), [thr] "v"(cross_thr), [c4375] "s"(c4375), [m23] "s"(m23),
+                               [maxs] "s"(P.max_steps), [amask] "s"(amask)
+                             : "vcc", "scc");
+                if (ev == 0) {
+                    if (((amask & ~go) >> lane) & 1) {
+                        lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = wx; lds.snap(3) = wy;
+                        lds.fate() = r2 < U.lo ? 0 : (r2 > U.hi ? 1 : 2);  // which guard fired, decided on the very values the guards compared
+                        lds.steps() = it < P.max_steps ? it + 1 : it;
+                    }
+                    amask = go;
+                    if (go == 0) break;
+                } else if (disk && (((amask & crossed) >> lane) & 1)) {
+                    const double unit = lds.snap(5);
+                    record_crossing(P, lds, yo, y, r2o, r2, unit * unit);
+                }
+            }
+        }
+#else
         auto step = [&]() -> bool {
             unsigned long long go = amask & ok;
             if (!(it < P.max_steps)) go = 0;
@@ -689,6 +726,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         };
         if (amask != 0)  // a wavefront with no ray at all (records kernel tail) must not enter: step() only returns false on a CHANGE of amask
             while (step() && step()) {}
+#endif
         // the snapshot is the PRE-step planar state of the terminating iteration (guards precede rk4), in the ray's units
         const double unit = lds.snap(5), vscale = unit / P.h;
         F.to_space(lds.snap(2) * vscale, lds.snap(3) * vscale, v);
