@@ -73,6 +73,37 @@ __global__ __launch_bounds__(256) void ubench_kernel(double *out, int iters, dou
     if (s == 12345.678) out[0] = s;  // keep the chains live without a store on the common path
 }
 
+// More of the same for the question "is there a cheaper seed than v_rsq_f64 (16 cycles)?": kind 9 v_rsq_f32, kind 10 the round trip
+// v_cvt_f32_f64 + v_cvt_f64_f32, kind 11 the whole candidate seed v_cvt_f32_f64 -> v_rsq_f32 -> v_cvt_f64_f32, kind 12 v_rsq_f64 with three
+// independent v_fma_f64 behind each (does anything overlap with the transcendental?).  8 chains per lane, 32 / 32 / 96 / 128 instructions per trip.
+template <int KIND>
+__global__ __launch_bounds__(256) void ubench_asm_kernel(double *out, int iters, double a, double b)
+{
+    double x[8], y[8];
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x[i] = 1.0 + 1e-3 * (threadIdx.x + i); f[i] = (float)x[i]; y[i] = x[i] + 0.5; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if constexpr (KIND == 9) asm volatile("v_rsq_f32 %0, %0" : "+v"(f[i]));
+                if constexpr (KIND == 10 && true) { if (u < 2) asm volatile("v_cvt_f32_f64 %1, %0\n\tv_cvt_f64_f32 %0, %1" : "+v"(x[i]), "+v"(f[i])); }
+                if constexpr (KIND == 11) asm volatile("v_cvt_f32_f64 %1, %0\n\tv_rsq_f32 %1, %1\n\tv_cvt_f64_f32 %0, %1" : "+v"(x[i]), "+v"(f[i]));
+                if constexpr (KIND == 12) {
+                    asm volatile("v_rsq_f64 %0, %0" : "+v"(x[i]));
+                    asm volatile("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(y[i]) : "v"(a), "v"(b));
+                }
+            }
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += x[i] + (double)f[i] + y[i];
+    if (s == 12345.678) out[0] = s;
+}
+
 }  // namespace
 
 int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
@@ -89,6 +120,10 @@ int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
     case 6: hipLaunchKernelGGL((ubench_kernel<0, 2>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     case 7: hipLaunchKernelGGL((ubench_kernel<0, 4>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     case 8: hipLaunchKernelGGL((ubench_kernel<3, 1>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 9: hipLaunchKernelGGL((ubench_asm_kernel<9>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 10: hipLaunchKernelGGL((ubench_asm_kernel<10>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 11: hipLaunchKernelGGL((ubench_asm_kernel<11>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 12: hipLaunchKernelGGL((ubench_asm_kernel<12>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
