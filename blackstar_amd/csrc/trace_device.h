@@ -46,6 +46,16 @@ __device__ __noinline__ double exp_call(double x) { return exp(x); }
 // GHC.Float signum: x>0 -> 1, x<0 -> -1, otherwise x (so signum 0 = 0).
 __device__ __forceinline__ double signum(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 
+// signum a /= signum b for the disk guard (Raytracer.hs:96) as four compares on the lane masks instead of two selects and a compare on
+// doubles (13 VALU -> 4).  For NaN-free operands it IS the reference's test (signum values are 1, -1 and +-0, and +0 == -0).  With a NaN
+// operand the reference's test is true and this one may be false -- but the only consumer then computes r2ave = NaN, which fails both radius
+// compares (:97): no layer either way.
+__device__ __forceinline__ bool signum_differs(double a, double b) { return ((a > 0) != (b > 0)) || ((a < 0) != (b < 0)); }
+
+// "this lane's bit is set in the wave-uniform mask m" as exec &= m (s_and_saveexec: no VALU).  Spelled ((m >> lane) & 1) it costs two v_and,
+// a v_cmp_ne_u64 and two registers holding 1 << lane -- in blocks that run ~30 times per tile of 224 steps.
+__device__ __forceinline__ bool in_mask(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // ---- correctly rounded f64 sqrt / divide without the range scaling -------------------------------------
 // hipcc lowers f64 sqrt and '/' to exactly these FMA sequences wrapped in v_ldexp / v_div_scale /
 // v_div_fixup range handling (only active for |x| < 2^-767 or extreme exponent gaps).  In the RK4 RHS the
@@ -482,7 +492,7 @@ constexpr int kOverflow = 1 << 20;
 // r2, r2n may be in the ray's own units of length (FAST): unit2 = s^2 brings r2ave back (1.0, exact, in STRICT).
 __device__ __forceinline__ void record_crossing(const TraceParams &P, const LaneLds &lds, double y, double yn, double r2, double r2n, double unit2)
 {
-    if (signum(yn) != signum(y)) {
+    if (signum_differs(yn, y)) {
         double r2ave = ((yn * r2 - y * r2n) / (yn - y)) * unit2;  // :102
         if (r2ave > P.in2 && r2ave < P.out2) {           // :97
             int n = lds.count();
@@ -585,7 +595,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
     lds.steps() = 0;
     // The set of lanes still stepping is a wave-uniform 64-bit mask in scalar registers: the guards are two fresh
     // compares whose ballots are ANDed on the scalar unit, "some lane finished" is a scalar compare, and the lane-level
-    // test (amask >> lane) & 1 is evaluated only inside the rare blocks.  (A per-lane bool costs a v_cndmask + v_cmp
+    // test "is this lane in the mask" is taken only inside the rare blocks, as exec &= mask (in_mask: no VALU).  (A per-lane bool costs a v_cndmask + v_cmp
     // round trip per step to turn the loop-carried mask back into a ballot.)  Lanes that are done free-run: their values
     // are never read, and a NaN state cannot enter the crossing block (y*yn <= 0 is false for NaN; the reference's
     // signum test passes NaN on to an r2ave that fails both radius compares, i.e. no layer either way).
@@ -593,7 +603,6 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
     // pair: as a scalar flag it was the one value the allocator spilled and re-read (2 v_readlane) in every step.
     double cross_thr = disk ? 0.0 : -__builtin_inf();
     asm volatile("" : "+v"(cross_thr));
-    const unsigned lane = threadIdx.x & 63u;
     unsigned long long amask = __builtin_amdgcn_ballot_w64(live);
     int it = 0;  // iterations of colorize' entered so far (wave-uniform)
     int fate_code;  // which guard ended the ray: 0 horizon, 1 escape, 2 neither (step cap)
@@ -612,7 +621,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             unsigned long long go = amask & ok;
             if (!(it < P.max_steps)) go = 0;
             if (__builtin_expect(go != amask, 0)) {  // a guard fired somewhere in the wavefront (rare, wave-uniform branch)
-                if (((amask & ~go) >> lane) & 1) {  // this lane: snapshot the state fed to the terminating findColor call
+                if (in_mask(amask & ~go)) {  // this lane: snapshot the state fed to the terminating findColor call
 #pragma unroll
                     for (int i = 0; i < 3; i++) { lds.snap(i) = v[i]; lds.snap(3 + i) = p[i]; }
                     lds.snap(6) = r2;
@@ -630,7 +639,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             rk4_strict_velocity(P, h2c, M, v, nv);
             if (__builtin_expect(crossed != 0, 0)) {
                 asm volatile("" ::"v"(nv[0]), "v"(nv[1]), "v"(nv[2]) : "memory");  // lane test stays here, the whole step stays in front of the branch
-                if (disk && (((amask & crossed) >> lane) & 1)) record_crossing(P, lds, p[1], np[1], r2, r2n, 1.0);
+                if (disk && in_mask(amask & crossed)) record_crossing(P, lds, p[1], np[1], r2, r2n, 1.0);
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) { v[i] = nv[i]; p[i] = np[i]; }
@@ -676,15 +685,22 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
                              : [c25] "v"(c25), [lo] "v"(lo), [hi] "v"(hi), [thr] "v"(cross_thr), [c4375] "s"(c4375), [m23] "s"(m23),
                                [maxs] "s"(P.max_steps), [amask] "s"(amask)
                              : "vcc", "scc");
+                // The statement has VGPR outputs too, and the compiler's divergence analysis then takes ALL its outputs for per-lane values:
+                // amask & ~go would be computed with v_and / v_bfi and read back with v_readfirstlane.  An empty statement whose only output
+                // is an SGPR (tied to its input: no instruction) says "wave-uniform".
+                asm("" : "=s"(go) : "0"(go));
+                asm("" : "=s"(crossed) : "0"(crossed));
+                asm("" : "=s"(ev) : "0"(ev));
+                asm("" : "=s"(it) : "0"(it));
                 if (ev == 0) {
-                    if (((amask & ~go) >> lane) & 1) {
+                    if (in_mask(amask & ~go)) {
                         lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = wx; lds.snap(3) = wy;
                         lds.fate() = r2 < U.lo ? 0 : (r2 > U.hi ? 1 : 2);  // which guard fired, decided on the very values the guards compared
                         lds.steps() = it < P.max_steps ? it + 1 : it;
                     }
                     amask = go;
                     if (go == 0) break;
-                } else if (disk && (((amask & crossed) >> lane) & 1)) {
+                } else if (disk && in_mask(amask & crossed)) {
                     const double unit = lds.snap(5);
                     record_crossing(P, lds, yo, y, r2o, r2, unit * unit);
                 }
@@ -695,7 +711,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
             unsigned long long go = amask & ok;
             if (!(it < P.max_steps)) go = 0;
             if (__builtin_expect(go != amask, 0)) {
-                if (((amask & ~go) >> lane) & 1) {
+                if (in_mask(amask & ~go)) {
                     lds.snap(0) = x; lds.snap(1) = y; lds.snap(2) = wx; lds.snap(3) = wy;
                     lds.fate() = r2 < U.lo ? 0 : (r2 > U.hi ? 1 : 2);  // which guard fired, decided on the very values the guards compared
                     lds.steps() = it < P.max_steps ? it + 1 : it;
@@ -715,7 +731,7 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
                 // keeps the lane test in this rare block; naming the new velocity as an input keeps the whole step in front
                 // of the branch (otherwise stage 4 is sunk below it and the compare -> branch latency is exposed again)
                 asm volatile("" ::"v"(wx), "v"(wy) : "memory");
-                if (disk && (((amask & crossed) >> lane) & 1)) {
+                if (disk && in_mask(amask & crossed)) {
                     const double unit = lds.snap(5);
                     record_crossing(P, lds, yo, y, r2o, r2n, unit * unit);
                 }
