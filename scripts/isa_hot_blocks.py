@@ -1,28 +1,52 @@
 #!/usr/bin/env python3
-"""Per-basic-block instruction mix of the first FAST (or --strict) stepping loop printed by isa_loop_stats.py --dump:
-shows which blocks are the per-step hot path (the big all-f64 ones) and what else sits in them."""
-import re, subprocess, sys, os
+"""Instruction mix of the trace kernels per basic block, from the compiler's own assembly (hipcc cross-compiles: no GPU needed).
+The stepping loops are the blocks with a hundred f64 instructions and more: FAST = `.Lbs_loop` (csrc/fast_loop_asm.h, two steps per trip:
+2 x (62 full-rate f64 VALU + 4 v_rsq_f64), 2 x 7 SALU + the branches), STRICT = the two big blocks of the compiled loop (178 + 4 rsq + 4 rcp
+per step).  These are the numbers `LOOP_VALU` in bench_legs.py carries (`roofline.valu_issue_frac`).
+Usage: isa_hot_blocks.py [--strict] [--all] [extra hipcc flags ...]     (--all: every block with >= 6 VALU, not only the loops)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-mode = "STRICT" if "--strict" in sys.argv else "FAST"
-out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/isa_loop_stats.py"), "--dump"], capture_output=True, text=True).stdout.split("\n")
-starts = [i for i, l in enumerate(out) if l.startswith(mode + ": loop")]
-ends = [i for i, l in enumerate(out) if re.match(r"^(FAST|STRICT): loop", l)] + [len(out)]
-L = out[starts[0]:min(e for e in ends if e > starts[0])]
-blk, cnt, order = None, {}, []
-for l in L:
-    m = re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l)
+flags = [a for a in sys.argv[1:] if a not in ("--strict", "--all")]
+kernel = "trace_frame_kernelILb0" if "--strict" in sys.argv else "trace_frame_kernelILb1"
+with tempfile.TemporaryDirectory() as d:
+    s = os.path.join(d, "k.s")
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DBS_PAD_NOPS=0",
+                           *flags, "--cuda-device-only", "-S", os.path.join(ROOT, "blackstar_amd/csrc/trace_kernel.hip"), "-o", s], stderr=subprocess.DEVNULL)
+    text = open(s).read().split("\n")
+start = next(i for i, l in enumerate(text) if re.match(r"^_Z\S*" + kernel + r"\S*:", l))
+end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+rows, cur = [], None
+for l in text[start:end]:
+    m = re.match(r"^(\.LBB\d+_\d+|; %bb\.\d+|\.Lbs_\w+):", l)
     if m:
-        blk = m.group(1); cnt[blk] = dict(valu=0, f64=0, lane=0, mov=0, salu=0, ds=0, br=[]); order.append(blk); continue
-    if blk and l.startswith("\t") and not l.strip().startswith((";", ".")):
-        op = l.split()[0]; c = cnt[blk]
-        if op.startswith("v_"):
-            c["valu"] += 1
-            if "_f64" in op: c["f64"] += 1
-            if "lane" in op: c["lane"] += 1
-            if op.startswith("v_mov"): c["mov"] += 1
-        elif op.startswith("s_"):
-            c["salu"] += 1
-            if "branch" in op: c["br"].append(l.strip().split()[-1])
-        elif op.startswith("ds_"): c["ds"] += 1
-print(L[0])
-for b in order: print(f"{b:14s}", cnt[b])
+        cur = dict(name=m.group(1).replace("; %", ""), valu=0, f64=0, trans=0, mov=0, salu=0, branch=0, lds=0, vmem=0, depth="")
+        d = re.search(r"Depth=(\d)", l)
+        cur["depth"] = d.group(1) if d else ""
+        rows.append(cur)
+        continue
+    t = l.strip()
+    if cur is None or not t or t[0] in ";.":
+        continue
+    op = t.split()[0]
+    if op.startswith("v_"):
+        cur["valu"] += 1
+        cur["f64"] += "_f64" in op
+        cur["trans"] += bool(re.match(r"v_(rsq|rcp|sqrt|exp|log|sin|cos)_", op))
+        cur["mov"] += op.startswith("v_mov")
+    elif op.startswith("s_"):
+        cur["salu"] += 1
+        cur["branch"] += "branch" in op
+    elif op.startswith("ds_"):
+        cur["lds"] += 1
+    elif op.startswith(("global_", "flat_", "buffer_")):
+        cur["vmem"] += 1
+print(f"{kernel}: {sum(r['valu'] for r in rows)} VALU instructions in {len(rows)} blocks")
+for r in rows:
+    if r["f64"] >= 100 or ("--all" in sys.argv and r["valu"] >= 6):
+        print(f"{r['name']:16s} depth {r['depth'] or '-'}  VALU {r['valu']:3d} (f64 {r['f64']:3d}, of them transcendental {r['trans']:2d}; v_mov {r['mov']})  "
+              f"SALU {r['salu']:3d} (branches {r['branch']})  LDS {r['lds']}  VMEM {r['vmem']}")
