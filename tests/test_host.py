@@ -591,3 +591,31 @@ def test_no_cpp_exception_can_cross_the_c_abi():
     assert bare <= {"bs_abi_version", "bs_last_error", "bs_get_mode", "bs_numa_node"}   # (one-line field reads: nothing in them can throw)
     batch = open(os.path.join(csrc, "batch.cpp")).read()
     assert batch.count("catch (const std::system_error &)") >= 2 and "th.emplace_back(body, c)" in batch   # thread creation failures are handled
+
+
+def test_stepping_loops_are_what_the_roofline_counts():
+    """d: `roofline.valu_issue_frac` prices a wavefront step at LOOP_VALU (bench_legs.py) issue slots.  The compiler's own assembly says what a step
+    is: the FAST loop (csrc/fast_loop_asm.h) is ONE block of two steps with no v_mov in it, the STRICT loop two blocks of one step each; and the
+    Makefile's PAD (scripts/pick_pad.py) puts the FAST loop's head at the start of a 32-byte fetch window.  hipcc cross-compiles: no GPU."""
+    import shutil
+    import subprocess
+    import sys
+    import bench_legs
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+
+    def blocks(*flags):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/isa_hot_blocks.py"), *flags], capture_output=True, text=True, check=True).stdout
+        return [(m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))
+                for m in re.finditer(r"^(\S+)\s+depth \S+\s+VALU\s+(\d+) \(f64\s+(\d+), of them transcendental\s+(\d+); v_mov (\d+)\)", out, re.M)]
+
+    fast = [b for b in blocks() if b[0].startswith(".Lbs_loop")]
+    assert len(fast) == 1, fast
+    lv = bench_legs.LOOP_VALU["fast"]
+    assert fast[0][1:] == (2 * (lv["full_rate"] + lv["quarter_rate"]), 2 * (lv["full_rate"] + lv["quarter_rate"]), 2 * lv["quarter_rate"], 0), fast
+    lv = bench_legs.LOOP_VALU["strict"]
+    strict = [b for b in blocks("--strict") if b[1] == lv["full_rate"] + lv["quarter_rate"] and b[3] == lv["quarter_rate"]]
+    assert len(strict) == 2, strict  # the loop is unrolled by two
+    show = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/pick_pad.py"), "--show"], capture_output=True, text=True, check=True)
+    assert re.search(r"PAD (\d+) puts the head at offset 0\b", show.stderr), show.stderr
+    assert 0 <= int(show.stdout) <= 7
