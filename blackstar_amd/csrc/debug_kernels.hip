@@ -76,6 +76,10 @@ __global__ __launch_bounds__(256) void ubench_kernel(double *out, int iters, dou
 // More of the same for the question "is there a cheaper seed than v_rsq_f64 (16 cycles)?": kind 9 v_rsq_f32, kind 10 the round trip
 // v_cvt_f32_f64 + v_cvt_f64_f32, kind 11 the whole candidate seed v_cvt_f32_f64 -> v_rsq_f32 -> v_cvt_f64_f32, kind 12 v_rsq_f64 with three
 // independent v_fma_f64 behind each (does anything overlap with the transcendental?).  8 chains per lane, 32 / 32 / 96 / 128 instructions per trip.
+// Kind 13: v_mfma_f64_4x4x4_4b_f64 alone (8 independent accumulators, 32 per trip); kind 14: each of them followed by three independent
+// v_fma_f64 (128 per trip) -- does the DP matrix pipe run BESIDE the DP VALU on this chip, i.e. could it serve as a second adder for the
+// uniform-scalar FMAs of a step?  (A measurement for the record: north_star rules MFMA out for this path, and a matrix instruction mixes
+// the lanes of a row, which the free-running finished lanes of the stepping loop would poison with their inf / NaN.)
 template <int KIND>
 __global__ __launch_bounds__(256) void ubench_asm_kernel(double *out, int iters, double a, double b)
 {
@@ -91,6 +95,11 @@ __global__ __launch_bounds__(256) void ubench_asm_kernel(double *out, int iters,
                 if constexpr (KIND == 9) asm volatile("v_rsq_f32 %0, %0" : "+v"(f[i]));
                 if constexpr (KIND == 10 && true) { if (u < 2) asm volatile("v_cvt_f32_f64 %1, %0\n\tv_cvt_f64_f32 %0, %1" : "+v"(x[i]), "+v"(f[i])); }
                 if constexpr (KIND == 11) asm volatile("v_cvt_f32_f64 %1, %0\n\tv_rsq_f32 %1, %1\n\tv_cvt_f64_f32 %0, %1" : "+v"(x[i]), "+v"(f[i]));
+                if constexpr (KIND == 13) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
+                if constexpr (KIND == 14) {
+                    asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
+                    asm volatile("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(y[i]) : "v"(a), "v"(b));
+                }
                 if constexpr (KIND == 12) {
                     asm volatile("v_rsq_f64 %0, %0" : "+v"(x[i]));
                     asm volatile("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(y[i]) : "v"(a), "v"(b));
@@ -98,6 +107,7 @@ __global__ __launch_bounds__(256) void ubench_asm_kernel(double *out, int iters,
             }
         }
     }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // kinds 13 / 14: the matrix pipe's last results before a VALU reads them
     double s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) s += x[i] + (double)f[i] + y[i];
@@ -124,6 +134,8 @@ int launch_ubench(int kind, int blocks, int iters, double *d_out, void *stream)
     case 10: hipLaunchKernelGGL((ubench_asm_kernel<10>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     case 11: hipLaunchKernelGGL((ubench_asm_kernel<11>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     case 12: hipLaunchKernelGGL((ubench_asm_kernel<12>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 13: hipLaunchKernelGGL((ubench_asm_kernel<13>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
+    case 14: hipLaunchKernelGGL((ubench_asm_kernel<14>), g, b, 0, s, d_out, iters, 0.999999, 1e-6); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -29,7 +29,7 @@ for kind, name in enumerate(("v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64",
     res[name] = {"Ginstr_per_s": r, "TFLOPs_if_fma": r * 2 / 1e3, "cycles_per_wave_instr_at_2.4GHz": 256 * 4 * 64 * 2.4 / r}
 # is there a cheaper seed than v_rsq_f64?  (kinds 9-12 of debug_kernels.hip; the library counts 32 instructions per trip, they run 32 / 32 / 96 / 128)
 for kind, name, per_trip, n_seq in ((9, "v_rsq_f32", 32, 1), (10, "v_cvt_f32_f64+v_cvt_f64_f32", 32, 2), (11, "v_cvt_f32_f64+v_rsq_f32+v_cvt_f64_f32", 96, 3),
-                                    (12, "v_rsq_f64+3*v_fma_f64", 128, 4)):
+                                    (12, "v_rsq_f64+3*v_fma_f64", 128, 4), (13, "v_mfma_f64_4x4x4_4b", 32, 1), (14, "v_mfma_f64_4x4x4_4b+3*v_fma_f64", 128, 4)):
     r = run(kind, 256 * 8, 5000) * per_trip / 32
     res[name] = {"Ginstr_per_s": r, "cycles_per_wave_instr_at_2.4GHz": 256 * 4 * 64 * 2.4 / r, "cycles_per_sequence_at_2.4GHz": n_seq * 256 * 4 * 64 * 2.4 / r}
 # dependent-chain latency: N waves per SIMD (N blocks of 256 threads per CU), c chains per lane
