@@ -29,6 +29,7 @@ struct bs_ctx {
     int blocks_per_cu = 4;       // resident workgroups per CU (VGPR/LDS-limited); env BLACKSTAR_BLOCKS_PER_CU for A/B builds
     int stagger_cycles = 16000;  // first-tile phase offset per SIMD slot (env BLACKSTAR_STAGGER overrides; 0 = off)
     int static_first_below = 1 << 20;  // launches of fewer tiles per resident wavefront than this (= every launch) start wavefront g on tile g, without a queue pop (env BLACKSTAR_STATIC_FIRST_BELOW for A/B; 0 = never, as in rounds 1-5)
+    int late_pop_slot = 0;       // wavefronts of residency slots >= this pop their next tile AFTER tracing the current one, not before: 0 = everybody (the product), 4 = nobody (rounds 1-5); env BLACKSTAR_LATE_POP_SLOT for A/B (trace_kernel.hip)
     int stagger_min_tiles = 6;   // ... applied to launches of at least this many tiles per resident wavefront (env BLACKSTAR_STAGGER_MIN_TILES; C2 = 7.9 tiles per wavefront gains 2 %, frames of 3-5 do not)
     size_t n_stars = 0;
     bs::StarNode *d_nodes = nullptr;

@@ -77,6 +77,7 @@ struct TraceParams {
     int32_t blocks_per_slot;     // workgroups per residency slot (= CUs): workgroup b sits in slot b / blocks_per_slot
     int32_t disk_slots;          // LDS crossing-queue depth in use (<= 4; tests shrink it to force the overflow path)
     int32_t queue_base;          // 0: every tile comes off the queue.  4 * grid_blocks: wavefront g of the grid starts on tile g without an atomic and the queue hands out the tiles from there on (short launches: render.cpp fill_params)
+    int32_t late_pop_slot;       // wavefronts of residency slots >= this pop their next tile AFTER tracing the current one (0: all of them -- nobody holds an untouched tile): trace_kernel.hip
     const StarNode *nodes;       // device, n_entries, sorted by cell
     const StarColor *colors;     // device, n_entries
     const uint32_t *cell_start;  // device, kGridCells + 2: entries of cell c are [cell_start[c], cell_start[c+1]); cell kGridCells = origin list

@@ -396,6 +396,7 @@ try {
     if (const char *m = std::getenv("BLACKSTAR_STAGGER")) ctx->stagger_cycles = std::atoi(m);
     if (const char *m = std::getenv("BLACKSTAR_STAGGER_MIN_TILES")) ctx->stagger_min_tiles = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_STATIC_FIRST_BELOW")) ctx->static_first_below = std::max(0, std::atoi(m));
+    if (const char *m = std::getenv("BLACKSTAR_LATE_POP_SLOT")) ctx->late_pop_slot = std::max(0, std::atoi(m));
     if (const char *m = std::getenv("BLACKSTAR_FAST_GUARD")) ctx->fast_guard = std::atoi(m) != 0;
     if (const char *m = std::getenv("BLACKSTAR_FAST_MAX_STEPS")) ctx->fast_max_steps = std::max(0.0, std::atof(m));   // (0: no long-path rule; for measurements)
     if (const char *m = std::getenv("BLACKSTAR_ZERO_COPY")) ctx->zero_copy = std::atoi(m) != 0;

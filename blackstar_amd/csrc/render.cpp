@@ -34,6 +34,7 @@ int fill_params(bs_ctx *ctx, const bs_config *cfg, TraceParams &p, int row0, int
         // wavefront g starts on tile g, no initial pop (trace_kernel.hip; one binary, the knob alone, profiles/r06_static_first_tile_ab.txt: the C3
         // frame 0.9 % faster, default.yaml at 1080p 2.3 %, 640 x 360 15 %, lensing-disk at 4K level)
         p.queue_base = tiles < (long)ctx->static_first_below * waves ? 4 * p.grid_blocks : 0;
+        p.late_pop_slot = ctx->late_pop_slot;
     }
     p.n_entries = (int32_t)ctx->n_entries;
     p.nodes = ctx->d_nodes;

@@ -71,10 +71,20 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     const int n_tiles = tiles_x * ((P.band_t1 - P.band_t0 + 7) >> 3);  // the band's tiles (a whole frame: band = [0, ht))
 
     // phase stagger (performance only): workgroups b, b+#CU, b+2#CU, ... are the ones observed to share a CU
+    const int slot = (int)(blockIdx.x / (unsigned)P.blocks_per_slot);
     if (P.stagger_cycles > 0) {
-        const int slot = (int)(blockIdx.x / (unsigned)P.blocks_per_slot);
         for (int c = 0; c < slot * P.stagger_cycles; c += 64 * 100) __builtin_amdgcn_s_sleep(100);
     }
+    // A wavefront pops its next tile when it has traced the current one -- not before it, as rounds 1-5 did to hide the pop's round trip (~2 us).
+    // A tile popped ahead sits untouched while its owner traces: 35 us for the wavefront its SIMD favours, but under oldest-first arbitration
+    // 0.15 / 0.9 / 4 ms for the three younger ones (C3: 27, 5 and 1-2 tiles per wavefront and frame) -- and the tiles still held like that when the
+    // queue runs dry are started after everybody else has finished: 12 wavefronts working for the last 80 us of a 4.2 ms frame, one of them on a
+    // tile it had owned for a millisecond (scripts/trace_timeline.py -> profiles/r06_late_pop_timeline.txt).  One binary, the knob alone, two
+    // boxes (profiles/r06_late_pop_ab.txt): everybody late (P.late_pop_slot 0, the product) C3 -0.4 ... -0.7 %, default.yaml at 1080p -3.4 %;
+    // only slots 1-3 late: -0.2 % / -4.1 %; only 2-3: -0.2 % / -1.2 %.  (Round 2 had measured exposed pops as a LOSS of 1.4-2.3 % and round 5's
+    // "late pops" chose by the INDEX of the tile being started, which a young wavefront popped a millisecond earlier: both were read against
+    // builds whose loop had landed differently -- EXPERIMENTS.md 6.6.)
+    const bool late_pop = slot >= P.late_pop_slot;
 
     // per-lane statistics summed over this wave's tiles live in LDS (six more registers held across trace_ray spill), as 64-bit
     // words: touched once per tile, never in the stepping loop, and a lane's step total is unbounded in the tiles it traces
@@ -83,9 +93,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
 #pragma unroll
     for (int k = 0; k < 6; k++) stat[k * kBlock] = 0ull;
     unsigned long long a_iters = 0;  // wave-uniform
-    // The queue pop for tile t+1 is issued BEFORE tile t is traced (the returned index is not needed until the next
-    // trip), so the ~1-2 us round trip of the device-scope atomic never stalls the wavefront.  Over-fetching past
-    // the end is harmless: indices >= n_tiles just end the loop.
+    // Over-fetching past the end of the queue is harmless: indices >= n_tiles just end the loop.
     // The FIRST tile needs no atomic (P.queue_base != 0, render.cpp): wavefront g of the grid takes tile g and the queue hands out the tiles
     // from queue_base = the number of wavefronts on.  Rounds 1-5 started every launch with up to 4096 pops on one address before anything
     // was traced: 25-45 us -- 2 % of the reference's default.yaml at 1080p, 15 % of a 640 x 360 frame, 0.9 % of the C3 frame
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
     for (;;) {
         const int tile = __builtin_amdgcn_readfirstlane(next_tile);
         if (tile >= n_tiles) break;
-        if (lane == 0) next_tile = queue_base + (int)atomicAdd(&P.counters[7], 1ull);
+        if (!late_pop && lane == 0) next_tile = queue_base + (int)atomicAdd(&P.counters[7], 1ull);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int xi = tx * 8 + lx, yb = ty * 8 + ly, yi = P.band_t0 + yb;  // yb: traced row within the band (band_t0 is even with supersampling)
         const bool inb = xi < P.wt && yi < P.band_t1;
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(kBlock, BS_MIN_WAVES) void trace_frame_kernel(const
         stat[4 * kBlock] += (unsigned long long)(unsigned)res.disk_hits;
         stat[5 * kBlock] += (unsigned long long)(unsigned)res.star_hits;
         a_iters += w_iters;
+        if (late_pop && lane == 0) next_tile = queue_base + (int)atomicAdd(&P.counters[7], 1ull);
 #ifdef BS_TRACE_PROBE
         probe_t2 = wall_clock64();
         probe_tiles++;
