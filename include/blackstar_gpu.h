@@ -316,7 +316,7 @@ int bs_star_lookup(bs_ctx *ctx, double intensity, double saturation, const doubl
 
 /* Environment read ONCE, at bs_create (A/B switches for measurements; a host application sets none of them): BLACKSTAR_MODE=strict|fast
  * (initial bs_set_mode), BLACKSTAR_POST_CUS (see bs_render_rgb8_batch), BLACKSTAR_ZERO_COPY=0, BLACKSTAR_FAST_GUARD=0, BLACKSTAR_HOST_BANDS,
- * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS, BLACKSTAR_NUMA_BIND=0, BLACKSTAR_FAST_MAX_STEPS. */
+ * BLACKSTAR_STAGGER, BLACKSTAR_STAGGER_MIN_TILES, BLACKSTAR_STATIC_FIRST_BELOW, BLACKSTAR_LATE_POP_SLOT, BLACKSTAR_BLOCKS_PER_CU, BLACKSTAR_POST_PLAN_CUS, BLACKSTAR_BLOOM_PLAN_CUS, BLACKSTAR_NUMA_BIND=0, BLACKSTAR_FAST_MAX_STEPS. */
 int bs_set_mode(bs_ctx *ctx, int mode);           /* BS_MODE_*; default BS_MODE_FAST */
 int bs_get_mode(const bs_ctx *ctx);
 /* The arithmetic a render of `cfg` on this context would be traced with: bs_get_mode(), except that a FAST context traces frames
