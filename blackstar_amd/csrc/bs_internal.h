@@ -56,6 +56,8 @@ struct TraceParams {
     double cam[3];
     double xa[3], ya[3], za[3];  // look-at basis, computed once on the host with the reference's op order
     double fov, W, H;            // traced resolution as doubles (cfg' of Raytracer.hs:63)
+    double inv_W, inv_H;         // 1.0 / W, 1.0 / H correctly rounded (host): generate_ray's divisions by W and H as three instructions each (trace_device.h div_by);
+                                 // both 0 when the camera holds a tiny non-zero number (|x| < 2^-300): the device then divides the compiler's way
     double h, hh, h6;            // stepSize, h/2, h/6
     double hh2, hhh, h2_6;       // FAST mode regrouping: h^2/4, h^2/2, h^2/6
     double e1[3], rcam;          // FAST mode orbital-plane frame: cam/|cam| and |cam|

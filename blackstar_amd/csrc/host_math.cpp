@@ -94,6 +94,17 @@ void host_hsi_to_rgb(double hp, double s, double i, double rgb[3], bool *ok)
     }
 }
 
+// 1 / b correctly rounded, for trace_device.h div_by -- or 0 when b is no divisor div_by may be used with: not finite, outside [2^-300, 2^300],
+// or with a significand of all ones (the one case in which q = RN(a y), r = a - b q, RN(q + r y) can miss the correctly rounded a / b).
+static double exact_reciprocal(double b)
+{
+    if (!(std::fabs(b) >= 0x1p-300 && std::fabs(b) <= 0x1p300)) return 0.0;
+    uint64_t bits;
+    std::memcpy(&bits, &b, sizeof bits);
+    if ((bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull) return 0.0;
+    return 1.0 / b;
+}
+
 bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
 {
     if (c.width <= 0 || c.height <= 0) { err = "resolution must be positive"; return false; }
@@ -138,6 +149,16 @@ bool derive_params(const bs_config &c, TraceParams &p, std::string &err)
     p.out_h = c.height;
     p.W = (double)p.wt;
     p.H = (double)p.ht;
+    {   // trace_device.h div_by: a / b from y = RN(1 / b) in three instructions IS IEEE division unless b's significand is all ones or something
+        // under- / overflows on the way: the reciprocal is handed over only for divisors in [2^-300, 2^300], and for generate_ray only if every
+        // number its numerators are made of (basis, fov) is zero or at least 2^-300 (then no quotient can be subnormal)
+        auto usable = [](double x) { return x == 0.0 || (std::fabs(x) >= 0x1p-300 && std::fabs(x) <= 0x1p300); };
+        bool cam_ok = usable(c.fov) && c.fov != 0.0;
+        for (int i = 0; i < 3; i++) cam_ok = cam_ok && usable(p.xa[i]) && usable(p.ya[i]) && usable(p.za[i]);
+        p.inv_W = cam_ok ? exact_reciprocal(p.W) : 0.0;
+        p.inv_H = cam_ok ? exact_reciprocal(p.H) : 0.0;
+        if (p.inv_W == 0.0 || p.inv_H == 0.0) p.inv_W = p.inv_H = 0.0;
+    }
     p.h = c.step_size;
     p.hh = c.step_size / 2;  // rk4: h / 2, h / 6  (:130-134)
     p.h6 = c.step_size / 6;

@@ -27,6 +27,9 @@
 namespace bs {
 namespace {
 
+#ifndef BS_EXACT_SHORTCUTS
+#define BS_EXACT_SHORTCUTS 1  // generate_ray: divisions by the (wave-uniform) resolution and the normalisation as short correctly-rounded sequences; 0 = the compiler's
+#endif
 #ifndef BS_ASM_LOOP
 #define BS_ASM_LOOP 1  // the FAST stepping loop: 1 = fast_loop_asm.h, 0 = the C++ statement of the same steps (A/B knob, and the readable version)
 #endif
@@ -86,6 +89,34 @@ __device__ __forceinline__ double div_rn(double a, double b)
     double r = __builtin_fma(-b, q, a);
     return __builtin_fma(r, y, q);
 }
+
+// a / b in three instructions when y = the correctly rounded 1 / b is at hand: q = RN(a y) is within an ulp of a / b, r = a - b q is exact in
+// an FMA, and RN(q + r y) is then the correctly rounded quotient (Markstein) -- i.e. the bits of IEEE division, for every b whose significand is
+// not all ones.  Used where b is wave-uniform and its reciprocal comes from the host (the traced width and height: integers <= 2^16;
+// tests/test_host.py checks every x / W, x < W <= 16384 and 65 M random numerators against the CPU's division: none differs).
+__device__ __forceinline__ double div_by(double a, double b, double y)
+{
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// v / s for three numerators and ONE per-lane divisor: the refined reciprocal of div_rn once (rcp + two Newton steps), then div_by's three
+// instructions per quotient -- div_rn's own sequence, which the GPU suite checks against IEEE division (14 instead of 3 x 8 instructions; the
+// compiler's '/' with its range scaling is 3 x 13).
+__device__ __forceinline__ void div3_rn(const double a[3], double b, double out[3])
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[i] = div_by(a[i], b, y);
+}
+
+// Where the bare sequences (sqrt_rn, div_rn, div_by) return IEEE's bits: nothing on the way may under- or overflow.
+__device__ __forceinline__ bool mid_range(double x) { return x >= 0x1p-500 && x <= 0x1p500; }  // false for NaN
 
 // STRICT: c = (1.5*h2) / |pos|^5 with q = quadrance pos given   (Raytracer.hs:127)
 __device__ __forceinline__ double coef_strict(double h2c, double q)
@@ -436,8 +467,18 @@ __device__ __forceinline__ void shade_disk(const TraceParams &P, double r2ave, d
 // generateRay (Raytracer.hs:40-51); look-at basis hoisted to the host (identical arithmetic, once per frame).
 __device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int xi, double v[3])
 {
-    double v0 = P.fov * ((double)xi / P.W - 0.5);
-    double v1 = P.fov * (0.5 - (double)yi / P.H) * P.H / P.W;
+    // the same quotients and root as the reference's (/) and sqrt, bit for bit, in fewer instructions (BS_EXACT_SHORTCUTS=0: the compiler's own):
+    // W and H are wave-uniform with host reciprocals (div_by); l = v0^2 + v1^2 + 1 lies in [1, 1 + fov^2] for every config bs_validate_config
+    // lets through, far from the range where sqrt_rn / div_rn would need the scaling the compiler wraps around them.
+    const bool shortcuts = BS_EXACT_SHORTCUTS && P.inv_W != 0.0;  // wave-uniform: the host found nothing tiny in the camera (host_math.cpp)
+    double v0, v1;
+    if (shortcuts) {
+        v0 = P.fov * (div_by((double)xi, P.W, P.inv_W) - 0.5);
+        v1 = div_by(P.fov * (0.5 - div_by((double)yi, P.H, P.inv_H)) * P.H, P.W, P.inv_W);
+    } else {
+        v0 = P.fov * ((double)xi / P.W - 0.5);
+        v1 = P.fov * (0.5 - (double)yi / P.H) * P.H / P.W;
+    }
     double d[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = (P.xa[i] * v0 + P.ya[i] * v1) + P.za[i];  // (-za_i) * (-1) == za_i exactly
@@ -445,8 +486,12 @@ __device__ __forceinline__ void generate_ray(const TraceParams &P, int yi, int x
     if (fabs(l) <= 1e-12 || fabs(1.0 - l) <= 1e-12) {  // linear.normalize shortcut
         v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
     } else {
-        double s = __builtin_sqrt(l);
-        v[0] = d[0] / s; v[1] = d[1] / s; v[2] = d[2] / s;
+        if (shortcuts && mid_range(l)) {
+            div3_rn(d, sqrt_rn(l), v);
+        } else {
+            double s = __builtin_sqrt(l);
+            v[0] = d[0] / s; v[1] = d[1] / s; v[2] = d[2] / s;
+        }
     }
 }
 

@@ -2099,3 +2099,27 @@ def test_destroy_waits_for_work_enqueued_on_a_callers_stream(catalogue_bytes):
         torch.cuda.synchronize()
     finally:
         ref_tree.close()
+
+
+@pytest.mark.gpu
+def test_generate_rays_short_divisions_are_the_references_at_every_resolution(full_catalogue, oracle):
+    """a3 (round 6): generate_ray divides by the traced width and height with three instructions and a host reciprocal, and normalises with one
+    reciprocal for the three components (csrc/trace_device.h div_by / div3_rn) -- the quotients of the reference's (/) bit for bit.  STRICT's initial
+    directions feed bit-exact trajectories, so terminal vel / pos against the oracle check them on every column and row: odd, prime and
+    power-of-two resolutions, with and without supersampling; and a camera with a component of 1e-305 and a fov of 1e-303, for which the host
+    withholds the reciprocals (csrc/host_math.cpp: quotients could be subnormal) and the device divides the compiler's way."""
+    t, ix = full_catalogue
+    t.set_mode(_lib.BS_MODE_STRICT)
+    rng = np.random.default_rng(20261001)
+    cases = [(w, h, ss, {}) for (w, h, ss) in ((1, 1, False), (3, 7, True), (127, 61, False), (251, 241, True), (1024, 512, True), (1366, 768, False), (4093, 3, True), (8191, 2, False))]
+    cases += [(97, 53, True, dict(fov=1e-303)), (97, 53, False, dict(cam_up=(1e-305, 1.0, 0.0)))]
+    for w, h, ss, over in cases:
+        cfg = dict(scenes.with_res(scenes.DEFAULT_AA, w, h), supersampling=ss, **over)
+        f = 2 if ss else 1
+        n = min(2048, f * w * f * h)
+        ys, xs = rng.integers(0, f * h, n), rng.integers(0, f * w, n)
+        xs[: min(n, f * w)] = np.arange(min(n, f * w))  # every column at least once where they fit
+        orc = oracle.trace_rays(cfg, ix, ys, xs)
+        rec = bs.trace_rays(cfg, t, ys, xs)
+        for k in ("steps", "fate", "disk_hits", "star_hits", "vel", "pos"):
+            assert np.array_equal(rec[k], orc[k]), (w, h, ss, over, k)

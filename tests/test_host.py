@@ -619,3 +619,43 @@ def test_stepping_loops_are_what_the_roofline_counts():
     show = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/pick_pad.py"), "--show"], capture_output=True, text=True, check=True)
     assert re.search(r"PAD (\d+) puts the head at offset 0\b", show.stderr), show.stderr
     assert 0 <= int(show.stdout) <= 7
+
+
+def test_division_by_the_resolution_in_three_instructions_is_ieee_division(tmp_path):
+    """a3: generate_ray divides by the traced width and height (Raytracer.hs:45-46) as q = a y, r = fma(-b, q, a), fma(r, y, q) with y = 1.0 / b
+    from the host (csrc/trace_device.h div_by).  That is the correctly rounded quotient whenever y is the correctly rounded reciprocal and b's
+    significand is not all ones -- checked here against the CPU's own division (same IEEE fma as the device's v_fma_f64): every pixel index over
+    every width up to 4096 and the large ones, and random numerators of every sign and magnitude generate_ray's second division sees."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "divby.c"
+    src.write_text(r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+static double div_by(double a, double b, double y) { double q = a * y; double r = fma(-b, q, a); return fma(r, y, q); }
+static uint64_t s = 0x9E3779B97F4A7C15ull;
+static uint64_t nxt(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+int main(void) {
+    long bad = 0, n = 0;
+    static const int big[] = {5120, 5760, 7680, 8192, 15360, 16384, 30720, 32768, 65535, 65536};
+    for (int k = 0; k < 4096 + 10; k++) {
+        const int W = k < 4096 ? k + 1 : big[k - 4096];
+        const double b = W, y = 1.0 / b;
+        for (int x = 0; x < W; x++, n++) bad += div_by((double)x, b, y) != (double)x / b;
+        for (int j = 0; j < 2000; j++, n++) {
+            const double m = (double)(nxt() >> 11) * 0x1p-53 + 0.5;
+            const double a = ldexp(m, (int)(nxt() % 61) - 30) * ((nxt() & 1) ? 1 : -1);
+            bad += div_by(a, b, y) != a / b;
+        }
+    }
+    printf("%ld %ld\n", n, bad);
+    return 0;
+}
+""")
+    exe = tmp_path / "divby"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"], check=True)
+    n, bad = (int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert n > 15_000_000 and bad == 0, (n, bad)
