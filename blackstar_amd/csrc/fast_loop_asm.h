@@ -6,7 +6,7 @@
 //   * the state is updated IN PLACE, y and r^2 ping-pong between two register pairs across the two copies of the step: no v_mov at all
 //     (the compiled loop carries one v_mov_b64 per step);
 //   * the wavefront's scalar bookkeeping is 7 SALU and two never-taken branches per step (compiled: 13 SALU, three branches that fall
-//     through and one that is taken per step), and the ONLY taken branch is the back edge, once per BS_FL_UNROLL steps;
+//     through and one that is taken per step), and the ONLY taken branch is the back edge, once per two steps;
 //   * the rare events -- some lane's guard fired, some lane crossed the disk plane -- LEAVE the statement: the C++ around it (trace_ray)
 //     snapshots / records and re-enters.  Nothing rare sits between the steps, so where the loop's second step lands is no longer a matter of
 //     what the rare blocks happen to weigh (a 1.5 % lottery per build, profiles/r06_code_alignment_ab.txt).
@@ -24,11 +24,8 @@
 // (trans -> VALU forwarding needs one); SALU reads of VALU-written SGPRs and s_cbranch_vccnz after a v_cmp are interlocked in hardware.
 #pragma once
 
-#ifndef BS_FL_UNROLL
-#define BS_FL_UNROLL 2  // steps per taken branch: 2 or 4
-#endif
-#ifndef BS_FL_EARLY
-#define BS_FL_EARLY 0  // 1: the scalar bookkeeping of the NEXT step issues in the shadow of stage 4 instead of behind it
+#ifndef BS_FL_SERIES
+#define BS_FL_SERIES 1  // stage 1's r^-5 from the previous step's stage 4 by a cubic series where the two radii agree to 2^-15 (95 % of all steps); 0: its own v_rsq_f64, always
 #endif
 
 // go = (it < maxs) ? amask & ok : 0;  SCC = (go != amask)
@@ -116,25 +113,125 @@
     "v_fmac_f64 %[wx], %[m23], %[t1]\n\t"                            \
     "v_fmac_f64 %[wy], %[m23], %[t0]\n\t"
 
-#if BS_FL_EARLY
-#define BS_FL_STEP(Y, R2, YN, R2N) BS_FL_PART1(Y, R2, YN, R2N) BS_FL_SCALAR BS_FL_PART2
+// ---- BS_FL_SERIES: three transcendentals per step instead of four ---------------------------------------------------------------------
+// Stage 4 of a step evaluates r^-5 at the PREDICTED end point p4, stage 1 of the next step at the end point itself: the two squared radii
+// differ by delta = q1 / q4 - 1, 2e-8 in the median of a frame's steps and below 2^-15 in 95 % of them (all but the few steps next to the
+// hole).  There c1 = c4 (1 + delta)^(-5/2) = c4 (1 - 5/2 d + 35/8 d^2 - 105/16 d^3), truncation < 9.1 d^4 < 8e-18: seven full-rate
+// instructions (the difference, its quotient by q4 -- 1 / q4 = y0^2 (1 + e) comes out of stage 4 for one FMA --, the compare, three FMAs,
+// the product) instead of v_rsq_f64 (a quarter of the rate) + 7.  c4 is stage 4's own value, fresh from its v_rsq_f64 every step: nothing
+// accumulates.  If ANY live lane's delta is larger (wave-uniform branch; finished lanes and their NaNs are masked out with amask) the
+// wavefront visits the out-of-line block, which redoes THOSE lanes with the old sequence.  The first step of a ray has no stage 4 behind it: q4 = 1, 1 / q4 = inf
+// make its delta infinite.  62 + 4 -> 63 + 3 per step: 312 -> 300 issue cycles.
+#define BS_FL_PART1S(Y, R2, YN, R2N, TAG)                            \
+    "v_add_f64 %[t2], " R2 ", -%[q4]\n\t"                            \
+    "v_fma_f64 " R2N ", 0.5, %[wx], %[x]\n\t"                        \
+    "v_fma_f64 %[t0], 0.5, %[wy], " Y "\n\t"                         \
+    "v_mul_f64 %[t2], %[t2], %[iq4]\n\t"                             \
+    "v_mul_f64 %[t1], " R2N ", " R2N "\n\t"                          \
+    "v_fmac_f64 %[t1], %[t0], %[t0]\n\t"                             \
+    "v_cmp_lt_f64 vcc, |%[t2]|, %[thr15]\n\t"                        \
+    "v_rsq_f64 %[t3], %[t1]\n\t"                                     \
+    "s_andn2_b64 %[crossed], %[amask], vcc\n\t"                      \
+    "v_fma_f64 %[t4], %[c6], %[t2], %[c4375]\n\t"                    \
+    "v_fma_f64 %[t4], %[t4], %[t2], -%[c25]\n\t"                     \
+    "v_fma_f64 %[t4], %[t4], %[t2], 1.0\n\t"                         \
+    "v_mul_f64 " YN ", %[c4], %[t4]\n\t"                             \
+    "s_cbranch_scc1 .Lbs_slow_" TAG "%=\n"                            \
+    ".Lbs_join_" TAG "%=:\n\t"                                       \
+    "v_fma_f64 %[t4], -" YN ", %[x], " R2N "\n\t"                    \
+    "v_fma_f64 %[t5], -" YN ", " Y ", %[t0]\n\t"                     \
+    "v_mul_f64 %[t6], %[t4], %[t4]\n\t"                              \
+    "v_mul_f64 %[t2], %[t3], %[t3]\n\t"                              \
+    "v_fmac_f64 %[t6], %[t5], %[t5]\n\t"                             \
+    "v_fma_f64 %[t1], -%[t1], %[t2], 1.0\n\t"                        \
+    "v_mul_f64 %[t2], %[t2], %[t2]\n\t"                              \
+    "v_rsq_f64 %[t7], %[t6]\n\t"                                     \
+    "v_mul_f64 %[t2], %[t3], %[t2]\n\t"                              \
+    "v_fma_f64 %[t3], %[c4375], %[t1], %[c25]\n\t"                   \
+    "v_mul_f64 %[t1], %[t1], %[t2]\n\t"                              \
+    "v_fmac_f64 %[t2], %[t1], %[t3]\n\t"                             \
+    "v_mul_f64 %[t1], " R2N ", %[t2]\n\t"                            \
+    "v_mul_f64 " R2N ", %[t7], %[t7]\n\t"                            \
+    "v_mul_f64 %[t0], %[t0], %[t2]\n\t"                              \
+    "v_fma_f64 %[t2], -%[t6], " R2N ", 1.0\n\t"                      \
+    "v_mul_f64 " R2N ", " R2N ", " R2N "\n\t"                        \
+    "v_mul_f64 " R2N ", %[t7], " R2N "\n\t"                          \
+    "v_fma_f64 %[t3], %[c4375], %[t2], %[c25]\n\t"                   \
+    "v_mul_f64 %[t2], %[t2], " R2N "\n\t"                            \
+    "v_fmac_f64 " R2N ", %[t2], %[t3]\n\t"                           \
+    "v_add_f64 %[t2], %[wx], %[x]\n\t"                               \
+    "v_add_f64 %[t3], %[wy], " Y "\n\t"                              \
+    "v_fma_f64 %[t6], -2.0, %[t1], %[t2]\n\t"                        \
+    "v_fmac_f64 %[t1], " R2N ", %[t4]\n\t"                           \
+    "v_fma_f64 %[t7], -2.0, %[t0], %[t3]\n\t"                        \
+    "v_fmac_f64 %[t0], " R2N ", %[t5]\n\t"                           \
+    "v_fma_f64 %[t4], " YN ", %[x], %[t1]\n\t"                       \
+    "v_fma_f64 %[x], %[m23], %[t4], %[t2]\n\t"                       \
+    "v_fma_f64 %[t5], " YN ", " Y ", %[t0]\n\t"                      \
+    "v_mul_f64 " R2N ", %[x], %[x]\n\t"                              \
+    "v_fma_f64 " YN ", %[m23], %[t5], %[t3]\n\t"                     \
+    "v_fmac_f64 " R2N ", " YN ", " YN "\n\t"                         \
+    "v_mul_f64 %[t2], " Y ", " YN "\n\t"                             \
+    "v_cmp_nlt_f64 %[ok], " R2N ", %[lo]\n\t"                        \
+    "v_cmp_ngt_f64 %[go], " R2N ", %[hi]\n\t"                        \
+    "v_cmp_le_f64 vcc, %[t2], %[thr]\n\t"                            \
+    "v_mul_f64 %[q4], %[t6], %[t6]\n\t"                              \
+    "v_fmac_f64 %[q4], %[t7], %[t7]\n\t"                             \
+    "v_rsq_f64 %[t3], %[q4]\n\t"                                     \
+    "v_add_f64 %[t1], %[t1], %[t4]\n\t"                              \
+    "v_add_f64 %[t0], %[t0], %[t5]\n\t"                              \
+    "v_mul_f64 %[t4], %[t3], %[t3]\n\t"                              \
+    "v_fma_f64 %[t2], -%[q4], %[t4], 1.0\n\t"                        \
+    "v_fma_f64 %[iq4], %[t4], %[t2], %[t4]\n\t"                      \
+    "v_mul_f64 %[t4], %[t4], %[t4]\n\t"                              \
+    "v_mul_f64 %[t3], %[t3], %[t4]\n\t"                              \
+    "v_fma_f64 %[t4], %[c4375], %[t2], %[c25]\n\t"                   \
+    "v_mul_f64 %[t2], %[t2], %[t3]\n\t"                              \
+    "v_fma_f64 %[c4], %[t2], %[t4], %[t3]\n\t"                       \
+    "v_fmac_f64 %[t1], %[c4], %[t6]\n\t"                             \
+    "v_fmac_f64 %[t0], %[c4], %[t7]\n\t"                             \
+    "v_fmac_f64 %[wx], %[m23], %[t1]\n\t"                            \
+    "v_fmac_f64 %[wy], %[m23], %[t0]\n\t"
+
+// The out-of-line stage 1 for the LANES whose radius has moved too far from the previous stage 4's (vcc = the lanes that are fine): the old
+// sequence, same bits as without BS_FL_SERIES, under exec &= ~vcc -- the other lanes keep their series value.  Which of the two a ray gets is
+// decided by the ray's own delta alone: its result does not depend on the rays that share its wavefront (row bands, split frames and
+// whole frames must stay bit-identical).
+#define BS_FL_SLOW(R2, YN, TAG)                                      \
+    ".Lbs_slow_" TAG "%=:\n\t"                                       \
+    "s_mov_b64 %[crossed], exec\n\t"                                 \
+    "s_andn2_b64 exec, exec, vcc\n\t"                                \
+    "v_rsq_f64 " YN ", " R2 "\n\t"                                   \
+    "s_nop 0\n\t"                                                    \
+    "v_mul_f64 %[t4], " YN ", " YN "\n\t"                            \
+    "v_fma_f64 %[t2], -" R2 ", %[t4], 1.0\n\t"                       \
+    "v_mul_f64 %[t4], %[t4], %[t4]\n\t"                              \
+    "v_mul_f64 " YN ", " YN ", %[t4]\n\t"                            \
+    "v_fma_f64 %[t4], %[c4375], %[t2], %[c25]\n\t"                   \
+    "v_mul_f64 %[t2], %[t2], " YN "\n\t"                             \
+    "v_fmac_f64 " YN ", %[t2], %[t4]\n\t"                            \
+    "s_mov_b64 exec, %[crossed]\n\t"                                 \
+    "s_branch .Lbs_join_" TAG "%=\n"
+
+#if BS_FL_SERIES
+#define BS_FL_STEP(Y, R2, YN, R2N, TAG) BS_FL_PART1S(Y, R2, YN, R2N, TAG) BS_FL_SCALAR
 #else
-#define BS_FL_STEP(Y, R2, YN, R2N) BS_FL_PART1(Y, R2, YN, R2N) BS_FL_PART2 BS_FL_SCALAR
+#define BS_FL_STEP(Y, R2, YN, R2N, TAG) BS_FL_PART1(Y, R2, YN, R2N) BS_FL_PART2 BS_FL_SCALAR
 #endif
 
 // step A: (y, r2) -> (yb, r2b); step B: back.  After each: leave if the step crossed, leave (before stepping) if the next step's guards fire.
-#define BS_FL_PAIR                                                   \
-    BS_FL_STEP("%[y]", "%[r2]", "%[yb]", "%[r2b]")                   \
+#define BS_FL_BODY                                                   \
+    BS_FL_STEP("%[y]", "%[r2]", "%[yb]", "%[r2b]", "a")              \
     "s_cbranch_vccnz .Lbs_cross_a%=\n\t"                             \
     "s_cbranch_scc1 .Lbs_guard_b%=\n\t"                              \
-    BS_FL_STEP("%[yb]", "%[r2b]", "%[y]", "%[r2]")                   \
+    BS_FL_STEP("%[yb]", "%[r2b]", "%[y]", "%[r2]", "b")              \
     "s_cbranch_vccnz .Lbs_cross_b%=\n\t"                             \
     "s_cbranch_scc1 .Lbs_guard_a%=\n\t"
 
-#if BS_FL_UNROLL == 4
-#define BS_FL_BODY BS_FL_PAIR BS_FL_PAIR
+#if BS_FL_SERIES
+#define BS_FL_SLOW_BLOCKS BS_FL_SLOW("%[r2]", "%[yb]", "a") BS_FL_SLOW("%[r2b]", "%[y]", "b")
 #else
-#define BS_FL_BODY BS_FL_PAIR
+#define BS_FL_SLOW_BLOCKS
 #endif
 
 #define BS_FAST_LOOP_ASM                                             \
@@ -143,6 +240,7 @@
     ".Lbs_loop%=:\n\t"                                               \
     BS_FL_BODY                                                       \
     "s_branch .Lbs_loop%=\n"                                         \
+    BS_FL_SLOW_BLOCKS                                                \
     ".Lbs_cross_a%=:\n\t"                                            \
     "v_mov_b64 %[t0], %[y]\n\t"                                      \
     "v_mov_b64 %[t1], %[r2]\n\t"                                     \

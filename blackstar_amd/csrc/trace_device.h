@@ -719,6 +719,12 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
         // y and r^2 before it, the state is the one after it).  The rare work is C++, here; then the statement is entered again.
         if (amask != 0) {  // a wavefront with no ray at all (records kernel tail) must not enter: the loop only ends on a CHANGE of amask
             const double lo = U.lo, hi = U.hi, c25 = U.c25, c4375 = U.c4375, m23 = U.m23;
+#if BS_FL_SERIES
+            // stage 4's squared radius, its reciprocal and r^-5, carried from step to step (fast_loop_asm.h BS_FL_SERIES); none yet: 1 / q4 = inf
+            // makes the first step's delta infinite, i.e. the step takes its own v_rsq_f64
+            double q4s = 1.0, iq4s = __builtin_inf(), c4s = 0.0, c6 = -6.5625;
+            asm volatile("" : "+v"(c6));
+#endif
             for (;;) {
                 double yo, r2o, yb, r2b, t2, t3, t4, t5, t6, t7;
                 unsigned long long go, crossed;
@@ -726,8 +732,14 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
                 asm volatile(BS_FAST_LOOP_ASM
                              : [x] "+v"(x), [y] "+v"(y), [wx] "+v"(wx), [wy] "+v"(wy), [r2] "+v"(r2), [yb] "=&v"(yb), [r2b] "=&v"(r2b), [t0] "=&v"(yo),
                                [t1] "=&v"(r2o), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+#if BS_FL_SERIES
+                               [q4] "+v"(q4s), [iq4] "+v"(iq4s), [c4] "+v"(c4s),
+#endif
                                [ok] "+s"(ok), [it] "+s"(it), [go] "=&s"(go), [crossed] "=&s"(crossed), [ev] "=&s"(ev)
                              : [c25] "v"(c25), [lo] "v"(lo), [hi] "v"(hi), [thr] "v"(cross_thr), [c4375] "s"(c4375), [m23] "s"(m23),
+#if BS_FL_SERIES
+                               [c6] "v"(c6), [thr15] "s"(0x1p-15),
+#endif
                                [maxs] "s"(P.max_steps), [amask] "s"(amask)
                              : "vcc", "scc");
                 // The statement has VGPR outputs too, and the compiler's divergence analysis then takes ALL its outputs for per-lane values:

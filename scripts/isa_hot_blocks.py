@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Instruction mix of the trace kernels per basic block, from the compiler's own assembly (hipcc cross-compiles: no GPU needed).
-The stepping loops are the blocks with a hundred f64 instructions and more: FAST = `.Lbs_loop` (csrc/fast_loop_asm.h, two steps per trip:
-2 x (62 full-rate f64 VALU + 4 v_rsq_f64), 2 x 7 SALU + the branches), STRICT = the two big blocks of the compiled loop (178 + 4 rsq + 4 rcp
-per step).  These are the numbers `LOOP_VALU` in bench_legs.py carries (`roofline.valu_issue_frac`).
+The stepping loops are the blocks with a hundred f64 instructions and more: FAST = FAST_LOOP_IN_LINE, the sum of `.Lbs_loop` and its join blocks
+(csrc/fast_loop_asm.h, two steps per trip: 2 x (63 full-rate f64 VALU + 3 v_rsq_f64), 2 x 8 SALU + the branches; `.Lbs_slow_*` = the out-of-line
+stage 1 with its own v_rsq_f64 that one step in twenty visits), STRICT = the two big blocks of the compiled loop (178 + 4 rsq + 4 rcp per step).  These are the numbers `LOOP_VALU` in bench_legs.py carries (`roofline.valu_issue_frac`).
 Usage: isa_hot_blocks.py [--strict] [--all] [extra hipcc flags ...]     (--all: every block with >= 6 VALU, not only the loops)"""
 import os
 import re
@@ -46,7 +46,14 @@ for l in text[start:end]:
     elif op.startswith(("global_", "flat_", "buffer_")):
         cur["vmem"] += 1
 print(f"{kernel}: {sum(r['valu'] for r in rows)} VALU instructions in {len(rows)} blocks")
+# the assembly stepping loop is several blocks (its join labels split it): add them up -- in line = .Lbs_loop up to the first out-of-line block
+names = [r["name"] for r in rows]
+lo = next((i for i, n in enumerate(names) if n.startswith(".Lbs_loop")), None)
+if lo is not None:
+    hi = next((i for i in range(lo, len(rows)) if names[i].startswith((".Lbs_slow", ".Lbs_cross"))), len(rows))
+    tot = {k: sum(r[k] for r in rows[lo:hi]) for k in ("valu", "f64", "trans", "mov", "salu", "branch", "lds", "vmem")}
+    rows.append(dict(name="FAST_LOOP_IN_LINE", depth="", **tot))
 for r in rows:
-    if r["f64"] >= 100 or ("--all" in sys.argv and r["valu"] >= 6):
+    if r["f64"] >= 100 or r["name"].startswith(".Lbs_slow") or ("--all" in sys.argv and r["valu"] >= 6):
         print(f"{r['name']:16s} depth {r['depth'] or '-'}  VALU {r['valu']:3d} (f64 {r['f64']:3d}, of them transcendental {r['trans']:2d}; v_mov {r['mov']})  "
               f"SALU {r['salu']:3d} (branches {r['branch']})  LDS {r['lds']}  VMEM {r['vmem']}")

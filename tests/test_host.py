@@ -595,7 +595,7 @@ def test_no_cpp_exception_can_cross_the_c_abi():
 
 def test_stepping_loops_are_what_the_roofline_counts():
     """d: `roofline.valu_issue_frac` prices a wavefront step at LOOP_VALU (bench_legs.py) issue slots.  The compiler's own assembly says what a step
-    is: the FAST loop (csrc/fast_loop_asm.h) is ONE block of two steps with no v_mov in it, the STRICT loop two blocks of one step each; and the
+    is: the FAST loop (csrc/fast_loop_asm.h) is two steps in line with no v_mov in them (plus an out-of-line block per step), the STRICT loop two blocks of one step each; and the
     Makefile's PAD (scripts/pick_pad.py) puts the FAST loop's head at the start of a 32-byte fetch window.  hipcc cross-compiles: no GPU."""
     import shutil
     import subprocess
@@ -609,10 +609,13 @@ def test_stepping_loops_are_what_the_roofline_counts():
         return [(m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))
                 for m in re.finditer(r"^(\S+)\s+depth \S+\s+VALU\s+(\d+) \(f64\s+(\d+), of them transcendental\s+(\d+); v_mov (\d+)\)", out, re.M)]
 
-    fast = [b for b in blocks() if b[0].startswith(".Lbs_loop")]
+    every = blocks()
+    fast = [b for b in every if b[0] == "FAST_LOOP_IN_LINE"]  # .Lbs_loop and its join blocks added up (scripts/isa_hot_blocks.py)
     assert len(fast) == 1, fast
     lv = bench_legs.LOOP_VALU["fast"]
     assert fast[0][1:] == (2 * (lv["full_rate"] + lv["quarter_rate"]), 2 * (lv["full_rate"] + lv["quarter_rate"]), 2 * lv["quarter_rate"], 0), fast
+    slow = [b for b in every if b[0].startswith(".Lbs_slow")]  # the out-of-line stage 1 (own v_rsq_f64), one per copy of the step
+    assert len(slow) == 2 and all(b[1:] == (8, 8, 1, 0) for b in slow), slow
     lv = bench_legs.LOOP_VALU["strict"]
     strict = [b for b in blocks("--strict") if b[1] == lv["full_rate"] + lv["quarter_rate"] and b[3] == lv["quarter_rate"]]
     assert len(strict) == 2, strict  # the loop is unrolled by two
