@@ -1,8 +1,9 @@
 // fast_loop_asm.h -- the FAST stepping loop of trace_ray<true> spelled in gfx950 assembly (one extended-asm statement).
 //
 // The arithmetic is rk4_planar_position + rk4_planar_velocity of trace_device.h, instruction for instruction what hipcc makes of them
-// (66 f64 VALU per step, 4 of them v_rsq_f64); what is written by hand is everything AROUND the arithmetic, which the compiler cannot be
-// talked into (profiles/EXPERIMENTS.md 1.2, 6.6):
+// (66 f64 VALU per step, 4 of them v_rsq_f64; with BS_FL_SERIES, below, stage 1 gets its r^-5 from the previous step's stage 4 instead:
+// 63 + 3); what is written by hand is everything AROUND the arithmetic, which the compiler cannot be talked into
+// (profiles/EXPERIMENTS.md 1.2, 6.6):
 //   * the state is updated IN PLACE, y and r^2 ping-pong between two register pairs across the two copies of the step: no v_mov at all
 //     (the compiled loop carries one v_mov_b64 per step);
 //   * the wavefront's scalar bookkeeping is 7 SALU and two never-taken branches per step (compiled: 13 SALU, three branches that fall
@@ -16,6 +17,7 @@
 //   VGPR scratch yb, r2b, t0..t7       "=&v"  on a crossing exit t0 = y and t1 = r^2 BEFORE the step that crossed
 //   VGPR consts  c25, lo, hi, thr      "v"    2.5; the per-lane guard thresholds; the crossing threshold (0 or -inf)
 //   SGPR consts  c4375, m23, maxs, amask
+//   BS_FL_SERIES q4, iq4, c4 "+v" (stage 4's squared radius, its reciprocal, its r^-5: carried from step to step), c6 "v" (-105/16), thr15 "s" (2^-15)
 //   SGPR state   ok "+s" (guards of the state about to be stepped), it "+s"
 //   SGPR out     go (the lanes that go on), crossed (the crossing ballot), ev (0: a guard fired BEFORE a step, nothing stepped; 1: a step crossed)
 // Clobbers vcc, scc.  exec is not touched: the steps run unmasked (finished lanes free-run, trace_device.h "per-lane LDS scratch").
