@@ -31,7 +31,8 @@ namespace {
 #define BS_EXACT_SHORTCUTS 1  // generate_ray: divisions by the (wave-uniform) resolution and the normalisation as short correctly-rounded sequences; 0 = the compiler's
 #endif
 #ifndef BS_ASM_LOOP
-#define BS_ASM_LOOP 1  // the FAST stepping loop: 1 = fast_loop_asm.h, 0 = the C++ statement of the same steps (A/B knob, and the readable version)
+#define BS_ASM_LOOP 1  // the FAST stepping loop: 1 = fast_loop_asm.h, 0 = the C++ statement of the same steps (A/B knob, and the readable version; the same bits as
+                       // the assembly built with -DBS_FL_SERIES=0)
 #endif
 constexpr int kBlock = 256;  // 4 wavefronts per workgroup; each wavefront traces one 8x8 tile of traced pixels at a time
 #ifndef BS_MIN_WAVES

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Bit-identity of two builds of the trace kernel (the assembly stepping loop against the C++ statement of the same steps, BS_ASM_LOOP=0):
+"""Bit-identity of two builds of the trace kernel (the assembly stepping loop -- built with -DBS_FL_SERIES=0, the series variant moves FAST by up to
+4.5e-10 -- against the C++ statement of the same steps, -DBS_ASM_LOOP=0; or any two builds that should not differ in a bit):
 prints one sha256 per frame over the FAST image bytes and the statistics -- the nine scene files the reference ships at 480 x 270 (with and
 without supersampling), N random fuzz scenes on the clustered sky (degenerate geometries, disks inside the photon sphere, tiny disk queues
 via long orbits), and the C3 frame at full size.  Run it once per library and diff the outputs:
