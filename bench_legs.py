@@ -20,9 +20,9 @@ PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X FP64 vector, FMA = 2 flop (= 1/2 of the g
 PEAK_HBM_GBS = 8000.0
 # VALU instructions the stepping loop issues per RK4 step of a wavefront (ISA count, scripts/isa_hot_blocks.py; static):
 # full-rate f64 ops and quarter-rate transcendental seeds (v_rsq_f64 / v_rcp_f64 occupy the pipe for 4 issue slots).  FAST: the in-line path
-# of csrc/fast_loop_asm.h (stage 1's r^-5 from the previous stage 4 by a series); the one step in twenty that visits the out-of-line block
-# (7 more + 1 seed) is not counted, so valu_issue_frac UNDER-states the issue rate by about 0.6 %.
-LOOP_VALU = {"fast": {"full_rate": 63, "quarter_rate": 3}, "strict": {"full_rate": 178, "quarter_rate": 8}}
+# of csrc/fast_loop_asm.h (the r^-5 of stages 1 and 3 from a neighbouring evaluation by a series); the few steps per hundred that visit an
+# out-of-line block (7 more + 1 seed each) are not counted, so valu_issue_frac UNDER-states the issue rate by about 1 %.
+LOOP_VALU = {"fast": {"full_rate": 65, "quarter_rate": 2}, "strict": {"full_rate": 178, "quarter_rate": 8}}
 WORKLOAD_C3 = ("scenes/default-aa.yaml 1920x1080, 4x supersample (8,294,400 rays/frame), {cat}, "
                "direction-grid star lookup (BASELINE configs[2])")
 WORKLOAD_C5 = ("animations/default-ani.yaml, nFrames=600, 1920x1080, 4x supersample, {cat}, "

@@ -728,6 +728,9 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
 #endif
             for (;;) {
                 double yo, r2o, yb, r2b, t2, t3, t4, t5, t6, t7;
+#if BS_FL_SERIES == 2
+                double t8;
+#endif
                 unsigned long long go, crossed;
                 int ev;
                 asm volatile(BS_FAST_LOOP_ASM
@@ -736,10 +739,16 @@ __device__ __forceinline__ void trace_ray(const TraceParams &P, const LaneLds &l
 #if BS_FL_SERIES
                                [q4] "+v"(q4s), [iq4] "+v"(iq4s), [c4] "+v"(c4s),
 #endif
+#if BS_FL_SERIES == 2
+                               [t8] "=&v"(t8),
+#endif
                                [ok] "+s"(ok), [it] "+s"(it), [go] "=&s"(go), [crossed] "=&s"(crossed), [ev] "=&s"(ev)
                              : [c25] "v"(c25), [lo] "v"(lo), [hi] "v"(hi), [thr] "v"(cross_thr), [c4375] "s"(c4375), [m23] "s"(m23),
 #if BS_FL_SERIES
                                [c6] "v"(c6), [thr15] "s"(0x1p-15),
+#endif
+#if BS_FL_SERIES == 2
+                               [c8] "s"(9.0234375), [thr12] "s"(0x1p-12),
 #endif
                                [maxs] "s"(P.max_steps), [amask] "s"(amask)
                              : "vcc", "scc");
