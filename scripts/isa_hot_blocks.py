@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Instruction mix of the trace kernels per basic block, from the compiler's own assembly (hipcc cross-compiles: no GPU needed).
 The stepping loops are the blocks with a hundred f64 instructions and more: FAST = FAST_LOOP_IN_LINE, the sum of `.Lbs_loop` and its join blocks
-(csrc/fast_loop_asm.h, two steps per trip: 2 x (63 full-rate f64 VALU + 3 v_rsq_f64), 2 x 8 SALU + the branches; `.Lbs_slow_*` = the out-of-line
-stage 1 with its own v_rsq_f64 that one step in twenty visits), STRICT = the two big blocks of the compiled loop (178 + 4 rsq + 4 rcp per step).  These are the numbers `LOOP_VALU` in bench_legs.py carries (`roofline.valu_issue_frac`).
+(csrc/fast_loop_asm.h, two steps per trip: 2 x (65 full-rate f64 VALU + 2 v_rsq_f64), 2 x 9 SALU + the branches; `.Lbs_slow*` = the out-of-line
+stages 1 and 3 with their own v_rsq_f64 that a few steps per hundred visit), STRICT = the two big blocks of the compiled loop (178 + 4 rsq + 4 rcp per step).  These are the numbers `LOOP_VALU` in bench_legs.py carries (`roofline.valu_issue_frac`).
 Usage: isa_hot_blocks.py [--strict] [--all] [extra hipcc flags ...]     (--all: every block with >= 6 VALU, not only the loops)"""
 import os
 import re
